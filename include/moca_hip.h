@@ -1,0 +1,193 @@
+/*
+ * moca_hip.h -- C-ABI of libmoca_hip.so: the MI355X (gfx950) kernels behind the
+ * MoCA-Video / VideoCrafter2 denoising hot path.
+ *
+ * Every entry point takes raw device pointers, sizes and a hipStream_t (as void*),
+ * launches asynchronously on that stream and returns 0 on success or a negative
+ * MOCA_E_* code.  No torch types appear here: the Python host
+ * (moca_video_amd/lib.py) binds these with ctypes, exactly as a maintainer of the
+ * reference would.
+ *
+ * The reference (ZhangT-tech/MoCA-Video) has no native code; each entry point
+ * cites the reference Python op(s) it replaces (file:line under the reference
+ * root).  Activations are channels-last fp16: a feature map of B videos x T
+ * frames is stored as [B*T][H][W][C] ("NHWC, frame outermost").
+ */
+#ifndef MOCA_HIP_H
+#define MOCA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOCA_OK            0
+#define MOCA_E_BADARG     -1   /* shape/alignment contract violated              */
+#define MOCA_E_LAUNCH     -2   /* hipLaunchKernel / runtime error                */
+#define MOCA_E_NODEVICE   -3   /* no gfx950 device visible                       */
+#define MOCA_E_GRAPH      -4   /* stream capture / graph replay failed           */
+
+/* ---- implicit-GEMM: conv2d 3x3, temporal conv (3,1,1), linear ------------- */
+/* A-operand gather modes */
+#define MOCA_A_LINEAR   0  /* A[m][k] = a[m*lda + k]                                       */
+#define MOCA_A_CONV3X3  1  /* k=(ky,kx,c): a[f][oy*s+ky-1][ox*s+kx-1][c], zero padded;      */
+                           /* with up=1 the source is read through a nearest x2 upsample     */
+#define MOCA_A_TCONV3   2  /* k=(kt,c): a[b][t+kt-1][pix][c], zero padded along t            */
+
+/* epilogue flags */
+#define MOCA_EP_GEGLU   1  /* out[m][j] = v[m][j] * gelu(g[m][j]); W rows are packed in     */
+                           /* 64-row groups: 32 value rows then their 32 gate rows           */
+#define MOCA_EP_OUT_F32 2  /* out is float32 instead of fp16                                 */
+
+typedef struct moca_gemm_params {
+    const void* a;         /* fp16 activations (gather source)                              */
+    const void* w;         /* fp16 weights [N][ldw], K-contiguous, zero padded to ldw       */
+    void*       out;       /* [M][ldo] fp16 (or f32 with MOCA_EP_OUT_F32)                   */
+    const float* bias;     /* [N] f32 or NULL (packed like W for GEGLU)                     */
+    const void* rowadd;    /* fp16 [M/rowadd_div][ld_rowadd] added per row group, or NULL   */
+    const void* residual;  /* fp16 [M][ldr] added last, or NULL                             */
+    float*      splitk_ws; /* f32 workspace [splits][M][N] when splits > 1                  */
+    int32_t M, N, K;       /* logical sizes; N % 64 == 0, K % 8 == 0                        */
+    int32_t lda, ldw, ldo, ldr, ld_rowadd;
+    int32_t rowadd_div;    /* rows per rowadd group (H*W of the output map)                 */
+    int32_t a_mode;
+    int32_t C;             /* channels per tap (conv modes), C % 8 == 0                     */
+    int32_t inH, inW;      /* stored source map (before the optional x2 upsample)           */
+    int32_t outH, outW;    /* output map                                                    */
+    int32_t stride;        /* 1 or 2                                                        */
+    int32_t up;            /* 1: nearest x2 upsample fused into the gather                  */
+    int32_t T;             /* frames per video (A_TCONV3)                                   */
+    int32_t HW;            /* pixels per frame (A_TCONV3)                                   */
+    int32_t flags;         /* MOCA_EP_*                                                     */
+    int32_t splits;        /* split-K factor (>=1)                                          */
+} moca_gemm_params;
+
+/* Replaces F.conv2d 3x3 (openaimodel3d.py:152,177,66-70,96-106,376,531),
+ * nn.Conv3d (3,1,1) (openaimodel3d.py:252-263) and every nn.Linear on the path
+ * (attention.py:54-57,242,258,302,328,379,399; openaimodel3d.py:166-172,362-372),
+ * with the bias / time-embedding add (openaimodel3d.py:217-226) / residual add
+ * (openaimodel3d.py:228,276; attention.py:217-219,278,373) / GEGLU
+ * (attention.py:381-383) folded into the epilogue.                              */
+int moca_gemm_f16(const moca_gemm_params* p, void* stream);
+/* bytes of split-K workspace moca_gemm_f16 needs for (M,N,splits) */
+int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits);
+
+/* ---- normalisation --------------------------------------------------------- */
+/* GroupNorm(32 groups) over channels-last fp16 x[F][HW][C], statistics over
+ * frames_per_stat consecutive frames (1: per-frame 4-D GroupNorm; T: the 5-D
+ * GroupNorm of TemporalConvBlock / TemporalTransformer), fp32 statistics, optional
+ * SiLU.  ws: f32 workspace of moca_groupnorm_ws_bytes().
+ * Replaces GroupNormSpecific (basics.py:76-87), nn.GroupNorm(32,C,eps=1e-6)
+ * (attention.py:238,297), nn.GroupNorm(32,C)+SiLU (openaimodel3d.py:253-262).   */
+int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma, const float* beta,
+                            int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
+                            float eps, int32_t silu, float* ws, void* stream);
+int64_t moca_groupnorm_ws_bytes(int32_t F, int32_t HW, int32_t C);
+
+/* LayerNorm over the last dim of fp16 x[M][C] (eps 1e-5): attention.py:199-201 */
+int moca_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta,
+                       int32_t M, int32_t C, float eps, void* stream);
+
+/* ---- attention --------------------------------------------------------------- */
+/* softmax(Q K^T * scale) V, head dim 64, fp16 in/out, fp32 softmax.
+ * q: [Bq][Nq][ldq] with head h at column h*64 of the q block; k, v likewise with
+ * row strides ldk, ldv; kv batch index = q batch index / kv_div (cross-attention
+ * shares one context per video: openaimodel3d.py:547).  out: [Bq][Nq][ldo].
+ * Replaces CrossAttention.forward (attention.py:92-114) in its spatial self /
+ * spatial cross roles.                                                           */
+int moca_attention_f16(const void* q, const void* k, const void* v, void* out,
+                       int32_t Bq, int32_t heads, int32_t Nq, int32_t Nk,
+                       int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                       int32_t kv_div, float scale, void* stream);
+
+/* Temporal self-attention over the frame axis: for every (video b, pixel p, head h)
+ * attend over the T (<=16) frames.  qkv rows are channels-last tokens
+ * [(b*T+t)*HW + p][ld]; q/k/v point at their first column.  Replaces
+ * CrossAttention.forward inside TemporalTransformer (attention.py:331-352) incl.
+ * the (b t) c h w <-> (b h w) t c reshuffles (attention.py:335-338,367).          */
+int moca_temporal_attention_f16(const void* q, const void* k, const void* v, void* out,
+                                int32_t B, int32_t T, int32_t HW, int32_t heads,
+                                int32_t ld_qkv, int32_t ldo, float scale, void* stream);
+
+/* ---- layout / embedding helpers ----------------------------------------------- */
+/* x [B][Cin][T][H][W] (f32 or f16) -> channels-last fp16 [B*T][H*W][Cpad], zero padded
+ * (openaimodel3d.py:552-554) */
+int moca_ncthw_to_nhwc_f16(const void* x, int32_t x_is_f32, void* y, int32_t B, int32_t Cin,
+                           int32_t T, int32_t HW, int32_t Cpad, void* stream);
+/* channels-last fp16 [B*T][H*W][ld] (first Cout columns) -> [B][Cout][T][H][W] f32/f16
+ * (openaimodel3d.py:573-577) */
+int moca_nhwc_to_ncthw(const void* y, int32_t ld, void* x, int32_t x_is_f32, int32_t B,
+                       int32_t Cout, int32_t T, int32_t HW, void* stream);
+/* out[r][0:C1] = a[r], out[r][C1:C1+C2] = b[r]  (torch.cat(dim=1), openaimodel3d.py:571) */
+int moca_concat_channels_f16(const void* a, const void* b, void* out, int64_t rows,
+                             int32_t C1, int32_t C2, void* stream);
+/* sinusoidal embedding [n][dim] fp16 = [cos(t f_k), sin(t f_k)] (utils_diffusion.py:8-28);
+ * t is int64 on device */
+int moca_timestep_embedding_f16(const int64_t* t, void* out, int32_t n, int32_t dim,
+                                float max_period, void* stream);
+/* y = silu(x) (+ broadcasting helper for the embedding MLPs): out[i][:] = silu(a[i/div_a] + b[i/div_b]) */
+int moca_silu_add_rows_f16(const void* a, int32_t div_a, const void* b, int32_t div_b, void* out,
+                           int32_t rows, int32_t C, int32_t apply_silu, void* stream);
+
+/* ---- sampler arithmetic (fp32) -------------------------------------------------- */
+/* e = e_u + s (e_c - e_u): ddim.py:304,372 */
+int moca_cfg_combine_f32(const float* e_c, const float* e_u, float* out, float scale,
+                         int64_t n, void* stream);
+/* base DDIM update with use_scale (ddim.py:328-357): per-element
+ *   pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t) [/ scale_t];
+ *   x_prev = sqrt(a_prev) [scale_prev] pred_x0 + sqrt(1-a_prev-sigma^2) e + sigma*noise  */
+int moca_ddim_update_f32(const float* x, const float* e, const float* noise, float* x_prev,
+                         float* pred_x0, float a_t, float a_prev, float sigma_t,
+                         float sqrt_one_minus_at, int32_t use_scale, float scale_t,
+                         float scale_prev, int64_t n, void* stream);
+/* MoCA FIFO step (ddim.py:405-430,556-609 arithmetic): per-frame coefficients, momentum
+ * EMA along the frame axis, x_prev, mask injection into pred_x0, gamma blend.  All latent
+ * tensors [B][C][F][HW] f32.  coef[F][6] = {sqrt(a_t), sqrt(a_prev), sigma_t, sqrt(1-a_t),
+ * sqrt(1-a_prev-sigma_t^2), 2(1-ts/1000)} evaluated by the host in fp32 exactly as the
+ * reference's 0-dim tensors are.  mask [B][1][Fm][HW] or NULL; cond [B][C][HW] or NULL;
+ * mask_index[F] = mask frame consulted for frame i (-1: none; the reference's clobbered
+ * loop variable makes this ceil(H/4)-1 for i>=1, ddim.py:477-567); enh[F] = factor k
+ * multiplying cond (ddim.py:582).  ws: Fm floats of scratch (per-frame mask sums).   */
+int moca_fifo_ddim_step_f32(const float* sample, const float* eps, const float* noise,
+                            float* momentum, float* x_prev, float* pred_x0,
+                            const float* coef, const float* mask, const float* cond,
+                            const int32_t* mask_index, const float* enh, float* ws,
+                            int32_t B, int32_t C, int32_t F, int32_t Fm, int32_t HW,
+                            float beta, float one_minus_beta, float gamma, float one_minus_gamma,
+                            void* stream);
+
+/* ---- FreeInit spectral mix (freeinit_utils.py:7-47) ------------------------------- */
+/* out = Re ifftn( fftshift^-1( fftshift(fftn x) * LPF + fftshift(fftn n) * (1-LPF) ) )
+ * over the last three dims of x,n [C][T][H][W] f32; lpf [T][H][W] f32 (shifted layout,
+ * as the reference builds it).  ws: f32 workspace of moca_freq_mix_ws_bytes().        */
+int moca_freq_mix_3d_f32(const float* x, const float* noise, const float* lpf, float* out,
+                         int32_t C, int32_t T, int32_t H, int32_t W, float* ws, void* stream);
+int64_t moca_freq_mix_ws_bytes(int32_t C, int32_t T, int32_t H, int32_t W);
+/* closed-form filters (freeinit_utils.py:73-156): type 0 gaussian, 1 butterworth, 2 ideal, 3 box */
+int moca_freq_filter_f32(float* lpf, int32_t T, int32_t H, int32_t W, int32_t type, int32_t n,
+                         double d_s, double d_t, void* stream);
+
+/* ---- runtime: capture a sequence of launches into a hipGraph and replay it --------- */
+int moca_graph_begin(void* stream);
+int moca_graph_end(void* stream, void** graph_exec_out);
+int moca_graph_launch(void* graph_exec, void* stream);
+int moca_graph_destroy(void* graph_exec);
+/* own non-blocking stream (so capture never touches the caller's default stream) */
+int moca_stream_create(void** stream_out);
+int moca_stream_destroy(void* stream);
+int moca_stream_sync(void* stream);
+/* HIP events on OUR stream (bench.py: torch.cuda.Event only sees torch's stream) */
+int moca_event_create(void** ev_out);
+int moca_event_record(void* ev, void* stream);
+int moca_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out);
+int moca_event_destroy(void* ev);
+
+/* device query: returns 0 and fills name[len] / cu count, or MOCA_E_NODEVICE */
+int moca_device_info(char* name, int32_t len, int32_t* cu_count);
+const char* moca_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOCA_HIP_H */

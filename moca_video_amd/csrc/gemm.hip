@@ -1,0 +1,451 @@
+// Implicit-GEMM for the VideoCrafter2 3D-UNet on gfx950 (MI355X).
+//
+//   out[M][N] = epilogue( gather(A)[M][K] . W[N][K]^T )
+//
+// One kernel family covers every contraction on the denoising path: 3x3 conv2d
+// (stride 1/2, optional fused nearest x2 upsample), the (3,1,1) temporal conv3d and
+// all nn.Linear layers; the A operand is gathered on the fly from channels-last fp16
+// activations ([frame][y][x][c]), so no im2col buffer and no layout shuffles exist.
+//
+// Tiling (CDNA4): 256 threads = 4 wavefronts (2 x 2), block tile 128 x BN x 64
+// (BN = 128 or 64), each wave owns a 64 x BN/2 sub-tile as 2 x (BN/64)
+// v_mfma_f32_32x32x16_f16 accumulators.  A/B k-tiles are staged through registers
+// (the gather needs zero fill) into double-buffered LDS with 128-byte rows and an
+// XOR swizzle on the 16-byte chunk index (chunk ^ ((row>>1)&7)) so that the
+// ds_read_b128 fragment reads are bank-conflict free.  The epilogue goes through an
+// fp32 LDS tile so that bias / time-embedding / residual are applied in fp32 and the
+// result leaves as full 16-byte coalesced stores.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+constexpr int ROW_BYTES = BK * 2;  // 128 B per LDS row
+
+struct Geo {
+    // conv3x3 / tconv geometry in registers
+    int C, inH, inW, outH, outW, stride, up, T, HW;
+};
+
+template <int BN>
+__device__ __forceinline__ void remap_block(int nblk, int& logical) {
+    // XCD-aware bijective remap: physical blocks b, b+8, b+16, ... share an XCD (L2);
+    // give each XCD a contiguous range of logical tiles so neighbours share A rows.
+    const int b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, j = b >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+template <int BN, int AMODE>
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const moca_gemm_params p) {
+    constexpr int NT = BN / 64;          // 32-wide n tiles per wave
+    constexpr int B_SLOTS = BN / 32;     // 16-B chunks of W per thread per k-tile
+    constexpr int A_BYTES = BM * ROW_BYTES;
+    constexpr int B_BYTES = BN * ROW_BYTES;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                  // [2][A_BYTES]
+    char* sB = smem + 2 * A_BYTES;    // [2][B_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = p.N / BN;
+    const int nblk = tiles_m * tiles_n * p.splits;
+    int logical;
+    remap_block<BN>(nblk, logical);
+    const int split = logical % p.splits;
+    const int tile = logical / p.splits;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int nk_total = p.ldw / BK;
+    const int kts = (nk_total + p.splits - 1) / p.splits;
+    const int kt_begin = split * kts;
+    const int kt_end = min(kt_begin + kts, nk_total);
+
+    // ---- per-thread staging coordinates --------------------------------------
+    const int cc = tid & 7;     // 16-byte chunk column inside the k-tile
+    const int r0 = tid >> 3;    // rows r0 + 32*i
+    const int swz = (r0 >> 1) & 7;  // identical for all rows r0+32i
+
+    const half_t* __restrict__ Aptr = reinterpret_cast<const half_t*>(p.a);
+    const half_t* __restrict__ Wptr = reinterpret_cast<const half_t*>(p.w);
+
+    // row descriptors
+    int64_t row_off[4];   // LINEAR: m*lda ; CONV: frame pixel base ; TCONV: m
+    int row_y[4], row_x[4];
+    bool row_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        row_ok[i] = m < p.M;
+        const int mm = row_ok[i] ? m : 0;
+        if (AMODE == MOCA_A_LINEAR) {
+            row_off[i] = (int64_t)mm * p.lda;
+            row_y[i] = row_x[i] = 0;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int ohw = p.outH * p.outW;
+            const int f = mm / ohw, rem = mm - f * ohw;
+            const int oy = rem / p.outW, ox = rem - oy * p.outW;
+            row_off[i] = (int64_t)f * p.inH * p.inW;
+            row_y[i] = oy * p.stride - 1;
+            row_x[i] = ox * p.stride - 1;
+        } else {  // TCONV3
+            const int frame = mm / p.HW;
+            row_off[i] = mm;
+            row_y[i] = frame % p.T;  // t
+            row_x[i] = 0;
+        }
+    }
+
+    half8v ra[4], rb[B_SLOTS];
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + cc * 8;
+        // ---- A ----
+        if (AMODE == MOCA_A_LINEAR) {
+            const bool kok = k < p.K;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                half8v v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (kok && row_ok[i]) v = *reinterpret_cast<const half8v*>(Aptr + row_off[i] + k);
+                ra[i] = v;
+            }
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int tap = k / p.C, c = k - tap * p.C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
+            const bool kok = tap < 9;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int iy = row_y[i] + ky, ix = row_x[i] + kx;
+                const bool ok = kok && row_ok[i] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+                if (p.up) { iy >>= 1; ix >>= 1; }
+                half8v v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) v = *reinterpret_cast<const half8v*>(Aptr + (row_off[i] + (int64_t)iy * p.inW + ix) * p.C + c);
+                ra[i] = v;
+            }
+        } else {
+            const int tap = k / p.C, c = k - tap * p.C;
+            const bool kok = tap < 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int tt = row_y[i] + tap - 1;
+                const bool ok = kok && row_ok[i] && tt >= 0 && tt < p.T;
+                half8v v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) v = *reinterpret_cast<const half8v*>(Aptr + (row_off[i] + (int64_t)(tap - 1) * p.HW) * p.C + c);
+                ra[i] = v;
+            }
+        }
+        // ---- W (always in range: N % BN == 0, ldw % 64 == 0, zero padded) ----
+#pragma unroll
+        for (int i = 0; i < B_SLOTS; ++i) {
+            const int n = n0 + r0 + 32 * i;
+            rb[i] = *reinterpret_cast<const half8v*>(Wptr + (int64_t)n * p.ldw + k);
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        char* a = sA + buf * A_BYTES;
+        char* b = sB + buf * B_BYTES;
+        const int coff = (cc ^ swz) << 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<half8v*>(a + (r0 + 32 * i) * ROW_BYTES + coff) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_SLOTS; ++i)
+            *reinterpret_cast<half8v*>(b + (r0 + 32 * i) * ROW_BYTES + coff) = rb[i];
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // fragment read coordinates
+    const int frow = lane & 31, fh = lane >> 5;
+    int a_row_b[2], a_swz[2], b_row_b[NT], b_swz[NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = wave_m * 64 + mt * 32 + frow;
+        a_row_b[mt] = row * ROW_BYTES;
+        a_swz[mt] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int row = wave_n * (BN / 2) + nt * 32 + frow;
+        b_row_b[nt] = row * ROW_BYTES;
+        b_swz[nt] = (row >> 1) & 7;
+    }
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool has_next = kt + 1 < kt_end;
+        if (has_next) load_tile(kt + 1);
+
+        const char* a = sA + cur * A_BYTES;
+        const char* b = sB + cur * B_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = ks * 2 + fh;
+            half8v af[2], bf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                af[mt] = *reinterpret_cast<const half8v*>(a + a_row_b[mt] + ((ch ^ a_swz[mt]) << 4));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                bf[nt] = *reinterpret_cast<const half8v*>(b + b_row_b[nt] + ((ch ^ b_swz[nt]) << 4));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+        }
+        if (has_next) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- split-K: raw fp32 partials, epilogue runs in splitk_reduce_kernel ----
+    if (p.splits > 1) {
+        float* ws = p.splitk_ws + (int64_t)split * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wave_m * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const int col = n0 + wave_n * (BN / 2) + nt * 32 + frow;
+                    if (row < p.M) ws[(int64_t)row * p.N + col] = acc[mt][nt][r];
+                }
+        return;
+    }
+
+    // ---- epilogue stage 1: registers -> fp32 LDS tile (bias, GEGLU) ----
+    // (the main loop's last __syncthreads() makes the pipeline buffers reusable)
+    float* sC = reinterpret_cast<float*>(smem);
+    const bool geglu = (p.flags & MOCA_EP_GEGLU) != 0;
+    const int out_bn = geglu ? BN / 2 : BN;  // output columns of this tile
+    if (geglu) {
+        if constexpr (NT == 2) {
+            const int ncol = n0 + wave_n * 64 + frow;
+            const float bv = p.bias ? p.bias[ncol] : 0.f;
+            const float bg = p.bias ? p.bias[ncol + 32] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wave_m * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const float v = acc[mt][0][r] + bv;
+                    const float g = acc[mt][1][r] + bg;
+                    sC[row * out_bn + wave_n * 32 + frow] = v * moca_gelu(g);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = wave_n * (BN / 2) + nt * 32 + frow;
+            const float bv = p.bias ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wave_m * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    sC[row * out_bn + col] = acc[mt][nt][r] + bv;
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue stage 2: coalesced 16-byte rows (+rowadd, +residual) ----
+    const int chunks_per_row = out_bn / 8;
+    const int total_chunks = BM * chunks_per_row;
+    const int on0 = geglu ? n0 / 2 : n0;
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    for (int idx = tid; idx < total_chunks; idx += 256) {
+        const int row = idx / chunks_per_row, ch = idx - row * chunks_per_row;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        const int col = on0 + ch * 8;
+        float v[8];
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(sC + row * out_bn + ch * 8);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(sC + row * out_bn + ch * 8 + 4);
+        v[0] = c0[0]; v[1] = c0[1]; v[2] = c0[2]; v[3] = c0[3];
+        v[4] = c1[0]; v[5] = c1[1]; v[6] = c1[2]; v[7] = c1[3];
+        if (rowadd) {
+            const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+        }
+        if (resid) {
+            const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+        }
+        if (p.flags & MOCA_EP_OUT_F32) {
+            float* o = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + col;
+            *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            half8v h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+            *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
+        }
+    }
+}
+
+// Sum the split-K partial slabs and run the same epilogue.  One thread per 8 output
+// columns; HBM-bound (reads splits*M*N*4 bytes).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const moca_gemm_params p) {
+    const bool geglu = (p.flags & MOCA_EP_GEGLU) != 0;
+    const int out_n = geglu ? p.N / 2 : p.N;
+    const int cpr = out_n / 8;
+    const int64_t total = (int64_t)p.M * cpr;
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int m = (int)(idx / cpr), ch = (int)(idx - (int64_t)m * cpr);
+        const int col = ch * 8;
+        float v[8];
+        if (geglu) {
+            // output col j <- value col (j/32)*64 + j%32, gate = value + 32; 8 | 32 so a chunk never straddles
+            const int vc = (col / 32) * 64 + (col % 32);
+            float a[8], g[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[j] = p.bias ? p.bias[vc + j] : 0.f; g[j] = p.bias ? p.bias[vc + 32 + j] : 0.f; }
+            for (int s = 0; s < p.splits; ++s) {
+                const float* w = p.splitk_ws + ((int64_t)s * p.M + m) * p.N + vc;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(w), a1 = *reinterpret_cast<const f32x4*>(w + 4);
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(w + 32), g1 = *reinterpret_cast<const f32x4*>(w + 36);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a[j] += a0[j]; a[4 + j] += a1[j]; g[j] += g0[j]; g[4 + j] += g1[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = a[j] * moca_gelu(g[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p.bias ? p.bias[col + j] : 0.f;
+            for (int s = 0; s < p.splits; ++s) {
+                const float* w = p.splitk_ws + ((int64_t)s * p.M + m) * p.N + col;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(w), a1 = *reinterpret_cast<const f32x4*>(w + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] += a0[j]; v[4 + j] += a1[j]; }
+            }
+        }
+        if (rowadd) {
+            const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+        }
+        if (resid) {
+            const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+        }
+        if (p.flags & MOCA_EP_OUT_F32) {
+            float* o = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + col;
+            *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            half8v h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+            *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
+        }
+    }
+}
+
+template <int BN, int AMODE>
+int launch_gemm(const moca_gemm_params& p, hipStream_t st) {
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
+    const int nblk = tiles_m * tiles_n * p.splits;
+    constexpr int lds_pipe = 2 * (BM + BN) * ROW_BYTES;
+    constexpr int lds_epi = BM * BN * 4;
+    constexpr int lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BN, AMODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MOCA_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f16_kernel<BN, AMODE>), dim3(nblk), dim3(256), lds, st, p);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits) {
+    return splits > 1 ? (int64_t)splits * M * N * 4 : 0;
+}
+
+extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
+    if (!pp) return MOCA_E_BADARG;
+    moca_gemm_params p = *pp;
+    if (p.splits < 1) p.splits = 1;
+    if (!p.a || !p.w || !p.out) return MOCA_E_BADARG;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MOCA_E_BADARG;
+    if (p.N % 64 || p.K % 8 || p.ldw % BK || p.ldw < p.K) return MOCA_E_BADARG;
+    const bool geglu = p.flags & MOCA_EP_GEGLU;
+    if (geglu && p.N % 128) return MOCA_E_BADARG;
+    if (p.ldo % 8 || (p.residual && p.ldr % 8) || (p.rowadd && (p.ld_rowadd % 8 || p.rowadd_div <= 0))) return MOCA_E_BADARG;
+    if (p.splits > 1 && !p.splitk_ws) return MOCA_E_BADARG;
+    if (p.splits > p.ldw / BK) p.splits = p.ldw / BK;
+    switch (p.a_mode) {
+        case MOCA_A_LINEAR:
+            if (p.lda % 8 || p.lda < p.K) return MOCA_E_BADARG;
+            break;
+        case MOCA_A_CONV3X3:
+            if (p.C % 8 || p.K != 9 * p.C || p.inH <= 0 || p.inW <= 0 || p.outH <= 0 || p.outW <= 0) return MOCA_E_BADARG;
+            if (p.stride != 1 && p.stride != 2) return MOCA_E_BADARG;
+            if (p.up && (p.stride != 1 || p.outH != 2 * p.inH || p.outW != 2 * p.inW)) return MOCA_E_BADARG;
+            if (!p.up && p.stride == 1 && (p.outH != p.inH || p.outW != p.inW)) return MOCA_E_BADARG;
+            if (p.stride == 2 && (p.outH != (p.inH - 1) / 2 + 1 || p.outW != (p.inW - 1) / 2 + 1)) return MOCA_E_BADARG;
+            if (p.M % (p.outH * p.outW)) return MOCA_E_BADARG;
+            break;
+        case MOCA_A_TCONV3:
+            if (p.C % 8 || p.K != 3 * p.C || p.T <= 0 || p.HW <= 0 || p.M % (p.T * p.HW)) return MOCA_E_BADARG;
+            break;
+        default:
+            return MOCA_E_BADARG;
+    }
+    hipStream_t st = moca_stream(stream);
+    const bool wide = (p.N % 128 == 0);
+    int rc;
+    if (wide) {
+        if (p.a_mode == MOCA_A_LINEAR) rc = launch_gemm<128, MOCA_A_LINEAR>(p, st);
+        else if (p.a_mode == MOCA_A_CONV3X3) rc = launch_gemm<128, MOCA_A_CONV3X3>(p, st);
+        else rc = launch_gemm<128, MOCA_A_TCONV3>(p, st);
+    } else {
+        if (p.a_mode == MOCA_A_LINEAR) rc = launch_gemm<64, MOCA_A_LINEAR>(p, st);
+        else if (p.a_mode == MOCA_A_CONV3X3) rc = launch_gemm<64, MOCA_A_CONV3X3>(p, st);
+        else rc = launch_gemm<64, MOCA_A_TCONV3>(p, st);
+    }
+    if (rc != MOCA_OK) return rc;
+    if (p.splits > 1) {
+        const int out_n = geglu ? p.N / 2 : p.N;
+        const int64_t total = (int64_t)p.M * (out_n / 8);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        MOCA_CHECK_LAUNCH();
+    }
+    return MOCA_OK;
+}

@@ -1,0 +1,214 @@
+// GroupNorm(32) (+SiLU) and LayerNorm on channels-last fp16 activations, fp32/fp64
+// statistics.  HBM-bound kernels: every access is a 16-byte (8 x fp16) coalesced
+// load/store along the channel axis; partial statistics are deterministic (no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int GN_GROUPS = 32;
+
+__host__ __device__ inline int gn_nchunk(int F, int HW) {
+    int n = 2048 / (F > 0 ? F : 1);
+    if (n < 1) n = 1;
+    const int maxc = (HW + 7) / 8;
+    if (n > maxc) n = maxc;
+    if (n < 1) n = 1;
+    return n;
+}
+
+// ---- K1: per (frame, pixel-chunk) partial sums per group ---------------------
+// blockDim = (C/8, ppb): thread (cx, py) owns channels [8cx, 8cx+8) of pixels py, py+ppb, ...
+__global__ void gn_partial_kernel(const half_t* __restrict__ x, float* __restrict__ partial,
+                                  int HW, int C, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* s_sum = reinterpret_cast<float*>(smem_raw);   // [ppb][C]
+    float* s_sq = s_sum + blockDim.y * C;                 // [ppb][C]
+    const int f = blockIdx.x, chunk = blockIdx.y;
+    const int cx = threadIdx.x, py = threadIdx.y, ppb = blockDim.y;
+    const int pc = (HW + nchunk - 1) / nchunk;
+    const int p_begin = chunk * pc, p_end = min(p_begin + pc, HW);
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    const half_t* base = x + ((int64_t)f * HW) * C + cx * 8;
+    for (int p = p_begin + py; p < p_end; p += ppb) {
+        const half8v v = *reinterpret_cast<const half8v*>(base + (int64_t)p * C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float a = (float)v[j]; s[j] += a; q[j] += a * a; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s_sum[py * C + cx * 8 + j] = s[j]; s_sq[py * C + cx * 8 + j] = q[j]; }
+    __syncthreads();
+    const int tid = py * blockDim.x + cx;
+    if (tid < GN_GROUPS) {
+        const int cpg = C / GN_GROUPS;
+        float a = 0.f, b = 0.f;
+        for (int y = 0; y < ppb; ++y)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += s_sum[y * C + c]; b += s_sq[y * C + c]; }
+        float* o = partial + (((int64_t)f * nchunk + chunk) * GN_GROUPS + tid) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+
+// ---- K2: finalize mean / rstd per (stat group, channel group) in fp64 --------
+// block = 256 threads = 32 groups x 8 lanes
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ meanrstd,
+                                                          int frames_per_stat, int nchunk, double inv_count, float eps) {
+    const int sg = blockIdx.x;
+    const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
+    const int n = frames_per_stat * nchunk;
+    const float* base = partial + (int64_t)sg * n * GN_GROUPS * 2;
+    double a = 0.0, b = 0.0;
+    for (int i = l; i < n; i += 8) {
+        a += (double)base[((int64_t)i * GN_GROUPS + g) * 2];
+        b += (double)base[((int64_t)i * GN_GROUPS + g) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (l == 0) {
+        const double mean = a * inv_count;
+        double var = b * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        meanrstd[((int64_t)sg * GN_GROUPS + g) * 2] = (float)mean;
+        meanrstd[((int64_t)sg * GN_GROUPS + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// ---- K3: apply (x - mean) * rstd * gamma + beta, optional SiLU ----------------
+__global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ meanrstd, int HW, int C, int nchunk,
+                                int frames_per_stat, int silu) {
+    const int f = blockIdx.x, chunk = blockIdx.y;
+    const int cx = threadIdx.x, py = threadIdx.y, ppb = blockDim.y;
+    const int pc = (HW + nchunk - 1) / nchunk;
+    const int p_begin = chunk * pc, p_end = min(p_begin + pc, HW);
+    const int cpg = C / GN_GROUPS;
+    const int sg = f / frames_per_stat;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cx * 8 + j;
+        const int g = c / cpg;
+        const float mean = meanrstd[((int64_t)sg * GN_GROUPS + g) * 2];
+        const float rstd = meanrstd[((int64_t)sg * GN_GROUPS + g) * 2 + 1];
+        sc[j] = rstd * gamma[c];
+        sh[j] = beta[c] - mean * sc[j];
+    }
+    const int64_t off = ((int64_t)f * HW) * C + cx * 8;
+    for (int p = p_begin + py; p < p_end; p += ppb) {
+        const half8v v = *reinterpret_cast<const half8v*>(x + off + (int64_t)p * C);
+        half8v o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = (float)v[j] * sc[j] + sh[j];
+            if (silu) a = moca_silu(a);
+            o[j] = (half_t)a;
+        }
+        *reinterpret_cast<half8v*>(y + off + (int64_t)p * C) = o;
+    }
+}
+
+// ---- LayerNorm: one wavefront per row, row kept in registers -------------------
+template <int MAXCH>  // max 16-byte chunks per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const int nch = C / 8;
+    const half_t* xr = x + (int64_t)row * C;
+    half8v v[MAXCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            v[i] = *reinterpret_cast<const half8v*>(xr + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+        }
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = (float)v[i][j] - mean; q += d * d; }
+        }
+    }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    half_t* yr = y + (int64_t)row * C;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch * 8), b1 = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
+            half8v o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (half_t)(((float)v[i][j] - mean) * rstd * g0[j] + b0[j]);
+                o[4 + j] = (half_t)(((float)v[i][4 + j] - mean) * rstd * g1[j] + b1[j]);
+            }
+            *reinterpret_cast<half8v*>(yr + ch * 8) = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t moca_groupnorm_ws_bytes(int32_t F, int32_t HW, int32_t C) {
+    (void)C;
+    const int nchunk = gn_nchunk(F, HW);
+    return ((int64_t)F * nchunk * GN_GROUPS * 2 + (int64_t)F * GN_GROUPS * 2) * 4;
+}
+
+extern "C" int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma, const float* beta,
+                                       int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
+                                       float eps, int32_t silu, float* ws, void* stream) {
+    if (!x || !y || !gamma || !beta || !ws) return MOCA_E_BADARG;
+    if (F <= 0 || HW <= 0 || C <= 0 || C % (8 * 1) || C % GN_GROUPS || frames_per_stat <= 0 || F % frames_per_stat) return MOCA_E_BADARG;
+    const int nch8 = C / 8;
+    if (nch8 > 1024) return MOCA_E_BADARG;
+    int ppb = 256 / nch8;
+    if (ppb < 1) ppb = 1;
+    const int nchunk = gn_nchunk(F, HW);
+    float* partial = ws;
+    float* meanrstd = ws + (int64_t)F * nchunk * GN_GROUPS * 2;
+    hipStream_t st = moca_stream(stream);
+    const dim3 grid(F, nchunk), block(nch8, ppb);
+    const size_t lds = (size_t)ppb * C * 2 * sizeof(float);
+    hipLaunchKernelGGL(gn_partial_kernel, grid, block, lds, st, reinterpret_cast<const half_t*>(x), partial, HW, C, nchunk);
+    MOCA_CHECK_LAUNCH();
+    const double inv_count = 1.0 / ((double)frames_per_stat * HW * (C / GN_GROUPS));
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(F / frames_per_stat), dim3(256), 0, st, partial, meanrstd,
+                       frames_per_stat, nchunk, inv_count, eps);
+    MOCA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, reinterpret_cast<const half_t*>(x), reinterpret_cast<half_t*>(y),
+                       gamma, beta, meanrstd, HW, C, nchunk, frames_per_stat, silu);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta,
+                                  int32_t M, int32_t C, float eps, void* stream) {
+    if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || C % 8) return MOCA_E_BADARG;
+    const int nch = C / 8;
+    hipStream_t st = moca_stream(stream);
+    const dim3 grid((M + 3) / 4), block(256);
+    const half_t* xi = reinterpret_cast<const half_t*>(x);
+    half_t* yo = reinterpret_cast<half_t*>(y);
+    if (nch <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, xi, yo, gamma, beta, M, C, eps);
+    else if (nch <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, xi, yo, gamma, beta, M, C, eps);
+    else if (nch <= 192) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, xi, yo, gamma, beta, M, C, eps);
+    else if (nch <= 320) hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, st, xi, yo, gamma, beta, M, C, eps);
+    else return MOCA_E_BADARG;
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}

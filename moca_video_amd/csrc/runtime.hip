@@ -1,0 +1,85 @@
+// Runtime helpers of libmoca_hip.so: hipGraph capture/replay of a launch sequence,
+// streams, events and device query.  A UNet forward is ~1000 short launches; after the
+// first eager pass the host replays it as one hipGraph (no tracing compiler involved:
+// the graph is just the recorded launch sequence of the C-ABI calls above).
+#include "common.h"
+#include <string.h>
+
+extern "C" int moca_graph_begin(void* stream) {
+    if (hipStreamBeginCapture(moca_stream(stream), hipStreamCaptureModeThreadLocal) != hipSuccess) return MOCA_E_GRAPH;
+    return MOCA_OK;
+}
+
+extern "C" int moca_graph_end(void* stream, void** graph_exec_out) {
+    if (!graph_exec_out) return MOCA_E_BADARG;
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture(moca_stream(stream), &g) != hipSuccess || !g) return MOCA_E_GRAPH;
+    hipGraphExec_t ge = nullptr;
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess || !ge) return MOCA_E_GRAPH;
+    *graph_exec_out = reinterpret_cast<void*>(ge);
+    return MOCA_OK;
+}
+
+extern "C" int moca_graph_launch(void* graph_exec, void* stream) {
+    if (!graph_exec) return MOCA_E_BADARG;
+    if (hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), moca_stream(stream)) != hipSuccess) return MOCA_E_GRAPH;
+    return MOCA_OK;
+}
+
+extern "C" int moca_graph_destroy(void* graph_exec) {
+    if (!graph_exec) return MOCA_OK;
+    return hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec)) == hipSuccess ? MOCA_OK : MOCA_E_GRAPH;
+}
+
+extern "C" int moca_stream_create(void** stream_out) {
+    if (!stream_out) return MOCA_E_BADARG;
+    hipStream_t s;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return MOCA_E_LAUNCH;
+    *stream_out = reinterpret_cast<void*>(s);
+    return MOCA_OK;
+}
+extern "C" int moca_stream_destroy(void* stream) {
+    return hipStreamDestroy(moca_stream(stream)) == hipSuccess ? MOCA_OK : MOCA_E_LAUNCH;
+}
+extern "C" int moca_stream_sync(void* stream) {
+    return hipStreamSynchronize(moca_stream(stream)) == hipSuccess ? MOCA_OK : MOCA_E_LAUNCH;
+}
+
+extern "C" int moca_event_create(void** ev_out) {
+    if (!ev_out) return MOCA_E_BADARG;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return MOCA_E_LAUNCH;
+    *ev_out = reinterpret_cast<void*>(e);
+    return MOCA_OK;
+}
+extern "C" int moca_event_record(void* ev, void* stream) {
+    return hipEventRecord(reinterpret_cast<hipEvent_t>(ev), moca_stream(stream)) == hipSuccess ? MOCA_OK : MOCA_E_LAUNCH;
+}
+extern "C" int moca_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out) {
+    if (!ms_out) return MOCA_E_BADARG;
+    if (hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev_stop)) != hipSuccess) return MOCA_E_LAUNCH;
+    return hipEventElapsedTime(ms_out, reinterpret_cast<hipEvent_t>(ev_start), reinterpret_cast<hipEvent_t>(ev_stop)) == hipSuccess
+               ? MOCA_OK : MOCA_E_LAUNCH;
+}
+extern "C" int moca_event_destroy(void* ev) {
+    return hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)) == hipSuccess ? MOCA_OK : MOCA_E_LAUNCH;
+}
+
+extern "C" int moca_device_info(char* name, int32_t len, int32_t* cu_count) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MOCA_E_NODEVICE;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MOCA_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MOCA_E_NODEVICE;
+    if (name && len > 0) {
+        strncpy(name, prop.gcnArchName, (size_t)len - 1);
+        name[len - 1] = 0;
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    return MOCA_OK;
+}
+
+extern "C" const char* moca_version(void) { return "moca_hip 0.1 (gfx950)"; }

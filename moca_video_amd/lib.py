@@ -1,0 +1,121 @@
+"""ctypes binding of libmoca_hip.so (the C-ABI declared in include/moca_hip.h).
+
+This is the only place the Python host touches native code.  There is NO fallback:
+if the shared library is missing the import fails loudly, and every wrapper raises
+on a non-zero status.  PyTorch is used purely as the device-memory / stream owner
+(tensor.data_ptr(), torch.cuda.Stream().cuda_stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmoca_hip.so")
+
+MOCA_A_LINEAR, MOCA_A_CONV3X3, MOCA_A_TCONV3 = 0, 1, 2
+MOCA_EP_GEGLU, MOCA_EP_OUT_F32 = 1, 2
+
+_ERR = {0: "ok", -1: "bad argument (shape/alignment contract)", -2: "HIP launch/runtime error",
+        -3: "no gfx950 device", -4: "graph capture/replay failed"}
+
+
+class MocaHipError(RuntimeError):
+    pass
+
+
+class GemmParams(C.Structure):
+    """Mirror of `moca_gemm_params` (include/moca_hip.h)."""
+    _fields_ = [
+        ("a", C.c_void_p), ("w", C.c_void_p), ("out", C.c_void_p), ("bias", C.c_void_p),
+        ("rowadd", C.c_void_p), ("residual", C.c_void_p), ("splitk_ws", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldw", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32), ("ld_rowadd", C.c_int32),
+        ("rowadd_div", C.c_int32), ("a_mode", C.c_int32), ("C", C.c_int32),
+        ("inH", C.c_int32), ("inW", C.c_int32), ("outH", C.c_int32), ("outW", C.c_int32),
+        ("stride", C.c_int32), ("up", C.c_int32), ("T", C.c_int32), ("HW", C.c_int32),
+        ("flags", C.c_int32), ("splits", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol of include/moca_hip.h
+_vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+SIGNATURES = {
+    "moca_gemm_f16": (C.c_int, [C.POINTER(GemmParams), _vp]),
+    "moca_gemm_splitk_ws_bytes": (_i64, [_i32, _i32, _i32]),
+    "moca_groupnorm_nhwc_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
+    "moca_groupnorm_ws_bytes": (_i64, [_i32, _i32, _i32]),
+    "moca_layernorm_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
+    "moca_attention_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "moca_temporal_attention_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "moca_ncthw_to_nhwc_f16": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "moca_nhwc_to_ncthw": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "moca_concat_channels_f16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "moca_timestep_embedding_f16": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _vp]),
+    "moca_silu_add_rows_f16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "moca_cfg_combine_f32": (C.c_int, [_vp, _vp, _vp, _f32, _i64, _vp]),
+    "moca_ddim_update_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i64, _vp]),
+    "moca_fifo_ddim_step_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
+    "moca_freq_mix_3d_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "moca_freq_mix_ws_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "moca_freq_filter_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f64, _f64, _vp]),
+    "moca_graph_begin": (C.c_int, [_vp]),
+    "moca_graph_end": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "moca_graph_launch": (C.c_int, [_vp, _vp]),
+    "moca_graph_destroy": (C.c_int, [_vp]),
+    "moca_stream_create": (C.c_int, [C.POINTER(_vp)]),
+    "moca_stream_destroy": (C.c_int, [_vp]),
+    "moca_stream_sync": (C.c_int, [_vp]),
+    "moca_event_create": (C.c_int, [C.POINTER(_vp)]),
+    "moca_event_record": (C.c_int, [_vp, _vp]),
+    "moca_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(_f32)]),
+    "moca_event_destroy": (C.c_int, [_vp]),
+    "moca_device_info": (C.c_int, [C.c_char_p, _i32, C.POINTER(_i32)]),
+    "moca_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmoca_hip.so.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C moca_video_amd/csrc`). "
+            "moca_video_amd has no CPU fallback by design.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise MocaHipError(f"{what or 'moca_hip call'} failed: {_ERR.get(rc, rc)} (rc={rc})")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def version() -> str:
+    return load().moca_version().decode()
+
+
+def device_info():
+    lib = load()
+    name = C.create_string_buffer(64)
+    cus = C.c_int32(0)
+    check(lib.moca_device_info(name, 64, C.byref(cus)), "moca_device_info")
+    return name.value.decode(), cus.value

@@ -1,0 +1,198 @@
+"""Thin tensor-level wrappers over the C-ABI (moca_video_amd/lib.py) plus the weight
+pre-packing that turns reference-shaped parameters (nn.Conv2d / nn.Conv3d / nn.Linear
+state-dict tensors) into the K-contiguous fp16 matrices the implicit-GEMM kernel reads.
+
+Every function launches on `ops.current_stream()` (a raw hipStream_t owned by a
+torch.cuda.Stream) and raises on failure.  Nothing here computes on the CPU or
+through torch kernels: torch only allocates the buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import torch
+
+from . import lib as _l
+
+_stream = None  # raw hipStream_t (int) all launches go to
+
+
+def set_stream(handle):
+    global _stream
+    _stream = handle
+
+
+def current_stream():
+    if _stream is None:
+        # torch's current stream on the current device
+        return torch.cuda.current_stream().cuda_stream
+    return _stream
+
+
+def _st():
+    return C.c_void_p(current_stream())
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------------------
+# weight packing (runs once at load_state_dict time; plain torch ops on the weights)
+# --------------------------------------------------------------------------------------
+class PackedWeight:
+    """fp16 [Npad][Kpad] K-contiguous weight + fp32 bias, as moca_gemm_f16 wants them."""
+    __slots__ = ("w", "bias", "N", "K", "n_out", "geglu")
+
+    def __init__(self, w, bias, N, K, n_out, geglu=False):
+        self.w, self.bias, self.N, self.K, self.n_out, self.geglu = w, bias, N, K, n_out, geglu
+
+
+def _finish(w2d: torch.Tensor, bias, device, n_out=None, geglu=False) -> PackedWeight:
+    n, k = w2d.shape
+    npad, kpad = _round_up(n, 64), _round_up(k, 64)
+    w = torch.zeros(npad, kpad, dtype=torch.float16, device=device)
+    w[:n, :k] = w2d.to(device=device, dtype=torch.float16)
+    b = None
+    if bias is not None:
+        b = torch.zeros(npad, dtype=torch.float32, device=device)
+        b[:n] = bias.to(device=device, dtype=torch.float32)
+    return PackedWeight(w, b, npad, k, n if n_out is None else n_out, geglu)
+
+
+def pack_linear(weight, bias=None, device="cuda"):
+    """nn.Linear weight [N][K] (or Conv1d k=1 [N][K][1])."""
+    w = weight.reshape(weight.shape[0], -1)
+    return _finish(w, bias, device)
+
+
+def pack_linear_cat(weights, biases=None, device="cuda"):
+    """Fuse several linears sharing an input (to_q/to_k/to_v) into one [sum N][K] GEMM."""
+    w = torch.cat([x.reshape(x.shape[0], -1) for x in weights], dim=0)
+    b = None
+    if biases is not None:
+        b = torch.cat(list(biases), dim=0)
+    return _finish(w, b, device)
+
+
+def pack_conv3x3(weight, bias=None, cpad=None, device="cuda"):
+    """nn.Conv2d weight [N][C][3][3] -> [N][(ky,kx,c)], channels zero padded to cpad."""
+    n, c = weight.shape[0], weight.shape[1]
+    cpad = c if cpad is None else cpad
+    w = torch.zeros(n, 3, 3, cpad, dtype=weight.dtype, device=weight.device)
+    w[..., :c] = weight.permute(0, 2, 3, 1)
+    return _finish(w.reshape(n, 9 * cpad), bias, device)
+
+
+def pack_conv1x1(weight, bias=None, device="cuda"):
+    return _finish(weight.reshape(weight.shape[0], weight.shape[1]), bias, device)
+
+
+def pack_tconv3(weight, bias=None, device="cuda"):
+    """nn.Conv3d weight [N][C][3][1][1] -> [N][(kt,c)]."""
+    n, c = weight.shape[0], weight.shape[1]
+    w = weight.reshape(n, c, 3).permute(0, 2, 1).reshape(n, 3 * c)
+    return _finish(w, bias, device)
+
+
+def pack_geglu(weight, bias, device="cuda"):
+    """GEGLU.proj weight [2*inner][K]: value rows first, gate rows second (attention.py:382).
+    Re-ordered in 64-row groups (32 value rows, then their 32 gate rows) so that one wave's
+    two 32-wide accumulator tiles hold value and gate of the same output columns."""
+    two_inner, k = weight.shape
+    inner = two_inner // 2
+    assert inner % 32 == 0
+    idx = torch.arange(inner, device=weight.device).reshape(inner // 32, 32)
+    order = torch.cat([idx, idx + inner], dim=1).reshape(-1)
+    p = _finish(weight[order], bias[order] if bias is not None else None, device, n_out=inner, geglu=True)
+    return p
+
+
+# --------------------------------------------------------------------------------------
+# kernel wrappers
+# --------------------------------------------------------------------------------------
+def gemm(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
+         residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None):
+    """out[M][:] = epilogue(gather(a) @ pw.w^T).  conv = (C, inH, inW, outH, outW, stride, up);
+    tconv = (C, T, HW)."""
+    lib = _l.load()
+    p = _l.GemmParams()
+    p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), out.data_ptr()
+    p.bias = pw.bias.data_ptr() if pw.bias is not None else None
+    p.rowadd = rowadd.data_ptr() if rowadd is not None else None
+    p.residual = residual.data_ptr() if residual is not None else None
+    p.splitk_ws = splitk_ws.data_ptr() if splitk_ws is not None else None
+    p.M, p.N, p.K = M, pw.N, pw.K
+    p.lda = lda if lda is not None else (a.stride(-2) if a.dim() >= 2 else pw.K)
+    p.ldw = pw.w.shape[1]
+    p.ldo = out.stride(-2)
+    p.ldr = residual.stride(-2) if residual is not None else 0
+    p.ld_rowadd = rowadd.stride(-2) if rowadd is not None else 0
+    p.rowadd_div = rowadd_div
+    p.a_mode = mode
+    if conv is not None:
+        p.C, p.inH, p.inW, p.outH, p.outW, p.stride, p.up = conv
+    if tconv is not None:
+        p.C, p.T, p.HW = tconv
+    p.flags = (_l.MOCA_EP_GEGLU if pw.geglu else 0) | (_l.MOCA_EP_OUT_F32 if out_f32 else 0)
+    p.splits = splits
+    _l.check(lib.moca_gemm_f16(C.byref(p), _st()), "moca_gemm_f16")
+    return out
+
+
+def groupnorm(x, y, gamma, beta, *, F, HW, Cn, frames_per_stat, eps, silu, ws):
+    _l.check(_l.load().moca_groupnorm_nhwc_f16(_l.ptr(x), _l.ptr(y), _l.ptr(gamma), _l.ptr(beta), F, HW, Cn,
+                                               frames_per_stat, eps, 1 if silu else 0, _l.ptr(ws), _st()),
+             "moca_groupnorm_nhwc_f16")
+    return y
+
+
+def groupnorm_ws_floats(F, HW, Cn):
+    return int(_l.load().moca_groupnorm_ws_bytes(F, HW, Cn)) // 4
+
+
+def layernorm(x, y, gamma, beta, *, M, Cn, eps=1e-5):
+    _l.check(_l.load().moca_layernorm_f16(_l.ptr(x), _l.ptr(y), _l.ptr(gamma), _l.ptr(beta), M, Cn, eps, _st()),
+             "moca_layernorm_f16")
+    return y
+
+
+def attention(q, k, v, out, *, Bq, heads, Nq, Nk, ldq, ldk, ldv, ldo, kv_div, scale):
+    _l.check(_l.load().moca_attention_f16(_l.ptr(q), _l.ptr(k), _l.ptr(v), _l.ptr(out), Bq, heads, Nq, Nk,
+                                          ldq, ldk, ldv, ldo, kv_div, scale, _st()), "moca_attention_f16")
+    return out
+
+
+def temporal_attention(q, k, v, out, *, B, T, HW, heads, ld_qkv, ldo, scale):
+    _l.check(_l.load().moca_temporal_attention_f16(_l.ptr(q), _l.ptr(k), _l.ptr(v), _l.ptr(out), B, T, HW, heads,
+                                                   ld_qkv, ldo, scale, _st()), "moca_temporal_attention_f16")
+    return out
+
+
+def ncthw_to_nhwc(x, y, *, B, Cin, T, HW, Cpad):
+    _l.check(_l.load().moca_ncthw_to_nhwc_f16(_l.ptr(x), 1 if x.dtype == torch.float32 else 0, _l.ptr(y), B, Cin, T, HW,
+                                              Cpad, _st()), "moca_ncthw_to_nhwc_f16")
+    return y
+
+
+def nhwc_to_ncthw(y, ld, x, *, B, Cout, T, HW):
+    _l.check(_l.load().moca_nhwc_to_ncthw(_l.ptr(y), ld, _l.ptr(x), 1 if x.dtype == torch.float32 else 0, B, Cout, T, HW,
+                                          _st()), "moca_nhwc_to_ncthw")
+    return x
+
+
+def concat_channels(a, b, out, *, rows, C1, C2):
+    _l.check(_l.load().moca_concat_channels_f16(_l.ptr(a), _l.ptr(b), _l.ptr(out), rows, C1, C2, _st()),
+             "moca_concat_channels_f16")
+    return out
+
+
+def timestep_embedding(t, out, *, n, dim, max_period=10000.0):
+    _l.check(_l.load().moca_timestep_embedding_f16(_l.ptr(t), _l.ptr(out), n, dim, max_period, _st()),
+             "moca_timestep_embedding_f16")
+    return out
+
+
+def silu_add_rows(a, div_a, b, div_b, out, *, rows, Cn, silu):
+    _l.check(_l.load().moca_silu_add_rows_f16(_l.ptr(a), div_a, _l.ptr(b), div_b, _l.ptr(out), rows, Cn,
+                                              1 if silu else 0, _st()), "moca_silu_add_rows_f16")
+    return out

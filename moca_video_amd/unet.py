@@ -1,0 +1,410 @@
+"""MI355X-native drop-in for `lvdm.modules.networks.openaimodel3d.UNetModel`.
+
+Same constructor kwargs as `configs/inference_t2v_512_v2.0.yaml: unet_config.params`
+(reference ctor: openaimodel3d.py:307-337), same `state_dict()` keys/shapes as the
+reference module tree (incl. the `temopral_conv` spelling, openaimodel3d.py:188) and the
+same `forward(x, timesteps, context=None, features_adapter=None, fps=16, **kwargs)`
+(openaimodel3d.py:534).  Swapping it in = changing the YAML `target:` string.
+
+Internally nothing of the reference's execution model survives: parameters are
+re-packed once into K-contiguous fp16 GEMM operands, activations live channels-last
+([frame][y][x][c] fp16), every contraction is the hand-written implicit-GEMM kernel,
+and the ~1000 launches of a forward are recorded into a hipGraph and replayed.
+There is no PyTorch compute fallback: without libmoca_hip.so the import fails.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import lib as _l
+from . import ops
+
+__all__ = ["UNetModel"]
+
+
+# --------------------------------------------------------------------------------------
+# parameter containers: reproduce the reference module tree / state_dict names only
+# --------------------------------------------------------------------------------------
+class _Param(nn.Module):
+    """weight (+bias) holder standing in for nn.Conv2d / nn.Conv3d / nn.Linear / norms."""
+
+    def __init__(self, wshape, bias=True, kind="linear"):
+        super().__init__()
+        self.kind = kind
+        self.weight = nn.Parameter(torch.empty(*wshape), requires_grad=False)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(wshape[0]), requires_grad=False)
+        else:
+            self.register_parameter("bias", None)
+
+
+def _seq(*mods):
+    return nn.Sequential(*mods)
+
+
+class _ResBlock(nn.Module):
+    """openaimodel3d.py:124-193"""
+
+    def __init__(self, cin, emb_ch, cout, temporal_conv):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.in_layers = _seq(_Param((cin,), kind="norm"), nn.Identity(), _Param((cout, cin, 3, 3), kind="conv"))
+        self.emb_layers = _seq(nn.Identity(), _Param((cout, emb_ch)))
+        self.out_layers = _seq(_Param((cout,), kind="norm"), nn.Identity(), nn.Identity(), _Param((cout, cout, 3, 3), kind="conv"))
+        if cin != cout:
+            self.skip_connection = _Param((cout, cin, 1, 1), kind="conv")
+        else:
+            self.skip_connection = nn.Identity()
+        self.use_temporal_conv = temporal_conv
+        if temporal_conv:
+            self.temopral_conv = _TemporalConvBlock(cout)
+
+
+class _TemporalConvBlock(nn.Module):
+    """openaimodel3d.py:242-267"""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.conv1 = _seq(_Param((ch,), kind="norm"), nn.Identity(), _Param((ch, ch, 3, 1, 1), kind="conv"))
+        for name in ("conv2", "conv3", "conv4"):
+            setattr(self, name, _seq(_Param((ch,), kind="norm"), nn.Identity(), nn.Identity(), _Param((ch, ch, 3, 1, 1), kind="conv")))
+
+
+class _CrossAttention(nn.Module):
+    """attention.py:45-57"""
+
+    def __init__(self, query_dim, context_dim, heads, dim_head):
+        super().__init__()
+        inner = heads * dim_head
+        context_dim = query_dim if context_dim is None else context_dim
+        self.heads, self.dim_head, self.is_self = heads, dim_head, context_dim == query_dim
+        self.to_q = _Param((inner, query_dim), bias=False)
+        self.to_k = _Param((inner, context_dim), bias=False)
+        self.to_v = _Param((inner, context_dim), bias=False)
+        self.to_out = _seq(_Param((query_dim, inner)), nn.Identity())
+
+
+class _GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = _Param((dim_out * 2, dim_in))
+
+
+class _FeedForward(nn.Module):
+    """attention.py:386-403 (glu=True, mult=4)"""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.net = _seq(_GEGLU(dim, dim * 4), nn.Identity(), _Param((dim, dim * 4)))
+
+
+class _BasicTransformerBlock(nn.Module):
+    """attention.py:189-202"""
+
+    def __init__(self, dim, n_heads, d_head, context_dim):
+        super().__init__()
+        self.attn1 = _CrossAttention(dim, None, n_heads, d_head)
+        self.ff = _FeedForward(dim)
+        self.attn2 = _CrossAttention(dim, context_dim, n_heads, d_head)
+        self.attn2.is_self = context_dim is None
+        self.norm1 = _Param((dim,), kind="norm")
+        self.norm2 = _Param((dim,), kind="norm")
+        self.norm3 = _Param((dim,), kind="norm")
+
+
+class _SpatialTransformer(nn.Module):
+    """attention.py:233-259"""
+
+    def __init__(self, ch, n_heads, d_head, depth, context_dim, use_linear):
+        super().__init__()
+        inner = n_heads * d_head
+        self.ch, self.inner, self.heads = ch, inner, n_heads
+        self.norm = _Param((ch,), kind="norm")
+        self.proj_in = _Param((inner, ch) if use_linear else (inner, ch, 1, 1))
+        self.transformer_blocks = nn.ModuleList([_BasicTransformerBlock(inner, n_heads, d_head, context_dim) for _ in range(depth)])
+        self.proj_out = _Param((ch, inner) if use_linear else (ch, inner, 1, 1))
+
+
+class _TemporalTransformer(nn.Module):
+    """attention.py:288-329 (only_self_att=True)"""
+
+    def __init__(self, ch, n_heads, d_head, depth, use_linear):
+        super().__init__()
+        inner = n_heads * d_head
+        self.ch, self.inner, self.heads = ch, inner, n_heads
+        self.norm = _Param((ch,), kind="norm")
+        self.proj_in = _Param((inner, ch) if use_linear else (inner, ch, 1))
+        self.transformer_blocks = nn.ModuleList([_BasicTransformerBlock(inner, n_heads, d_head, None) for _ in range(depth)])
+        self.proj_out = _Param((ch, inner) if use_linear else (ch, inner, 1))
+
+
+class _Downsample(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.op = _Param((ch, ch, 3, 3), kind="conv")
+
+
+class _Upsample(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = _Param((ch, ch, 3, 3), kind="conv")
+
+
+# --------------------------------------------------------------------------------------
+# buffer pool for the recorded forward
+# --------------------------------------------------------------------------------------
+class _Pool:
+    def __init__(self, device):
+        self.device = device
+        self.free = {}
+        self.total_bytes = 0
+
+    def get(self, rows, cols, dtype=torch.float16):
+        key = (rows * cols, dtype)
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop().view(rows, cols)
+        t = torch.empty(rows * cols, dtype=dtype, device=self.device)
+        self.total_bytes += t.numel() * t.element_size()
+        return t.view(rows, cols)
+
+    def put(self, *ts):
+        for t in ts:
+            if t is None:
+                continue
+            flat = t.reshape(-1)
+            self.free.setdefault((flat.numel(), flat.dtype), []).append(flat)
+
+
+class _FMap:
+    """channels-last feature map: buf [F*H*W][C] fp16"""
+    __slots__ = ("buf", "F", "H", "W", "C")
+
+    def __init__(self, buf, F, H, W, C):
+        self.buf, self.F, self.H, self.W, self.C = buf, F, H, W, C
+
+    @property
+    def M(self):
+        return self.F * self.H * self.W
+
+
+# --------------------------------------------------------------------------------------
+# the model
+# --------------------------------------------------------------------------------------
+class UNetModel(nn.Module):
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0.0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, context_dim=None,
+                 use_scale_shift_norm=False, resblock_updown=False, num_heads=-1, num_head_channels=-1,
+                 transformer_depth=1, use_linear=False, use_checkpoint=False, temporal_conv=False,
+                 tempspatial_aware=False, temporal_attention=True, temporal_selfatt_only=True,
+                 use_relative_position=True, use_causal_attention=False, temporal_length=None, use_fp16=False,
+                 addition_attention=False, use_image_attention=False, temporal_transformer_depth=1, fps_cond=False):
+        super().__init__()
+        # same asserts as openaimodel3d.py:339-342
+        if num_heads == -1:
+            assert num_head_channels != -1, 'Either num_heads or num_head_channels has to be set'
+        if num_head_channels == -1:
+            assert num_heads != -1, 'Either num_heads or num_head_channels has to be set'
+        unsupported = []
+        if dims != 2: unsupported.append("dims != 2")
+        if use_scale_shift_norm: unsupported.append("use_scale_shift_norm")
+        if resblock_updown: unsupported.append("resblock_updown")
+        if tempspatial_aware: unsupported.append("tempspatial_aware")
+        if use_relative_position: unsupported.append("use_relative_position")
+        if use_causal_attention: unsupported.append("use_causal_attention")
+        if use_image_attention: unsupported.append("use_image_attention")
+        if not temporal_selfatt_only: unsupported.append("temporal_selfatt_only=False")
+        if not conv_resample: unsupported.append("conv_resample=False")
+        if num_head_channels != 64: unsupported.append("num_head_channels != 64 (kernels are head-dim 64)")
+        if model_channels % 32 or model_channels % 64: unsupported.append("model_channels % 64 != 0")
+        if unsupported:
+            raise NotImplementedError("moca_video_amd.UNetModel covers the inference_t2v_512_v2.0.yaml surface; "
+                                      "unsupported: " + ", ".join(unsupported))
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = list(attention_resolutions)
+        self.dropout = dropout            # inference only: Dropout is the identity
+        self.channel_mult = list(channel_mult)
+        self.temporal_attention = temporal_attention
+        self.use_checkpoint = use_checkpoint  # accepted and ignored (no autograd on this path)
+        self.dtype = torch.float16            # compute dtype of the HIP path (reference: :355)
+        self.addition_attention = addition_attention
+        self.fps_cond = fps_cond
+        self.context_dim = context_dim
+        self.temporal_length = temporal_length
+        time_embed_dim = model_channels * 4
+
+        self.time_embed = _seq(_Param((time_embed_dim, model_channels)), nn.Identity(), _Param((time_embed_dim, time_embed_dim)))
+        if fps_cond:
+            self.fps_embedding = _seq(_Param((time_embed_dim, model_channels)), nn.Identity(), _Param((time_embed_dim, time_embed_dim)))
+
+        self.input_blocks = nn.ModuleList([_seq(_Param((model_channels, in_channels, 3, 3), kind="conv"))])
+        if addition_attention:
+            self.init_attn = _seq(_TemporalTransformer(model_channels, 8, num_head_channels, transformer_depth, use_linear=False))
+
+        def attn_layers(ch):
+            heads = ch // num_head_channels
+            layers = [_SpatialTransformer(ch, heads, num_head_channels, transformer_depth, context_dim, use_linear)]
+            if temporal_attention:
+                layers.append(_TemporalTransformer(ch, heads, num_head_channels, temporal_transformer_depth, use_linear))
+            return layers
+
+        input_block_chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [_ResBlock(ch, time_embed_dim, mult * model_channels, temporal_conv)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers += attn_layers(ch)
+                self.input_blocks.append(_seq(*layers))
+                input_block_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(_seq(_Downsample(ch)))
+                input_block_chans.append(ch)
+                ds *= 2
+        mid = [_ResBlock(ch, time_embed_dim, ch, temporal_conv),
+               _SpatialTransformer(ch, ch // num_head_channels, num_head_channels, transformer_depth, context_dim, use_linear)]
+        if temporal_attention:
+            mid.append(_TemporalTransformer(ch, ch // num_head_channels, num_head_channels, temporal_transformer_depth, use_linear))
+        mid.append(_ResBlock(ch, time_embed_dim, ch, temporal_conv))
+        self.middle_block = _seq(*mid)
+
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = input_block_chans.pop()
+                layers = [_ResBlock(ch + ich, time_embed_dim, mult * model_channels, temporal_conv)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers += attn_layers(ch)
+                if level and i == num_res_blocks:
+                    layers.append(_Upsample(ch))
+                    ds //= 2
+                self.output_blocks.append(_seq(*layers))
+        self.out = _seq(_Param((ch,), kind="norm"), nn.Identity(), _Param((out_channels, model_channels, 3, 3), kind="conv"))
+
+        self._packed = None       # id(param module) -> packed GEMM operands
+        self._plans = {}          # (B,T,H,W,L,in_dtype) -> _Plan
+        self.use_graph = True
+        self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
+        _l.load()                 # fail loudly at construction time if the HIP library is missing
+
+    # ---- weights -----------------------------------------------------------------------
+    def _invalidate(self):
+        self._packed = None
+        self._plans = {}
+
+    def _apply(self, fn, recurse=True):   # .cuda()/.to() moves parameters: re-pack lazily
+        out = super()._apply(fn, recurse)
+        self._invalidate()
+        return out
+
+    def _pack(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("moca_video_amd.UNetModel runs on an MI355X only; call .cuda() first (no CPU path)")
+        P = {}
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+        def norm(m):
+            P[id(m)] = (f32(m.weight), f32(m.bias))
+
+        def lin(m):
+            P[id(m)] = ops.pack_linear(m.weight.detach(), None if m.bias is None else m.bias.detach(), device=dev)
+
+        for mod in self.modules():
+            if isinstance(mod, _ResBlock):
+                norm(mod.in_layers[0]); norm(mod.out_layers[0])
+                c1 = mod.in_layers[2]
+                P[id(c1)] = ops.pack_conv3x3(c1.weight.detach(), c1.bias.detach(), device=dev)
+                c2 = mod.out_layers[3]
+                P[id(c2)] = ops.pack_conv3x3(c2.weight.detach(), c2.bias.detach(), device=dev)
+                lin(mod.emb_layers[1])
+                if isinstance(mod.skip_connection, _Param):
+                    s = mod.skip_connection
+                    P[id(s)] = ops.pack_conv1x1(s.weight.detach(), s.bias.detach(), device=dev)
+            elif isinstance(mod, _TemporalConvBlock):
+                for name, idx in (("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3)):
+                    sq = getattr(mod, name)
+                    norm(sq[0])
+                    P[id(sq[idx])] = ops.pack_tconv3(sq[idx].weight.detach(), sq[idx].bias.detach(), device=dev)
+            elif isinstance(mod, (_SpatialTransformer, _TemporalTransformer)):
+                norm(mod.norm); lin(mod.proj_in); lin(mod.proj_out)
+            elif isinstance(mod, _BasicTransformerBlock):
+                norm(mod.norm1); norm(mod.norm2); norm(mod.norm3)
+                for att in (mod.attn1, mod.attn2):
+                    if att.is_self:
+                        P[id(att)] = ops.pack_linear_cat([att.to_q.weight.detach(), att.to_k.weight.detach(), att.to_v.weight.detach()], device=dev)
+                    else:
+                        P[id(att)] = (ops.pack_linear(att.to_q.weight.detach(), device=dev),
+                                      ops.pack_linear_cat([att.to_k.weight.detach(), att.to_v.weight.detach()], device=dev))
+                    lin(att.to_out[0])
+                g = mod.ff.net[0].proj
+                P[id(g)] = ops.pack_geglu(g.weight.detach().to(dev), g.bias.detach().to(dev), device=dev)
+                lin(mod.ff.net[2])
+            elif isinstance(mod, _Downsample):
+                P[id(mod.op)] = ops.pack_conv3x3(mod.op.weight.detach(), mod.op.bias.detach(), device=dev)
+            elif isinstance(mod, _Upsample):
+                P[id(mod.conv)] = ops.pack_conv3x3(mod.conv.weight.detach(), mod.conv.bias.detach(), device=dev)
+        for sq in (self.time_embed,) + ((self.fps_embedding,) if self.fps_cond else ()):
+            lin(sq[0]); lin(sq[2])
+        cin = self.input_blocks[0][0]
+        P[id(cin)] = ops.pack_conv3x3(cin.weight.detach(), cin.bias.detach(), cpad=8, device=dev)
+        norm(self.out[0])
+        P[id(self.out[2])] = ops.pack_conv3x3(self.out[2].weight.detach(), self.out[2].bias.detach(), device=dev)
+        self._packed = P
+
+    # ---- forward -----------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x, timesteps, context=None, features_adapter=None, fps=16, **kwargs):
+        """openaimodel3d.py:534-578.  x [B,C,T,h,w]; timesteps int64 [B] (or [T] with B == 1: the
+        FIFO per-frame-timestep path, :535; or [B*T] per-(b,t), an extension); context [B,L,ctx];
+        fps int or [B]; unknown kwargs (clean_cond, gamma, ...) are ignored exactly as upstream."""
+        if features_adapter is not None:
+            raise NotImplementedError("features_adapter is always None on the MoCA path")
+        if context is None:
+            raise ValueError("context is required (conditioning_key='crossattn')")
+        if x.dim() != 5 or not x.is_cuda:
+            raise ValueError("x must be a CUDA tensor [B, C, T, h, w]")
+        if self._packed is None:
+            self._pack()
+        B, Cin, T, H, W = x.shape
+        assert Cin == self.in_channels
+        if T > 16:
+            raise ValueError("temporal attention kernel supports T <= 16 (temporal_length of the YAML)")
+        timesteps = torch.as_tensor(timesteps, device=x.device).reshape(-1).to(torch.int64)
+        n_t = timesteps.shape[0]
+        if n_t == B:                       # not is_fifo: emb.repeat_interleave(T) (:548-549)
+            t_rows = timesteps.repeat_interleave(T)
+        elif B == 1 and n_t == T:          # is_fifo (:535): one timestep per frame
+            t_rows = timesteps
+        elif n_t == B * T:                 # extension: per-(b,t) timesteps
+            t_rows = timesteps
+        else:
+            raise ValueError(f"timesteps has {n_t} entries for x of batch {B}, frames {T}")
+        if isinstance(fps, int):
+            fps_rows = torch.full_like(t_rows, fps)       # :540-541
+        else:
+            fps = torch.as_tensor(fps, device=x.device).reshape(-1).to(torch.int64)
+            if fps.shape[0] == B:
+                fps_rows = fps.repeat_interleave(T)
+            elif fps.shape[0] == B * T:
+                fps_rows = fps
+            elif fps.shape[0] == 1:
+                fps_rows = fps.expand(B * T)
+            else:
+                raise ValueError("fps must be an int or a tensor of B entries")
+        if context.shape[0] != B:
+            raise ValueError("context batch must equal x batch")
+        L = context.shape[1]
+        key = (B, T, H, W, L, x.dtype, x.device.index)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(self, B, T, H, W, L, x.dtype, x.device)
+            self._plans[key] = plan
+        return plan.run(x, t_rows, fps_rows, context)
+
+
+from .plan import _Plan  # noqa: E402  (split for readability; needs the classes above)

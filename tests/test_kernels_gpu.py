@@ -1,0 +1,242 @@
+"""Kernel-level parity: every C-ABI kernel of libmoca_hip.so against a plain PyTorch fp32
+restatement of the same op, computed on the same (fp16-rounded) inputs.  These run on the
+GPU box only (`-m gpu`).  Tolerances: fp16 outputs -> max|err| <= 3e-3 * max|ref| (one fp16
+rounding is 4.9e-4 relative; K up to ~3000 fp32-accumulated products); fp32 sampler /
+FreeInit kernels -> 1e-5 relative."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from moca_video_amd import lib as L  # noqa: E402
+from moca_video_amd import ops  # noqa: E402
+
+DEV = "cuda"
+TOL16 = 3e-3
+
+
+def relerr(got, ref):
+    got, ref = got.float(), ref.float()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+
+
+def check(got, ref, tol, what):
+    assert torch.isfinite(got.float()).all(), f"{what}: non-finite output"
+    e = relerr(got, ref)
+    assert e <= tol, f"{what}: rel max err {e:.3e} > {tol:.1e}"
+
+
+@pytest.fixture(autouse=True)
+def _stream():
+    ops.set_stream(None)
+    yield
+    torch.cuda.synchronize()
+
+
+def rnd(*shape, scale=1.0, dtype=torch.float16, seed=[0]):
+    seed[0] += 1
+    g = torch.Generator(device="cpu").manual_seed(1234 + seed[0])
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+# ---------------------------------------------------------------- GEMM: linear
+@pytest.mark.parametrize("M,N,K,splits", [(300, 192, 328, 1), (1000, 256, 2880, 1), (128, 64, 64, 1),
+                                         (640, 1280, 2304, 1), (640, 1280, 2304, 4), (77, 640, 1024, 3),
+                                         (16, 1280, 320, 1)])
+def test_gemm_linear(M, N, K, splits):
+    a = rnd(M, K)
+    w = rnd(N, K, scale=K ** -0.5)
+    b = rnd(N, dtype=torch.float32)
+    res = rnd(M, N)
+    pw = ops.pack_linear(w, b)
+    out = torch.empty(M, pw.N, dtype=torch.float16, device=DEV)
+    ws = torch.empty(splits * M * pw.N, dtype=torch.float32, device=DEV) if splits > 1 else None
+    ops.gemm(a, pw, out, M=M, residual=res if pw.N == N else None, splits=splits, splitk_ws=ws)
+    ref = a.float() @ w.float().t() + b
+    if pw.N == N:
+        ref = ref + res.float()
+    check(out[:, :N], ref, TOL16, f"gemm linear {M}x{N}x{K} s{splits}")
+
+
+def test_gemm_rowadd_f32out():
+    M, N, K, div = 600, 128, 256, 100
+    a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+    ra = rnd(M // div, N)
+    pw = ops.pack_linear(w, None)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(a, pw, out, M=M, rowadd=ra, rowadd_div=div, out_f32=True)
+    ref = a.float() @ w.float().t() + ra.float().repeat_interleave(div, dim=0)
+    check(out, ref, 1e-3, "gemm rowadd f32")
+
+
+@pytest.mark.parametrize("splits", [1, 2])
+def test_gemm_geglu(splits):
+    M, K, inner = 520, 320, 1280
+    a = rnd(M, K)
+    w = rnd(2 * inner, K, scale=K ** -0.5)
+    b = rnd(2 * inner, dtype=torch.float32, scale=0.1)
+    pw = ops.pack_geglu(w, b)
+    out = torch.empty(M, inner, dtype=torch.float16, device=DEV)
+    ws = torch.empty(splits * M * pw.N, dtype=torch.float32, device=DEV) if splits > 1 else None
+    ops.gemm(a, pw, out, M=M, splits=splits, splitk_ws=ws)
+    y = a.float() @ w.float().t() + b
+    ref = y[:, :inner] * F.gelu(y[:, inner:])
+    check(out, ref, TOL16, "gemm geglu")
+
+
+# ---------------------------------------------------------------- GEMM: conv
+def nhwc(x):   # [F,C,H,W] -> [F,H,W,C] contiguous
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("Fr,C,H,W,N,stride,up", [(3, 64, 10, 12, 128, 1, 0), (2, 320, 8, 8, 320, 1, 0),
+                                                  (2, 64, 10, 12, 64, 2, 0), (2, 64, 5, 6, 128, 1, 1),
+                                                  (1, 8, 16, 16, 320, 1, 0), (16, 128, 5, 8, 128, 1, 0)])
+def test_gemm_conv3x3(Fr, C, H, W, N, stride, up):
+    x = rnd(Fr, C, H, W)
+    w = rnd(N, C, 3, 3, scale=(9 * C) ** -0.5)
+    b = rnd(N, dtype=torch.float32)
+    pw = ops.pack_conv3x3(w, b)
+    xin = x.float()
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, w.float(), b, stride=stride, padding=1)
+    oH, oW = ref.shape[-2:]
+    M = Fr * oH * oW
+    out = torch.empty(M, pw.N, dtype=torch.float16, device=DEV)
+    ops.gemm(nhwc(x), pw, out, M=M, mode=L.MOCA_A_CONV3X3, conv=(C, H, W, oH, oW, stride, up))
+    got = out.view(Fr, oH, oW, pw.N)[..., :N].permute(0, 3, 1, 2)
+    check(got, ref, TOL16, f"conv3x3 s{stride} up{up}")
+
+
+@pytest.mark.parametrize("B,T,HW,C,N", [(2, 5, 30, 64, 64), (1, 16, 40, 320, 320), (1, 8, 64, 128, 128)])
+def test_gemm_tconv(B, T, HW, C, N):
+    x = rnd(B, C, T, HW, 1)
+    w = rnd(N, C, 3, 1, 1, scale=(3 * C) ** -0.5)
+    b = rnd(N, dtype=torch.float32)
+    pw = ops.pack_tconv3(w, b)
+    ref = F.conv3d(x.float(), w.float(), b, padding=(1, 0, 0))          # [B,N,T,HW,1]
+    xr = x[..., 0].permute(0, 2, 3, 1).contiguous()                      # [B,T,HW,C]
+    M = B * T * HW
+    out = torch.empty(M, pw.N, dtype=torch.float16, device=DEV)
+    res = rnd(M, pw.N)
+    ops.gemm(xr, pw, out, M=M, mode=L.MOCA_A_TCONV3, tconv=(C, T, HW), residual=res)
+    got = out.view(B, T, HW, pw.N).permute(0, 3, 1, 2)
+    check(got, ref[..., 0] + res.float().view(B, T, HW, pw.N).permute(0, 3, 1, 2), TOL16, "tconv3")
+
+
+# ---------------------------------------------------------------- norms
+@pytest.mark.parametrize("Fr,HW,C,fps,silu,eps", [(4, 100, 320, 1, True, 1e-5), (4, 100, 320, 2, True, 1e-5),
+                                                   (16, 40, 1280, 16, False, 1e-6), (2, 2560, 320, 1, False, 1e-6),
+                                                   (3, 37, 64, 1, True, 1e-5), (2, 64, 2560, 1, True, 1e-5),
+                                                   (8, 64, 960, 8, True, 1e-5)])
+def test_groupnorm(Fr, HW, C, fps, silu, eps):
+    x = (rnd(Fr, HW, C) * 1.5 + 0.7).half()
+    g = rnd(C, dtype=torch.float32) * 0.2 + 1.0
+    b = rnd(C, dtype=torch.float32) * 0.2
+    y = torch.empty_like(x)
+    ws = torch.empty(ops.groupnorm_ws_floats(Fr, HW, C), dtype=torch.float32, device=DEV)
+    ops.groupnorm(x, y, g, b, F=Fr, HW=HW, Cn=C, frames_per_stat=fps, eps=eps, silu=silu, ws=ws)
+    # reference: [B, C, fps*HW]
+    xr = x.float().view(Fr // fps, fps * HW, C).permute(0, 2, 1)
+    ref = F.group_norm(xr, 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(Fr, HW, C)
+    check(y, ref, TOL16, "groupnorm")
+
+
+@pytest.mark.parametrize("M,C", [(500, 320), (333, 640), (200, 1280), (64, 512), (10, 2560)])
+def test_layernorm(M, C):
+    x = (rnd(M, C) * 2 + 0.5).half()
+    g = rnd(C, dtype=torch.float32) * 0.2 + 1.0
+    b = rnd(C, dtype=torch.float32) * 0.2
+    y = torch.empty_like(x)
+    ops.layernorm(x, y, g, b, M=M, Cn=C)
+    check(y, F.layer_norm(x.float(), (C,), g, b, 1e-5), TOL16, "layernorm")
+
+
+# ---------------------------------------------------------------- attention
+def sdpa_ref(q, k, v, scale):
+    s = torch.einsum("bhid,bhjd->bhij", q.float(), k.float()) * scale
+    return torch.einsum("bhij,bhjd->bhid", s.softmax(-1), v.float())
+
+
+@pytest.mark.parametrize("Bq,heads,Nq,Nk,kv_div", [(4, 5, 300, 300, 1), (2, 5, 2560, 2560, 1), (4, 10, 160, 77, 2),
+                                                   (6, 5, 100, 154, 3), (2, 20, 40, 40, 1), (1, 1, 33, 1, 1)])
+def test_attention(Bq, heads, Nq, Nk, kv_div):
+    C = heads * 64
+    Bk = Bq // kv_div
+    q = rnd(Bq, Nq, C)
+    kv = rnd(Bk, Nk, 2 * C)
+    k, v = kv[..., :C], kv[..., C:]
+    out = torch.empty(Bq, Nq, C, dtype=torch.float16, device=DEV)
+    ops.attention(q, k, v, out, Bq=Bq, heads=heads, Nq=Nq, Nk=Nk, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, kv_div=kv_div,
+                  scale=0.125)
+    qh = q.view(Bq, Nq, heads, 64).permute(0, 2, 1, 3)
+    kh = k.reshape(Bk, Nk, heads, 64).permute(0, 2, 1, 3).repeat_interleave(kv_div, dim=0)
+    vh = v.reshape(Bk, Nk, heads, 64).permute(0, 2, 1, 3).repeat_interleave(kv_div, dim=0)
+    ref = sdpa_ref(qh, kh, vh, 0.125).permute(0, 2, 1, 3).reshape(Bq, Nq, C)
+    check(out, ref, TOL16, "attention")
+
+
+def test_attention_peaky():
+    """online-softmax rescale path: a late key dominates an early maximum."""
+    Bq, heads, Nq, Nk = 1, 1, 64, 200
+    q = rnd(Bq, Nq, 64)
+    k = rnd(Bq, Nk, 64)
+    v = rnd(Bq, Nk, 64)
+    k[0, 150] = q[0, 3] * 4.0
+    k[0, 10] = q[0, 3] * 2.0
+    out = torch.empty(Bq, Nq, 64, dtype=torch.float16, device=DEV)
+    ops.attention(q, k, v, out, Bq=1, heads=1, Nq=Nq, Nk=Nk, ldq=64, ldk=64, ldv=64, ldo=64, kv_div=1, scale=0.125)
+    ref = sdpa_ref(q[:, None], k[:, None], v[:, None], 0.125)[:, 0]
+    check(out, ref, TOL16, "attention peaky")
+
+
+@pytest.mark.parametrize("B,T,HW,heads", [(2, 16, 50, 5), (1, 8, 64, 8), (1, 16, 2560, 5), (3, 5, 7, 2)])
+def test_temporal_attention(B, T, HW, heads):
+    C = heads * 64
+    qkv = rnd(B * T * HW, 3 * C)
+    out = torch.empty(B * T * HW, C, dtype=torch.float16, device=DEV)
+    ops.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, B=B, T=T, HW=HW, heads=heads,
+                           ld_qkv=3 * C, ldo=C, scale=0.125)
+    x = qkv.view(B, T, HW, 3, heads, 64).permute(3, 0, 2, 4, 1, 5)   # [3,B,HW,heads,T,64]
+    ref = sdpa_ref(x[0].reshape(-1, heads, T, 64), x[1].reshape(-1, heads, T, 64), x[2].reshape(-1, heads, T, 64), 0.125)
+    ref = ref.view(B, HW, heads, T, 64).permute(0, 3, 1, 2, 4).reshape(B * T * HW, C)
+    check(out, ref, TOL16, "temporal attention")
+
+
+# ---------------------------------------------------------------- layout / embedding
+def test_layout_roundtrip_and_concat():
+    B, Cc, T, HW = 2, 4, 5, 30
+    x = rnd(B, Cc, T, HW, dtype=torch.float32)
+    y = torch.empty(B * T * HW, 8, dtype=torch.float16, device=DEV)
+    ops.ncthw_to_nhwc(x, y, B=B, Cin=Cc, T=T, HW=HW, Cpad=8)
+    ref = x.permute(0, 2, 3, 1).reshape(B * T * HW, Cc).half()
+    assert torch.equal(y[:, :Cc], ref) and (y[:, Cc:] == 0).all()
+    back = torch.empty(B, Cc, T, HW, dtype=torch.float32, device=DEV)
+    ops.nhwc_to_ncthw(y, 8, back, B=B, Cout=Cc, T=T, HW=HW)
+    assert torch.equal(back, x.half().float())
+    a, b = rnd(100, 64), rnd(100, 40)
+    o = torch.empty(100, 104, dtype=torch.float16, device=DEV)
+    ops.concat_channels(a, b, o, rows=100, C1=64, C2=40)
+    assert torch.equal(o, torch.cat([a, b], 1))
+
+
+def test_timestep_embedding_and_silu_rows():
+    t = torch.tensor([0, 1, 17, 500, 999, 250], dtype=torch.int64, device=DEV)
+    out = torch.empty(6, 320, dtype=torch.float16, device=DEV)
+    ops.timestep_embedding(t, out, n=6, dim=320)
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=DEV) / half)
+    args = t[:, None].float() * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    assert (out.float() - ref).abs().max().item() < 2e-3
+    a, b = rnd(6, 128), rnd(2, 128)
+    o = torch.empty(6, 128, dtype=torch.float16, device=DEV)
+    ops.silu_add_rows(a, 1, b, 3, o, rows=6, Cn=128, silu=True)
+    check(o, F.silu(a.float() + b.float().repeat_interleave(3, 0)), TOL16, "silu_add_rows")
