@@ -1,0 +1,328 @@
+"""Recorded forward of the MI355X UNet: walks the reference-shaped module tree ONCE per
+input signature, allocates every intermediate from a pool and records the launch
+sequence (C-ABI calls with bound device pointers).  Replays are a single hipGraph launch.
+
+Data layout in HBM: every activation is a row-major [B*T*H*W][C] fp16 matrix
+(channels-last, frame outermost).  Spatial ops see contiguous channels per pixel; the
+temporal conv / temporal attention reach the other frames of a pixel with a constant
+row stride of H*W, so the reference's `(b t) c h w <-> b c t h w <-> (b h w) t c`
+rearranges (openaimodel3d.py:43-45,231-233; attention.py:268,275,335-338,352,367) do
+not exist here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+import warnings
+
+import torch
+
+from . import lib as _l
+from . import ops
+from .unet import (_BasicTransformerBlock, _Downsample, _FMap, _Pool, _ResBlock, _SpatialTransformer,
+                   _TemporalTransformer, _Upsample)
+
+N_CU = 256
+
+
+class _Plan:
+    def __init__(self, model, B, T, H, W, L, in_dtype, device):
+        self.model, self.B, self.T, self.H, self.W, self.L = model, B, T, H, W, L
+        self.BT = B * T
+        self.device = device
+        self.P = model._packed
+        self.pool = _Pool(device)
+        self.stream = torch.cuda.Stream(device=device)
+        self.steps = []
+        self._pinned = set()
+        self.graph = None
+        self.graph_failed = False
+        self.n_runs = 0
+        m = model
+        self.x_in = torch.empty(B, m.in_channels, T, H, W, dtype=in_dtype, device=device)
+        self.t_rows = torch.empty(self.BT, dtype=torch.int64, device=device)
+        self.fps_rows = torch.empty(self.BT, dtype=torch.int64, device=device)
+        self.ctx = torch.empty(B * L, m.context_dim, dtype=torch.float16, device=device)
+        self.out = torch.empty(B, m.out_channels, T, H, W, dtype=in_dtype, device=device)
+        self._build()
+
+    # ------------------------------------------------------------------ emit helpers
+    def _emit(self, fn, *args, **kw):
+        self.steps.append(functools.partial(fn, *args, **kw))
+
+    def _release(self, *bufs):
+        for b in bufs:
+            if b is None:
+                continue
+            if b.data_ptr() in self._pinned:
+                continue
+            self.pool.put(b)
+
+    def _splits(self, M, pw):
+        bn = 128 if pw.N % 128 == 0 else 64
+        tiles = ((M + 127) // 128) * (pw.N // bn)
+        nk = pw.w.shape[1] // 64
+        if tiles >= N_CU:
+            return 1
+        return max(1, min((N_CU * 3 // 2) // tiles, nk // 8))
+
+    def _gemm(self, a, pw, M, *, out_cols=None, **kw):
+        n_out = pw.n_out if pw.geglu else pw.N
+        out = self.pool.get(M, n_out)
+        splits = self._splits(M, pw)
+        ws = None
+        if splits > 1:
+            ws = self.pool.get(splits * M, pw.N, torch.float32)
+        self._emit(ops.gemm, a, pw, out, M=M, splits=splits, splitk_ws=ws, **kw)
+        if ws is not None:
+            self.pool.put(ws)
+        return out
+
+    def linear(self, a, M, pw, residual=None, lda=None):
+        return self._gemm(a, pw, M, lda=lda if lda is not None else a.stride(-2), residual=residual)
+
+    def conv(self, fm, pw, *, stride=1, up=0, rowadd=None, rowadd_div=1, residual=None):
+        if up:
+            oH, oW = fm.H * 2, fm.W * 2
+        elif stride == 2:
+            oH, oW = (fm.H - 1) // 2 + 1, (fm.W - 1) // 2 + 1
+        else:
+            oH, oW = fm.H, fm.W
+        M = fm.F * oH * oW
+        out = self._gemm(fm.buf, pw, M, mode=_l.MOCA_A_CONV3X3, conv=(fm.C, fm.H, fm.W, oH, oW, stride, up),
+                         rowadd=rowadd, rowadd_div=rowadd_div, residual=residual)
+        return _FMap(out, fm.F, oH, oW, pw.N)
+
+    def tconv(self, fm, pw, residual=None):
+        out = self._gemm(fm.buf, pw, fm.M, mode=_l.MOCA_A_TCONV3, tconv=(fm.C, self.T, fm.H * fm.W), residual=residual)
+        return _FMap(out, fm.F, fm.H, fm.W, pw.N)
+
+    def gn(self, fm, gb, *, fps, eps, silu):
+        y = self.pool.get(fm.M, fm.C)
+        ws = self.pool.get(1, ops.groupnorm_ws_floats(fm.F, fm.H * fm.W, fm.C), torch.float32)
+        self._emit(ops.groupnorm, fm.buf, y, gb[0], gb[1], F=fm.F, HW=fm.H * fm.W, Cn=fm.C, frames_per_stat=fps,
+                   eps=eps, silu=silu, ws=ws)
+        self.pool.put(ws)
+        return y
+
+    def ln(self, x, M, Cn, gb):
+        y = self.pool.get(M, Cn)
+        self._emit(ops.layernorm, x, y, gb[0], gb[1], M=M, Cn=Cn, eps=1e-5)
+        return y
+
+    # ------------------------------------------------------------------ blocks
+    def res_block(self, mod, x):
+        """ResBlock._forward, openaimodel3d.py:208-234"""
+        P, HW = self.P, x.H * x.W
+        g1 = self.gn(x, P[id(mod.in_layers[0])], fps=1, eps=1e-5, silu=True)
+        emb_out = self.linear(self.emb_silu, self.BT, P[id(mod.emb_layers[1])])
+        h1 = self.conv(_FMap(g1, x.F, x.H, x.W, x.C), P[id(mod.in_layers[2])], rowadd=emb_out, rowadd_div=HW)
+        self._release(g1, emb_out)
+        g2 = self.gn(h1, P[id(mod.out_layers[0])], fps=1, eps=1e-5, silu=True)
+        self._release(h1.buf)
+        if isinstance(mod.skip_connection, torch.nn.Identity):
+            sk = x.buf
+        else:
+            sk = self.linear(x.buf, x.M, P[id(mod.skip_connection)])
+        h2 = self.conv(_FMap(g2, x.F, x.H, x.W, mod.cout), P[id(mod.out_layers[3])], residual=sk)
+        self._release(g2)
+        if sk is not x.buf:
+            self._release(sk)
+        if not mod.use_temporal_conv:
+            return h2
+        # TemporalConvBlock.forward, openaimodel3d.py:269-276 (GroupNorm statistics over (C/32, T, H, W))
+        tc = mod.temopral_conv
+        cur = h2
+        for i, (name, idx) in enumerate((("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3))):
+            sq = getattr(tc, name)
+            g = self.gn(cur, P[id(sq[0])], fps=self.T, eps=1e-5, silu=True)
+            nxt = self.tconv(_FMap(g, cur.F, cur.H, cur.W, cur.C), P[id(sq[idx])], residual=h2.buf if i == 3 else None)
+            self._release(g)
+            if cur is not h2:
+                self._release(cur.buf)
+            cur = nxt
+        self._release(h2.buf)
+        return cur
+
+    def _attn_self(self, att, l, M, Cn, heads, spatial, F, HW):
+        P = self.P
+        qkv = self.linear(l, M, P[id(att)])                     # [M][3C] fused to_q|to_k|to_v
+        o = self.pool.get(M, Cn)
+        q, k, v = qkv[:, :Cn], qkv[:, Cn:2 * Cn], qkv[:, 2 * Cn:]
+        scale = att.dim_head ** -0.5
+        if spatial:
+            self._emit(ops.attention, q, k, v, o, Bq=F, heads=heads, Nq=HW, Nk=HW, ldq=3 * Cn, ldk=3 * Cn, ldv=3 * Cn,
+                       ldo=Cn, kv_div=1, scale=scale)
+        else:
+            self._emit(ops.temporal_attention, q, k, v, o, B=self.B, T=self.T, HW=HW, heads=heads, ld_qkv=3 * Cn, ldo=Cn,
+                       scale=scale)
+        self._release(qkv)
+        return o
+
+    def _attn_cross(self, att, l, M, Cn, heads, F, HW):
+        pq, pkv = self.P[id(att)]
+        q = self.linear(l, M, pq)
+        kv = self.linear(self.ctx, self.B * self.L, pkv)         # one K/V per video (context.repeat_interleave, :547)
+        o = self.pool.get(M, Cn)
+        self._emit(ops.attention, q, kv[:, :Cn], kv[:, Cn:], o, Bq=F, heads=heads, Nq=HW, Nk=self.L, ldq=Cn, ldk=2 * Cn,
+                   ldv=2 * Cn, ldo=Cn, kv_div=self.T, scale=att.dim_head ** -0.5)
+        self._release(q, kv)
+        return o
+
+    def tblock(self, blk, h, M, Cn, heads, spatial, F, HW):
+        """BasicTransformerBlock._forward, attention.py:216-220"""
+        P = self.P
+        for att, nrm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):
+            l = self.ln(h, M, Cn, P[id(nrm)])
+            if att.is_self:
+                o = self._attn_self(att, l, M, Cn, heads, spatial, F, HW)
+            else:
+                o = self._attn_cross(att, l, M, Cn, heads, F, HW)
+            self._release(l)
+            nh = self.linear(o, M, P[id(att.to_out[0])], residual=h)
+            self._release(o, h)
+            h = nh
+        l = self.ln(h, M, Cn, P[id(blk.norm3)])
+        ff = self.linear(l, M, P[id(blk.ff.net[0].proj)])        # GEGLU fused into the epilogue
+        self._release(l)
+        nh = self.linear(ff, M, P[id(blk.ff.net[2])], residual=h)
+        self._release(ff, h)
+        return nh
+
+    def transformer(self, mod, x, spatial):
+        """SpatialTransformer.forward attention.py:262-278 / TemporalTransformer.forward :331-373"""
+        P = self.P
+        n = self.gn(x, P[id(mod.norm)], fps=1 if spatial else self.T, eps=1e-6, silu=False)
+        h = self.linear(n, x.M, P[id(mod.proj_in)])
+        self._release(n)
+        for blk in mod.transformer_blocks:
+            h = self.tblock(blk, h, x.M, mod.inner, mod.heads, spatial, x.F, x.H * x.W)
+        out = self.linear(h, x.M, P[id(mod.proj_out)], residual=x.buf)
+        self._release(h)
+        return _FMap(out, x.F, x.H, x.W, x.C)
+
+    def run_seq(self, seq, h):
+        """TimestepEmbedSequential.forward, openaimodel3d.py:36-48"""
+        for layer in seq:
+            if isinstance(layer, _ResBlock):
+                nh = self.res_block(layer, h)
+            elif isinstance(layer, _SpatialTransformer):
+                nh = self.transformer(layer, h, True)
+            elif isinstance(layer, _TemporalTransformer):
+                nh = self.transformer(layer, h, False)
+            elif isinstance(layer, _Downsample):
+                nh = self.conv(h, self.P[id(layer.op)], stride=2)
+            elif isinstance(layer, _Upsample):
+                nh = self.conv(h, self.P[id(layer.conv)], up=1)
+            else:
+                raise TypeError(type(layer))
+            self._release(h.buf)
+            h = nh
+        return h
+
+    # ------------------------------------------------------------------ whole forward
+    def _embed_mlp(self, sq, rows_t):
+        """timestep_embedding -> Linear -> SiLU -> Linear (openaimodel3d.py:362-372,536-543)"""
+        m, P, BT = self.model, self.P, self.BT
+        te = self.pool.get(BT, m.model_channels)
+        self._emit(ops.timestep_embedding, rows_t, te, n=BT, dim=m.model_channels)
+        e1 = self.linear(te, BT, P[id(sq[0])])
+        s1 = self.pool.get(BT, e1.shape[1])
+        self._emit(ops.silu_add_rows, e1, 1, None, 1, s1, rows=BT, Cn=e1.shape[1], silu=True)
+        e2 = self.linear(s1, BT, P[id(sq[2])])
+        self._release(te, e1, s1)
+        return e2
+
+    def _build(self):
+        m, P, B, T, H, W = self.model, self.P, self.B, self.T, self.H, self.W
+        BT = self.BT
+        emb = self._embed_mlp(m.time_embed, self.t_rows)
+        femb = self._embed_mlp(m.fps_embedding, self.fps_rows) if m.fps_cond else None
+        # every consumer of `emb` is ResBlock.emb_layers = SiLU -> Linear (openaimodel3d.py:166-172)
+        self.emb_silu = self.pool.get(BT, emb.shape[1])
+        self._emit(ops.silu_add_rows, emb, 1, femb, 1, self.emb_silu, rows=BT, Cn=emb.shape[1], silu=True)
+        self._release(emb, femb)
+        self._pinned.add(self.emb_silu.data_ptr())
+
+        x8 = self.pool.get(BT * H * W, 8)
+        self._emit(ops.ncthw_to_nhwc, self.x_in, x8, B=B, Cin=m.in_channels, T=T, HW=H * W, Cpad=8)
+        h = self.conv(_FMap(x8, BT, H, W, 8), P[id(m.input_blocks[0][0])])
+        self._release(x8)
+        hs = []
+        for i, module in enumerate(m.input_blocks):
+            if i == 0:
+                if m.addition_attention:
+                    nh = self.transformer(m.init_attn[0], h, False)
+                    self._release(h.buf)
+                    h = nh
+            else:
+                h = self.run_seq(module, h)
+            hs.append(h)
+            self._pinned.add(h.buf.data_ptr())
+        h = self.run_seq(m.middle_block, h)
+        for module in m.output_blocks:
+            skip = hs.pop()
+            cat = self.pool.get(h.M, h.C + skip.C)
+            self._emit(ops.concat_channels, h.buf, skip.buf, cat, rows=h.M, C1=h.C, C2=skip.C)   # torch.cat(dim=1), :571
+            self._pinned.discard(skip.buf.data_ptr())
+            self._release(h.buf, skip.buf)
+            h = self.run_seq(module, _FMap(cat, h.F, h.H, h.W, h.C + skip.C))
+        g = self.gn(h, P[id(m.out[0])], fps=1, eps=1e-5, silu=True)
+        self._release(h.buf)
+        o = self.conv(_FMap(g, h.F, h.H, h.W, h.C), P[id(m.out[2])])
+        self._release(g)
+        self._emit(ops.nhwc_to_ncthw, o.buf, o.C, self.out, B=B, Cout=m.out_channels, T=T, HW=H * W)
+        self._release(o.buf)
+
+    def _run_steps(self):
+        for s in self.steps:
+            s()
+
+    def run(self, x, t_rows, fps_rows, context):
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.x_in.copy_(x, non_blocking=True)
+            self.t_rows.copy_(t_rows, non_blocking=True)
+            self.fps_rows.copy_(fps_rows, non_blocking=True)
+            self.ctx.copy_(context.reshape(self.B * self.L, -1), non_blocking=True)
+            handle = self.stream.cuda_stream
+            ops.set_stream(handle)
+            try:
+                self._launch(handle)
+            finally:
+                ops.set_stream(None)
+            out = self.out.clone()
+        out.record_stream(cur)
+        cur.wait_stream(self.stream)
+        self.n_runs += 1
+        return out
+
+    def _launch(self, handle):
+        lib = _l.load()
+        if self.graph is not None:
+            _l.check(lib.moca_graph_launch(self.graph, C.c_void_p(handle)), "moca_graph_launch")
+            return
+        use_graph = self.model.use_graph and not self.graph_failed
+        if self.n_runs == 0 or not use_graph:
+            self._run_steps()          # first pass eager: surfaces argument errors outside of capture
+            return
+        # second pass: record the same launch sequence into a hipGraph, then replay it
+        rc = lib.moca_graph_begin(C.c_void_p(handle))
+        if rc != 0:
+            self.graph_failed = True
+            warnings.warn("moca_video_amd: hipStreamBeginCapture failed; staying on eager HIP launches")
+            self._run_steps()
+            return
+        try:
+            self._run_steps()
+        finally:
+            g = C.c_void_p()
+            rc = lib.moca_graph_end(C.c_void_p(handle), C.byref(g))
+        if rc != 0 or not g.value:
+            self.graph_failed = True
+            warnings.warn("moca_video_amd: hipGraph instantiate failed; staying on eager HIP launches")
+            self._run_steps()
+            return
+        self.graph = g
+        _l.check(lib.moca_graph_launch(self.graph, C.c_void_p(handle)), "moca_graph_launch")

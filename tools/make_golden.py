@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (imported read-only from
+/root/reference) on CPU.  Runs only in the build container; the reference never
+travels, only these small input-recipe/output fixtures do.
+
+    python tools/make_golden.py [--full]      (--full adds the full-width 1.41 B-param UNet cases)
+
+Inputs and parameters are not stored: they are regenerated bit-identically from
+moca_video_amd.weightgen (numpy Philox keyed by tensor name), so a fixture is
+{recipe metadata, expected outputs}.
+"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    """Harness-side stubs for packages the image lacks and the hot path never calls."""
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.path.insert(0, REF)
+    stub("cv2")
+    stub("pytorch_lightning", LightningModule=torch.nn.Module)
+    tv = stub("torchvision")
+    tv.utils = stub("torchvision.utils", make_grid=None, save_image=None)
+    tv.transforms = stub("torchvision.transforms")
+    tr = stub("transformers", AutoProcessor=None, AutoModelForZeroShotObjectDetection=None)
+    stub("sam2")
+    stub("sam2.build_sam", build_sam2_video_predictor=None, build_sam2=None)
+    stub("sam2.sam2_image_predictor", SAM2ImagePredictor=None)
+    stub("decord", VideoReader=None, cpu=None)
+    stub("imageio")
+    from lvdm.modules.networks import openaimodel3d  # noqa
+    from lvdm.modules import attention  # noqa
+    return openaimodel3d, attention
+
+
+def inp(name, shape, seed=0):
+    from moca_video_amd.weightgen import gen_tensor
+    # 2-D+ tensors from gen_tensor are scaled by fan_in^-0.5; inputs want unit variance
+    t = gen_tensor("input:" + name, (int(np.prod(shape)),), seed)   # 1-D, 'input:..' does not end in 'weight' -> 0.1*z
+    return (t * 10.0).reshape(shape)
+
+
+def fill(module, seed=0):
+    from moca_video_amd.weightgen import fill_module_
+    return fill_module_(module, seed)
+
+
+def save(name, **arrays):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# --------------------------------------------------------------------------------------
+def blocks(om, att):
+    torch.manual_seed(0)
+    with torch.no_grad():
+        # ResBlock 64 -> 128 with TemporalConvBlock, b=2, t=4, 6x10
+        rb = fill(om.ResBlock(64, 256, 0.0, out_channels=128, dims=2, use_checkpoint=False, use_temporal_conv=True).eval(), 1)
+        x = inp("rb.x", (8, 64, 6, 10)); emb = inp("rb.emb", (8, 256))
+        save("block_resblock", y=rb(x, emb, batch_size=2), meta=np.array([2, 4, 64, 128, 6, 10, 256]))
+        rb2 = fill(om.ResBlock(64, 256, 0.0, out_channels=64, dims=2, use_checkpoint=False, use_temporal_conv=True).eval(), 2)
+        save("block_resblock_same", y=rb2(x, emb, batch_size=2))
+        # SpatialTransformer 128 ch, 2 heads, ctx 96 dims, 77 tokens
+        st = fill(att.SpatialTransformer(128, 2, 64, depth=1, context_dim=96, use_linear=True, use_checkpoint=False).eval(), 3)
+        x = inp("st.x", (4, 128, 6, 10)); ctx = inp("st.ctx", (4, 77, 96))
+        save("block_spatial_transformer", y=st(x, ctx))
+        # TemporalTransformer (linear) 128 ch, and the init_attn flavour (conv1d proj, 8 heads on 64 ch)
+        tt = fill(att.TemporalTransformer(128, 2, 64, depth=1, use_linear=True, use_checkpoint=False, only_self_att=True,
+                                          relative_position=False, temporal_length=16).eval(), 4)
+        x5 = inp("tt.x", (2, 128, 8, 3, 5))
+        save("block_temporal_transformer", y=tt(x5))
+        ti = fill(att.TemporalTransformer(64, 8, 64, depth=1, use_checkpoint=False, only_self_att=True,
+                                          relative_position=False, temporal_length=16).eval(), 5)
+        x5 = inp("ti.x", (1, 64, 16, 3, 5))
+        save("block_init_attn", y=ti(x5))
+        # Downsample / Upsample
+        dn = fill(om.Downsample(64, True, dims=2, out_channels=64).eval(), 6)
+        up = fill(om.Upsample(64, True, dims=2, out_channels=64).eval(), 7)
+        x = inp("ud.x", (3, 64, 6, 10))
+        save("block_down_up", down=dn(x), up=up(x))
+        # timestep_embedding
+        from lvdm.models.utils_diffusion import timestep_embedding
+        t = torch.tensor([0, 1, 17, 250, 500, 999])
+        save("timestep_embedding", t=t, y=timestep_embedding(t, 320))
+
+
+REDUCED = dict(in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+               channel_mult=[1, 2, 4, 4], num_head_channels=64, transformer_depth=1, context_dim=128, use_linear=True,
+               use_checkpoint=False, temporal_conv=True, temporal_attention=True, temporal_selfatt_only=True,
+               use_relative_position=False, use_causal_attention=False, temporal_length=16, addition_attention=True,
+               fps_cond=True)
+
+
+def unet_cases(om, params, tag, shape_x, ctx_dim, cases):
+    t0 = time.time()
+    model = om.UNetModel(**params).eval()
+    fill(model, 11)
+    print(f"[{tag}] reference UNet built+filled in {time.time() - t0:.1f}s "
+          f"({sum(p.numel() for p in model.parameters()) / 1e6:.1f} M params)")
+    out = {}
+    with torch.no_grad():
+        for name, B, tvals, L, fps in cases:
+            x = inp(f"{tag}.{name}.x", (B,) + shape_x)
+            ctx = inp(f"{tag}.{name}.ctx", (B, L, ctx_dim))
+            t = torch.tensor(tvals, dtype=torch.long)
+            f = fps if isinstance(fps, int) else torch.tensor(fps, dtype=torch.long)
+            t1 = time.time()
+            y = model(x, t, context=ctx, fps=f, clean_cond=True, gamma=0.5)   # unknown kwargs are swallowed (:534)
+            print(f"[{tag}] {name}: forward {time.time() - t1:.1f}s, out std {y.std():.4f}")
+            out[name] = y
+            out[name + "__t"] = t
+            out[name + "__fps"] = np.asarray(fps)
+            out[name + "__L"] = np.asarray(L)
+    save(f"unet_{tag}", **out)
+    del model
+
+
+def unet_reduced(om):
+    T = 8
+    unet_cases(om, REDUCED, "reduced", (4, T, 16, 16), 128, [
+        ("uniform", 1, [500], 77, 16),
+        ("fifo", 1, [int(v) for v in np.linspace(999, 0, T).round()], 154, [10]),
+        ("batch2", 2, [981, 20], 77, [10, 24]),
+    ])
+
+
+def unet_full(om):
+    import yaml
+    with open(os.path.join(REF, "configs/inference_t2v_512_v2.0.yaml")) as f:
+        params = yaml.safe_load(f)["model"]["params"]["unet_config"]["params"]
+    params = dict(params)
+    params["use_checkpoint"] = False   # no effect on results under no_grad (common.py:80-94)
+    unet_cases(om, params, "full", (4, 8, 32, 32), 1024, [
+        ("cfg0_uniform", 1, [500], 77, [10]),
+        ("cfg0_fifo", 1, [int(v) for v in np.linspace(999, 0, 8).round()], 154, [10]),
+    ])
+    # cfgN: the headline shape, FIFO window call
+    unet_cases(om, params, "full_cfgN", (4, 16, 40, 64), 1024, [
+        ("fifo16", 1, [int(v) for v in np.linspace(999, 0, 16).round()], 77, [10]),
+    ])
+
+
+# --------------------------------------------------------------------------------------
+class FakeModel:
+    """What DDIMSampler reads from LatentDiffusion; apply_model returns queued eps tensors."""
+
+    def __init__(self):
+        from lvdm.models.utils_diffusion import make_beta_schedule
+        betas = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+        ac = np.cumprod(1. - betas, axis=0)
+        self.num_timesteps = 1000
+        self.betas = torch.tensor(betas, dtype=torch.float32)
+        self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+        self.alphas_cumprod_prev = torch.tensor(np.append(1., ac[:-1]), dtype=torch.float32)
+        self.use_scale = True
+        self.scale_arr = torch.tensor(np.concatenate((np.linspace(1, 0.7, 400), np.full(1000, 0.7))), dtype=torch.float32)
+        self.device = torch.device("cpu")
+        self.parameterization = "eps"
+        self.queue = []
+
+    def apply_model(self, x, t, c, **kw):
+        return self.queue.pop(0)
+
+
+def sampler_cases():
+    from lvdm.models.samplers import ddim as D
+    D.DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)   # drop hard-coded .to("cuda") (:53-60)
+    fm = FakeModel()
+    out = {}
+    for S in (10, 50, 64):
+        s = D.DDIMSampler(fm, use_self_attention=True)
+        s.make_schedule(S, ddim_eta=1.0, verbose=False)
+        for k in ("ddim_timesteps", "ddim_sigmas", "ddim_alphas", "ddim_alphas_prev", "ddim_sqrt_one_minus_alphas",
+                  "ddim_scale_arr", "ddim_scale_arr_prev"):
+            out[f"S{S}_{k}"] = np.asarray(getattr(s, k))
+    save("sampler_schedule", **out)
+
+    # p_sample_ddim with CFG, captured noise
+    s = D.DDIMSampler(fm, use_self_attention=True)
+    s.make_schedule(50, ddim_eta=1.0, verbose=False)
+    shape = (1, 4, 8, 16, 24)
+    res = {}
+    for index in (49, 20, 0):
+        x = inp(f"ps.x{index}", shape); e_c = inp(f"ps.ec{index}", shape); e_u = inp(f"ps.eu{index}", shape)
+        nz = inp(f"ps.nz{index}", shape)
+        fm.queue = [e_c.clone(), e_u.clone()]
+        D.noise_like = lambda shp, dev, repeat=False, _n=nz: _n.clone()
+        t = torch.full((1,), int(s.ddim_timesteps[index]), dtype=torch.long)
+        xp, p0 = s.p_sample_ddim(x, {"c_crossattn": [None]}, t, index, unconditional_guidance_scale=12.0,
+                                 unconditional_conditioning={"c_crossattn": [None]})
+        res[f"i{index}_x_prev"] = xp; res[f"i{index}_pred_x0"] = p0
+    save("sampler_p_sample_ddim", **res)
+
+    # ddim_step (MoCA FIFO step, DAVIS-mask branch), two consecutive calls (momentum state persists)
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)   # it writes ./visualizations/**
+    try:
+        for tag, (C, F, H, W), S in (("small", (4, 6, 16, 16), 64), ("cfgN", (4, 16, 40, 64), 64)):
+            s = D.DDIMSampler(fm, use_self_attention=True)
+            s.make_schedule(S, ddim_eta=1.0, verbose=False)
+            res = {}
+            # window of the FIFO queue: indices / timesteps as funcs.py:290-312 builds them
+            ts_all = np.concatenate([np.full((F // 2,), s.ddim_timesteps[0]), s.ddim_timesteps])
+            idx_all = np.concatenate([np.full((F // 2,), 0), np.arange(S)])
+            for call, start in enumerate((0, 24)):
+                idx = idx_all[start:start + F]; tsn = ts_all[start:start + F]
+                ts = torch.Tensor(tsn.copy()).to(dtype=torch.long)
+                shape = (1, C, F, H, W)
+                x = inp(f"ds.{tag}.x{call}", shape); e = inp(f"ds.{tag}.e{call}", shape)
+                noises = [inp(f"ds.{tag}.nz{call}.{i}", (1, C, 1, H, W)) for i in range(F)]
+                q = list(noises)
+                D.noise_like = lambda shp, dev, repeat=False: q.pop(0).clone()
+                cond = (inp(f"ds.{tag}.cond", (1, C, 1, H, W)) * 0.25 + 0.5).clamp(0, 1)
+                mask = (inp(f"ds.{tag}.mask", (1, 1, F, H, W)) > 0.5).float()
+                mask[:, :, 1] = 0.0   # an all-zero mask frame exercises `mask.sum() != 0`
+                t0 = time.time()
+                xp, p0 = s.ddim_step(x, e, idx, cond, None, ts, use_self_attention=True, davis_masks=mask)
+                print(f"ddim_step {tag} call {call}: {time.time() - t0:.1f}s")
+                res[f"c{call}_x_prev"] = xp; res[f"c{call}_pred_x0"] = p0; res[f"c{call}_momentum"] = s.momentum.clone()
+                res[f"c{call}_indices"] = idx; res[f"c{call}_ts"] = tsn
+            save(f"sampler_ddim_step_{tag}", **res)
+    finally:
+        os.chdir(cwd)
+
+
+def freeinit_cases():
+    from utils.freeinit_utils import freq_mix_3d, get_freq_filter
+    out = {}
+    for shp in ((1, 4, 1, 40, 64), (1, 4, 16, 40, 64), (1, 2, 3, 5, 7), (1, 4, 8, 32, 32)):
+        tag = "x".join(map(str, shp[2:]))
+        for ft, (ds, dt) in (("gaussian", (0.25, 0.25)), ("butterworth", (0.25, 0.25)), ("ideal", (0.25, 0.25)),
+                             ("box", (0.25, 0.25)), ("gaussian", (0.3, 0.6)), ("box", (0.5, 0.5))):
+            lpf = get_freq_filter(shp, "cpu", ft, 4, ds, dt)
+            out[f"{tag}_{ft}_{ds}_{dt}_lpf"] = lpf[0, 0]
+            x = inp(f"fi.x.{tag}", shp); nz = inp(f"fi.n.{tag}", shp)
+            out[f"{tag}_{ft}_{ds}_{dt}_mix"] = freq_mix_3d(x, nz, lpf)
+    save("freeinit", **out)
+
+
+def fifo_cases():
+    """prepare_latents / shift_latents (funcs.py:21-118).  They hard-code .to("cuda") and
+    torch.randn*: the harness feeds a CPU tensor through a patched Tensor.to and a recorded
+    randn_like so the queue construction can be pinned exactly."""
+    stub_t = sys.modules["torchvision"]
+    sys.modules["torchvision.transforms"] = stub_t.transforms
+    from scripts.evaluation import funcs as Fn
+    from lvdm.models.samplers import ddim as D
+    fm = FakeModel()
+    s = D.DDIMSampler(fm, use_self_attention=True)
+    s.make_schedule(64, ddim_eta=1.0, verbose=False)
+    args = types.SimpleNamespace(num_inference_steps=64, video_length=16, lookahead_denoising=True)
+    z = inp("fifo.z", (1, 4, 16, 8, 12))
+    tmp = tempfile.mkdtemp()
+    torch.save(z, os.path.join(tmp, "64.pt"))
+    noises = []
+    real_randn_like = torch.randn_like
+    real_to = torch.Tensor.to
+
+    def rec_randn_like(t, *a, **k):
+        n = inp(f"fifo.nz{len(noises)}", tuple(t.shape))
+        noises.append(n)
+        return n.clone()
+
+    def to_nocuda(self, *a, **k):
+        if a and isinstance(a[0], str) and a[0] == "cuda":
+            return self
+        return real_to(self, *a, **k)
+
+    torch.randn_like = rec_randn_like
+    torch.Tensor.to = to_nocuda
+    try:
+        lat = Fn.prepare_latents(args, tmp, s)
+        n_prep = len(noises)
+        shifted = Fn.shift_latents(lat.clone())
+    finally:
+        torch.randn_like = real_randn_like
+        torch.Tensor.to = real_to
+    save("fifo_queue", prepared=lat, shifted=shifted, n_noise_prepare=np.asarray(n_prep), n_noise_total=np.asarray(len(noises)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    om, att = import_reference()
+    todo = a.only.split(",") if a.only else ["blocks", "reduced", "sampler", "freeinit", "fifo"] + (["full"] if a.full else [])
+    if "blocks" in todo: blocks(om, att)
+    if "reduced" in todo: unet_reduced(om)
+    if "sampler" in todo: sampler_cases()
+    if "freeinit" in todo: freeinit_cases()
+    if "fifo" in todo: fifo_cases()
+    if "full" in todo: unet_full(om)
+
+
+if __name__ == "__main__":
+    main()
