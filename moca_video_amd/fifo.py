@@ -1,0 +1,130 @@
+"""Latent-queue side of the FIFO / MoCA loop (`scripts/evaluation/funcs.py`): `prepare_latents`
+(:21-82), `shift_latents` (:86-99), `base_ddim_sampling` (:177-241) and the window scheduling of
+`fifo_ddim_sampling` (:243-373).  The queue stays resident in HBM; VAE decoding of emitted frames
+(funcs.py:359-365) is outside the hot path: the loop hands each emitted latent to `emit`.
+Noise is an optional explicit argument wherever the reference calls torch.randn*."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .freeinit import freq_mix_3d, get_freq_filter
+from .sampler import DDIMSampler
+
+
+def prepare_latents(args, input_path, sampler, model=None, data=None, initial_latents=None, noises=None):
+    """funcs.py:21-82 (non-DAVIS branch): frame j of the queue = sqrt(a_j) z[frame_idx] + sqrt(1-a_j) eps,
+    frame_idx = max(0, j - (N - z.shape[2])); with lookahead the first f/2 frames all use a_0."""
+    if data is not None:
+        raise NotImplementedError("DAVIS frame encoding needs the VAE (out of scope); pass initial_latents")
+    if initial_latents is None:
+        initial_latents = torch.load(input_path + f"/{args.num_inference_steps}.pt")
+    initial_latents = initial_latents.to("cuda")
+    latents_list = []
+    k = 0
+
+    def draw(like):
+        nonlocal k
+        n = torch.randn_like(like) if noises is None else noises[k].to(like.device, like.dtype)
+        k += 1
+        return n
+
+    if args.lookahead_denoising:
+        for i in range(args.video_length // 2):
+            alpha = sampler.ddim_alphas[0]
+            beta = 1 - alpha
+            latents = alpha ** (0.5) * initial_latents[:, :, [0]] + beta ** (0.5) * draw(initial_latents[:, :, [0]])
+            latents_list.append(latents)
+    for i in range(args.num_inference_steps):
+        alpha = sampler.ddim_alphas[i]
+        frame_idx = max(0, i - (args.num_inference_steps - initial_latents.shape[2]))
+        current_latents = initial_latents[:, :, [frame_idx]]
+        noise = draw(current_latents)
+        latents_list.append(alpha ** (0.5) * current_latents + (1 - alpha) ** (0.5) * noise)
+    return torch.cat(latents_list, dim=2)
+
+
+def shift_latents(latents, noise=None):
+    """funcs.py:86-99: dequeue frame 0, shift left, enqueue FreeInit-mixed noise."""
+    anchor_frame = latents[:, :, 0].clone().unsqueeze(2)
+    latents[:, :, :-1] = latents[:, :, 1:].clone()
+    new_noise = (torch.randn_like(latents[:, :, -1]) if noise is None else noise.to(latents.device, latents.dtype).reshape(latents[:, :, -1].shape)).unsqueeze(2)
+    freq_filter = get_freq_filter(anchor_frame.shape, latents.device, "gaussian", 1, 0.25, 0.25)
+    latents[:, :, -1] = freq_mix_3d(anchor_frame, new_noise, freq_filter).squeeze(2)
+    return latents
+
+
+def base_ddim_sampling(model, cond, noise_shape, ddim_steps=50, ddim_eta=1.0, cfg_scale=1.0, uc_emb=None,
+                       latents_dir=None, x_T=None, noises=None):
+    """funcs.py:177-241 without the VAE decode (:239).  `uc_emb` replaces
+    model.get_learned_conditioning([""]) (the text encoder is out of scope)."""
+    sampler = DDIMSampler(model)
+    uc = None
+    if cfg_scale != 1.0:
+        if uc_emb is None:
+            c_emb = cond["c_crossattn"][0] if isinstance(cond, dict) else cond
+            uc_emb = torch.zeros_like(c_emb)              # uncond_type == "zero_embed" (:204-206)
+        if isinstance(cond, dict):
+            uc = {key: cond[key] for key in cond.keys()}
+            uc.update({'c_crossattn': [uc_emb]})
+        else:
+            uc = uc_emb
+    samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=noise_shape[0], shape=noise_shape[1:],
+                                verbose=False, unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc,
+                                eta=ddim_eta, x_T=x_T, latents_dir=latents_dir, noises=noises)
+    return sampler, samples
+
+
+def fifo_windows(args):
+    """Window schedule of one outer iteration (funcs.py:290-312): yields (start, mid, end) for
+    rank = 2n-1 .. 0 (reversed so every window reads only not-yet-rewritten frames)."""
+    f = args.video_length
+    n = 2 * args.num_partitions if args.lookahead_denoising else args.num_partitions
+    for rank in reversed(range(n)):
+        start = rank * (f // 2) if args.lookahead_denoising else rank * f
+        yield start, start + f // 2, start + f
+
+
+def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg_scale=1.0, uc_emb=None,
+                       latents=None, latents_dir=None, conditioned_image=None, masks=None, gamma=0.5, emit=None,
+                       n_iterations=None, **kwargs):
+    """funcs.py:243-373: returns the list of emitted latent frames [B,4,1,h,w] (decode is the caller's).
+    `masks` [B,1,Q,h,w] (Q = queue length) plays the role of the DAVIS masks (:296-302,315)."""
+    kwargs.update({"clean_cond": True})
+    cond = conditioning
+    uc = None
+    if cfg_scale != 1.0:
+        if uc_emb is None:
+            uc_emb = torch.zeros_like(cond["c_crossattn"][0])
+        uc = {key: cond[key] for key in cond.keys()}
+        uc.update({'c_crossattn': [uc_emb]})
+    if latents is None:
+        latents = prepare_latents(args, latents_dir, ddim_sampler)
+    f = args.video_length
+    timesteps = ddim_sampler.ddim_timesteps
+    indices = np.arange(args.num_inference_steps)
+    if args.lookahead_denoising:
+        timesteps = np.concatenate([np.full((f // 2,), timesteps[0]), timesteps])
+        indices = np.concatenate([np.full((f // 2,), 0), indices])
+    total = args.new_video_length + args.num_inference_steps - f if n_iterations is None else n_iterations
+    frames = []
+    for i in range(total):
+        for start, mid, end in fifo_windows(args):
+            t, idx = timesteps[start:end], indices[start:end]
+            input_latents = latents[:, :, start:end].clone()
+            input_masks = masks[:, :, start:end].clone() if masks is not None else None
+            output_latents, _ = ddim_sampler.fifo_onestep(cond=cond, shape=noise_shape, latents=input_latents, timesteps=t,
+                                                          indices=idx, unconditional_guidance_scale=cfg_scale,
+                                                          unconditional_conditioning=uc, cond_image=conditioned_image,
+                                                          davis_masks=input_masks, gamma=gamma, **kwargs)
+            if args.lookahead_denoising:
+                latents[:, :, mid:end] = output_latents[:, :, -(f // 2):]
+            else:
+                latents[:, :, start:end] = output_latents
+        first = f // 2 if args.lookahead_denoising else 0
+        frame = latents[:, :, [first]].clone()
+        frames.append(frame if emit is None else emit(frame))
+        latents = shift_latents(latents)
+        if masks is not None:
+            masks[:, :, :-1] = masks[:, :, 1:].clone()
+    return frames

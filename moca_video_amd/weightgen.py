@@ -46,3 +46,28 @@ def fill_module_(module: torch.nn.Module, seed: int = 0):
     new = gen_state_dict({k: v.shape for k, v in sd.items()}, seed)
     module.load_state_dict(new, strict=True)
     return module
+
+
+@torch.no_grad()
+def init_random_(module: torch.nn.Module, seed: int = 0):
+    """Fast on-device random init with the same per-tensor statistics as gen_tensor (torch RNG:
+    NOT bit-identical to gen_tensor; for benchmarks, where ranks then share rank 0's weights by
+    RCCL broadcast).  The architecture is the reference's; VideoCrafter2 weights do not exist offline."""
+    g = torch.Generator(device=next(module.parameters()).device)
+    g.manual_seed(seed)
+    for name, p in module.named_parameters():
+        if p.dim() == 1:
+            p.normal_(0.0, 0.1, generator=g)
+            if name.endswith("weight"):
+                p.add_(1.0)
+        else:
+            fan_in = 1
+            for s in p.shape[1:]:
+                fan_in *= int(s)
+            p.normal_(0.0, fan_in ** -0.5, generator=g)
+    if hasattr(module, "_invalidate"):
+        module._invalidate()
+    for m in module.modules():
+        if hasattr(m, "_invalidate"):
+            m._invalidate()
+    return module

@@ -71,7 +71,7 @@ def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2)
     """utils_diffusion.py:31-53 (the 'linear' branch the YAML uses)"""
     if schedule != "linear":
         raise NotImplementedError(schedule)
-    betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
+    betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64, device="cpu") ** 2
     return betas.numpy()
 
 

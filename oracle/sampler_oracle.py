@@ -1,0 +1,93 @@
+"""ORACLE (test infrastructure only): CPU restatement of the sampler arithmetic of
+`/root/reference/lvdm/models/samplers/ddim.py` and `lvdm/models/utils_diffusion.py`,
+`lvdm/models/ddpm3d.py` schedule buffers.  Pinned by tests/golden/sampler_*.npz (outputs of
+the real reference, tools/make_golden.py).  No plotting, no SAM: masks are inputs."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+# ---- utils_diffusion.py:31-53, ddpm3d.py:113-165,362-376 ----------------------------------
+def ddpm_buffers(timesteps=1000, linear_start=0.00085, linear_end=0.012, scale_a=1, scale_b=0.7, mid_step=400):
+    betas = (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2).numpy()
+    ac = np.cumprod(1. - betas, axis=0)
+    scale_arr = np.concatenate((np.linspace(scale_a, scale_b, mid_step), np.full(timesteps, scale_b)))
+    return dict(betas=torch.tensor(betas, dtype=torch.float32), alphas_cumprod=torch.tensor(ac, dtype=torch.float32),
+                scale_arr=torch.tensor(scale_arr, dtype=torch.float32))
+
+
+# ---- ddim.py:62-106, utils_diffusion.py:56-93 ------------------------------------------------
+def make_schedule(buf, S, eta, T=1000):
+    ts = np.linspace(0, T - 1, S).round().copy().astype(np.int64)
+    ac = buf["alphas_cumprod"]
+    alphas = ac[ts]
+    alphas_prev = np.asarray([ac[0]] + ac[ts[:-1]].tolist())
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    sa = buf["scale_arr"]
+    return dict(ddim_timesteps=ts, ddim_sigmas=np.asarray(sigmas), ddim_alphas=np.asarray(alphas), ddim_alphas_prev=alphas_prev,
+                ddim_sqrt_one_minus_alphas=np.sqrt(1. - np.asarray(alphas)), ddim_scale_arr=np.asarray(sa[ts]),
+                ddim_scale_arr_prev=np.asarray([sa[0]] + sa[ts[:-1]].tolist()))
+
+
+# ---- ddim.py:290-357 --------------------------------------------------------------------------
+def p_sample_ddim(sch, x, e_c, e_u, cfg, index, noise, use_scale=True):
+    e_t = e_u + cfg * (e_c - e_u)
+    size = (x.shape[0], 1, 1, 1, 1)
+    a_t = torch.full(size, sch["ddim_alphas"][index])
+    a_prev = torch.full(size, sch["ddim_alphas_prev"][index])
+    sigma_t = torch.full(size, sch["ddim_sigmas"][index])
+    s1m = torch.full(size, sch["ddim_sqrt_one_minus_alphas"][index])
+    pred_x0 = (x - s1m * e_t) / a_t.sqrt()
+    dir_xt = (1. - a_prev - sigma_t ** 2).sqrt() * e_t
+    nz = sigma_t * noise
+    if use_scale:
+        scale_t = torch.full(size, sch["ddim_scale_arr"][index])
+        scale_prev = torch.full(size, sch["ddim_scale_arr_prev"][index])
+        pred_x0 = pred_x0 / scale_t
+        x_prev = a_prev.sqrt() * scale_prev * pred_x0 + dir_xt + nz
+    else:
+        x_prev = a_prev.sqrt() * pred_x0 + dir_xt + nz
+    return x_prev, pred_x0
+
+
+# ---- ddim.py:377-649 (arithmetic only) ---------------------------------------------------------
+def ddim_step(sch, sample, noise_pred, indices, cond_image, ts, noises, momentum, davis_masks=None, gamma=0.5, beta=0.9,
+              reference_index_quirk=True):
+    """noises: list of per-frame [b,c,1,h,w]; momentum: [b,c,f,h,w] state, updated in place. Returns (x_prev, pred_x0)."""
+    b, _, f, H, W = sample.shape
+    size = (b, 1, 1, 1, 1)
+    x_prevs, pred_x0s = [], []
+    prev_frame = None
+    for i, index in enumerate(indices):
+        x = sample[:, :, [i]]
+        e_t = noise_pred[:, :, [i]]
+        timestep = ts[i]
+        a_t = torch.full(size, sch["ddim_alphas"][index])
+        a_prev = torch.full(size, sch["ddim_alphas_prev"][index])
+        sigma_t = torch.full(size, sch["ddim_sigmas"][index])
+        s1m = torch.full(size, sch["ddim_sqrt_one_minus_alphas"][index])
+        pred_x0 = (x - s1m * e_t) / a_t.sqrt()                         # :415
+        dir_xt = (1. - a_prev - sigma_t ** 2).sqrt() * e_t             # :418
+        mi = i
+        if prev_frame is not None:
+            g = pred_x0 - prev_frame                                   # :422
+            g = g + 1.5 * dir_xt                                       # :423
+            momentum[:, :, [i]] = beta * momentum[:, :, [i - 1]] + (1 - beta) * g   # :424-427
+            correction_strength = 2 * (1.0 - timestep / 1000.0)        # :428
+            pred_x0 = pred_x0 + correction_strength * momentum[:, :, [i]]    # :430,557
+            if reference_index_quirk:
+                mi = len(range(0, H, 4)) - 1     # plotting loops `for i in range(len(X))` clobber i (:477,502,533)
+        prev_frame = pred_x0                                            # :559
+        noise = sigma_t * noises[i]                                     # :561
+        x_prev = a_prev.sqrt() * pred_x0 + dir_xt + noise               # :562
+        if davis_masks is not None and davis_masks.shape[2] > mi:       # :565
+            mask = davis_masks[:, :, mi, :, :].unsqueeze(0)
+            mask = mask.expand(-1, pred_x0.shape[1], -1, -1, -1)
+            enhancement_factor = 1.5 if timestep <= 300 else 1.0        # :582
+            if mask.sum() != 0:                                         # :585
+                pred_x0 = torch.where(mask > 0.5, cond_image * enhancement_factor, pred_x0)
+        pred_x0 = (1 - gamma) * pred_x0 + gamma * noise                 # :609
+        x_prevs.append(x_prev)
+        pred_x0s.append(pred_x0)
+    return torch.cat(x_prevs, dim=2), torch.cat(pred_x0s, dim=2)

@@ -1,0 +1,68 @@
+"""CPU, world_size 2 on the gloo backend: the multi-GPU harness (moca_video_amd/dist.py) -- strided
+prompt sharding (videocrafter_main.py:181), flat-bucketed parameter broadcast (C1), result gather (C2)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from moca_video_amd import dist as md
+    r, l, w = md.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)
+    m = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.LayerNorm(53), torch.nn.Linear(53, 7, bias=False))
+    m.register_buffer("sched", torch.randn(11))
+    before = [p.clone() for p in m.parameters()]
+    sent = md.broadcast_parameters(m, src=0, bucket_bytes=4096)        # small buckets: several messages
+    flat = torch.cat([p.reshape(-1) for p in m.parameters()] + [m.sched])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], g) for g in gathered)
+    changed = rank == 0 or any(not torch.equal(a, b) for a, b in zip(before, m.parameters()))
+    res = torch.full((2, 3), float(rank))
+    outs = md.gather_results(res, dst=0)
+    ok_gather = (outs is None) if rank != 0 else all(torch.equal(o, torch.full((2, 3), float(i))) for i, o in enumerate(outs))
+    t = md.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    md.barrier()
+    q.put((rank, same, changed, ok_gather, t, sent, md.shard_indices(10, rank, world)))
+    dist.destroy_process_group()
+
+
+def test_dist_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, same, changed, ok_gather, t, sent, shard in out:
+        assert same and changed and ok_gather
+        assert t == 2.0
+        assert sent > 0
+        assert shard == list(range(10))[rank::world]
+
+
+def test_shard_indices_cover():
+    from moca_video_amd.dist import shard_indices
+    for n in (0, 1, 7, 64):
+        for w in (1, 2, 8):
+            got = sorted(i for r in range(w) for i in shard_indices(n, r, w))
+            assert got == list(range(n))
