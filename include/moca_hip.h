@@ -39,6 +39,7 @@ extern "C" {
 #define MOCA_EP_GEGLU   1  /* out[m][j] = v[m][j] * gelu(g[m][j]); W rows are packed in     */
                            /* 64-row groups: 32 value rows then their 32 gate rows           */
 #define MOCA_EP_OUT_F32 2  /* out is float32 instead of fp16                                 */
+#define MOCA_FORCE_SMALL_TILE 4  /* tuning/testing: use the 128-row register-staged kernel   */
 
 typedef struct moca_gemm_params {
     const void* a;         /* fp16 activations (gather source)                              */

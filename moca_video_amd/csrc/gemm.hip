@@ -371,6 +371,394 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const moca_gemm_para
     }
 }
 
+
+// =====================================================================================
+// Large-tile kernel: 256 x BN x 64 block tile (BN = 128 or 160), 512 threads = 8
+// wavefronts (4 x 2), wave tile 64 x BN/2 as 4 x (BN/32) v_mfma_f32_16x16x32_f16
+// accumulators.  Operands are staged global -> LDS directly (global_load_lds_dwordx4,
+// no VGPR round trip) into a 3-slot ring, two k-tiles in flight, ONE raw s_barrier per
+// k-tile behind a counted s_waitcnt vmcnt(N) (never 0 in the steady state).  The LDS
+// image of a DMA is lane-linear, so the bank-conflict XOR swizzle is applied on the
+// per-lane SOURCE address (logical chunk = physical chunk ^ ((row>>1)&7)) and again on
+// the fragment reads.  Zero padding (conv halo, M/K tails) is a lane whose source is a
+// 16-byte zero page.
+// =====================================================================================
+__device__ __attribute__((aligned(16))) half_t g_zero_page[64];
+
+typedef __attribute__((address_space(3))) char* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+template <int BN, int AMODE>
+__global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_params p) {
+    constexpr int TM = 256;
+    constexpr int NT = BN / 32;                       // 16-wide n tiles per wave
+    constexpr int A_BYTES = TM * ROW_BYTES;           // 32 KiB
+    constexpr int B_BYTES = BN * ROW_BYTES;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int B_GROUPS = BN / 8;                  // 1 KiB row groups of the W tile (16 or 20)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    const int tiles_m = (p.M + TM - 1) / TM;
+    const int tiles_n = p.N / BN;
+    const int nblk = tiles_m * tiles_n * p.splits;
+    int logical;
+    remap_block<BN>(nblk, logical);
+    const int split = logical % p.splits;
+    const int tile = logical / p.splits;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int m0 = tile_m * TM, n0 = tile_n * BN;
+
+    const int nk_total = p.ldw / BK;
+    const int kts = (nk_total + p.splits - 1) / p.splits;
+    const int kt_begin = split * kts;
+    const int kt_end = min(kt_begin + kts, nk_total);
+    const int nk = kt_end - kt_begin;
+
+    const half_t* __restrict__ Aptr = reinterpret_cast<const half_t*>(p.a);
+    const half_t* __restrict__ Wptr = reinterpret_cast<const half_t*>(p.w);
+    const half_t* zero = g_zero_page;
+
+    // ---- DMA coordinates: instruction g of this wave fills row group q = g*8 + wave,
+    //      i.e. rows q*8 + (lane>>3), physical chunk lane&7
+    const int lrow = lane >> 3, pch = lane & 7;
+    const int swz = (((wave * 8 + lrow) >> 1) & 7);   // same for every g (64 g rows apart)
+    const int lch = pch ^ swz;                        // logical 16-byte chunk of the k-tile this lane fetches
+
+    int64_t row_off[4];
+    int row_y[4], row_x[4];
+    bool row_ok[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int m = m0 + (g * 8 + wave) * 8 + lrow;
+        row_ok[g] = m < p.M;
+        const int mm = row_ok[g] ? m : 0;
+        if (AMODE == MOCA_A_LINEAR) {
+            row_off[g] = (int64_t)mm * p.lda;
+            row_y[g] = row_x[g] = 0;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int ohw = p.outH * p.outW;
+            const int f = mm / ohw, rem = mm - f * ohw;
+            const int oy = rem / p.outW, ox = rem - oy * p.outW;
+            row_off[g] = (int64_t)f * p.inH * p.inW;
+            row_y[g] = oy * p.stride - 1;
+            row_x[g] = ox * p.stride - 1;
+        } else {
+            row_off[g] = mm;
+            row_y[g] = (mm / p.HW) % p.T;
+            row_x[g] = 0;
+        }
+    }
+    // W rows of this lane: group q = g*8 + wave (valid while q < B_GROUPS)
+    const half_t* w_row[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int q = g * 8 + wave;
+        const int n = n0 + (q < B_GROUPS ? q : 0) * 8 + lrow;
+        w_row[g] = Wptr + (int64_t)n * p.ldw + lch * 8;
+    }
+
+    // Gather addresses.  When C % 64 == 0 a 64-wide k-tile lies inside ONE tap, so the tap index is
+    // block-uniform (scalar) and the per-lane pixel offsets are recomputed only when the tap changes
+    // (every C/64 tiles) instead of per tile: the per-tile cost drops to one 64-bit add + select per row.
+    const bool tap_aligned = (AMODE != MOCA_A_LINEAR) && (p.C % BK == 0);
+    const int tiles_per_tap = tap_aligned ? p.C / BK : 1;
+    int64_t tap_off[4] = {0, 0, 0, 0};
+    bool tap_ok[4] = {false, false, false, false};
+    int tap_cur = -1;
+
+    auto set_tap = [&](int tap) {
+        tap_cur = tap;
+        if (AMODE == MOCA_A_CONV3X3) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int iy = row_y[g] + ky, ix = row_x[g] + kx;
+                tap_ok[g] = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+                if (p.up) { iy >>= 1; ix >>= 1; }
+                tap_off[g] = (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + lch * 8;
+            }
+        } else if (AMODE == MOCA_A_TCONV3) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int tt = row_y[g] + tap - 1;
+                tap_ok[g] = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
+                tap_off[g] = (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + lch * 8;
+            }
+        }
+    };
+
+    auto issue = [&](int kt, int slot) {
+        const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
+        const lds_ptr sb = sa + A_BYTES;
+        // ---- A: 4 x 1 KiB ----
+        if (AMODE == MOCA_A_LINEAR) {
+            const int k = kt * BK + lch * 8;
+            const bool kok = k < p.K;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const half_t* src = (kok && row_ok[g]) ? Aptr + row_off[g] + k : zero;
+                __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (g * 8 + wave) * 1024, 16, 0, 0);
+            }
+        } else if (tap_aligned) {
+            const int tap = kt / tiles_per_tap;              // scalar
+            const int c0 = (kt - tap * tiles_per_tap) * BK;  // scalar
+            if (tap != tap_cur) set_tap(tap);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const half_t* src = tap_ok[g] ? Aptr + tap_off[g] + c0 : zero;
+                __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (g * 8 + wave) * 1024, 16, 0, 0);
+            }
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int k = kt * BK + lch * 8;
+            const int tap = k / p.C, c = k - tap * p.C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
+            const bool kok = tap < 9;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int iy = row_y[g] + ky, ix = row_x[g] + kx;
+                const bool ok = kok && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+                if (p.up) { iy >>= 1; ix >>= 1; }
+                const half_t* src = ok ? Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + c : zero;
+                __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (g * 8 + wave) * 1024, 16, 0, 0);
+            }
+        } else {
+            const int k = kt * BK + lch * 8;
+            const int tap = k / p.C, c = k - tap * p.C;
+            const bool kok = tap < 3;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int tt = row_y[g] + tap - 1;
+                const bool ok = kok && row_ok[g] && tt >= 0 && tt < p.T;
+                const half_t* src = ok ? Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + c : zero;
+                __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (g * 8 + wave) * 1024, 16, 0, 0);
+            }
+        }
+        // ---- W: BN/64 full rounds (+ half a round for BN = 160, waves 0-3) ----
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            if (g * 8 + 7 < B_GROUPS || (g * 8 < B_GROUPS && wave < B_GROUPS - g * 8))
+                __builtin_amdgcn_global_load_lds((glb_ptr)(w_row[g] + kt * BK), sb + (g * 8 + wave) * 1024, 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    int a_row_b[4], a_swz[4], b_row_b[NT], b_swz[NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int row = wave_m * 64 + mt * 16 + fr;
+        a_row_b[mt] = row * ROW_BYTES;
+        a_swz[mt] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int row = wave_n * (BN / 2) + nt * 16 + fr;
+        b_row_b[nt] = row * ROW_BYTES;
+        b_swz[nt] = (row >> 1) & 7;
+    }
+
+    // number of DMA instructions this wave issues per k-tile (for the counted wait)
+    const bool extra_w = (B_GROUPS % 8) != 0 && wave < (B_GROUPS % 8);
+
+    if (nk > 0) issue(kt_begin, 0);
+    if (nk > 1) issue(kt_begin + 1, 1);
+
+    for (int i = 0; i < nk; ++i) {
+        // tile i has landed once at most one tile's worth of this wave's DMAs is still in flight
+        if (i + 1 < nk) {
+            if (B_GROUPS % 8 == 0) {
+                if (BN == 128) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                if (extra_w) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();     // every wave's part of tile i is in LDS; slot (i-1)%3 is free
+        if (i + 2 < nk) issue(kt_begin + i + 2, (i + 2) % 3);
+
+        const char* a = smem + (i % 3) * STAGE;
+        const char* b = a + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ks * 4 + fg;
+            half8v af[4], bf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                af[mt] = *reinterpret_cast<const half8v*>(a + a_row_b[mt] + ((ch ^ a_swz[mt]) << 4));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                bf[nt] = *reinterpret_cast<const half8v*>(b + b_row_b[nt] + ((ch ^ b_swz[nt]) << 4));
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);   // D^T: lane = row m, regs = 4 consecutive n
+        }
+    }
+    __syncthreads();   // all fragment reads done before the ring is reused by the epilogue
+
+    // The MFMAs above compute the TRANSPOSED tile (W fragment as A operand), so accumulator element r
+    // of tile (mt, nt) is row m = wave_m*64 + mt*16 + fr, column n = wave_n*BN/2 + nt*16 + 4*fg + r:
+    // each lane owns 4 CONSECUTIVE output columns of one row -> 8-byte fp16 / 16-byte fp32 accesses.
+    if (p.splits > 1) {
+        float* ws = p.splitk_ws + (int64_t)split * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int row = m0 + wave_m * 64 + mt * 16 + fr;
+            if (row < p.M) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = n0 + wave_n * (BN / 2) + nt * 16 + 4 * fg;
+                    *reinterpret_cast<f32x4*>(ws + (int64_t)row * p.N + col) = acc[mt][nt];
+                }
+            }
+        }
+        return;
+    }
+
+    const bool geglu = (p.flags & MOCA_EP_GEGLU) != 0;
+    const int out_bn = geglu ? BN / 2 : BN;
+    const int on0 = geglu ? n0 / 2 : n0;
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+
+    if (p.flags & MOCA_EP_OUT_F32) {
+        // fp32 output: stage the tile in fp32 (no intermediate rounding)
+        float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = wave_n * (BN / 2) + nt * 16 + 4 * fg;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int row = wave_m * 64 + mt * 16 + fr;
+                *reinterpret_cast<f32x4*>(sC + row * BN + col) = acc[mt][nt] + bv;
+            }
+        }
+        __syncthreads();
+        const int cpr = BN / 4;
+        for (int idx = tid; idx < TM * cpr; idx += 512) {
+            const int row = idx / cpr, ch = idx - row * cpr;
+            const int m = m0 + row;
+            if (m >= p.M) continue;
+            const int col = n0 + ch * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * BN + ch * 4);
+            if (rowadd) {
+                const half4v e = *reinterpret_cast<const half4v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)e[j];
+            }
+            if (resid) {
+                const half4v e = *reinterpret_cast<const half4v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)e[j];
+            }
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + col) = v;
+        }
+        return;
+    }
+
+    // fp16 output: stage fp16 rows (pitch = out_bn*2 + 16 bytes: conflict-free ds_write_b64 / ds_read_b128)
+    const int pitch = out_bn * 2 + 16;
+    if (geglu) {
+        if constexpr (NT == 4) {
+            // wave span of 64 packed columns = 32 value columns (tiles 0,1) then their 32 gate columns (tiles 2,3)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int ncol = n0 + wave_n * 64 + nt * 16 + 4 * fg;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) { bv = *reinterpret_cast<const f32x4*>(p.bias + ncol); bg = *reinterpret_cast<const f32x4*>(p.bias + ncol + 32); }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int row = wave_m * 64 + mt * 16 + fr;
+                    half4v h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (half_t)((acc[mt][nt][r] + bv[r]) * moca_gelu(acc[mt][nt + 2][r] + bg[r]));
+                    *reinterpret_cast<half4v*>(smem + row * pitch + (wave_n * 32 + nt * 16 + 4 * fg) * 2) = h;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = wave_n * (BN / 2) + nt * 16 + 4 * fg;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int row = wave_m * 64 + mt * 16 + fr;
+                half4v h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[mt][nt][r] + bv[r]);
+                *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = h;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int chunks_per_row = out_bn / 8;
+    const int total_chunks = TM * chunks_per_row;
+    for (int idx = tid; idx < total_chunks; idx += 512) {
+        const int row = idx / chunks_per_row, ch = idx - row * chunks_per_row;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        const int col = on0 + ch * 8;
+        half8v h = *reinterpret_cast<const half8v*>(smem + row * pitch + ch * 16);
+        if (rowadd || resid) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+            if (rowadd) {
+                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            }
+            if (resid) {
+                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+        }
+        *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
+    }
+}
+
+template <int BN, int AMODE>
+int launch_gemm_glds(const moca_gemm_params& p, hipStream_t st) {
+    const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / BN;
+    const int nblk = tiles_m * tiles_n * p.splits;
+    constexpr int lds_pipe = 3 * (256 + BN) * ROW_BYTES;
+    constexpr int lds_epi = 256 * BN * 4;
+    constexpr int lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BN, AMODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MOCA_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_glds_kernel<BN, AMODE>), dim3(nblk), dim3(512), lds, st, p);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
 template <int BN, int AMODE>
 int launch_gemm(const moca_gemm_params& p, hipStream_t st) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
@@ -429,7 +817,18 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     hipStream_t st = moca_stream(stream);
     const bool wide = (p.N % 128 == 0);
     int rc;
-    if (wide) {
+    // large-tile direct-to-LDS kernel whenever a 256-row tile is at least half full
+    const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
+    const bool use_big = big_bn != 0 && p.M > 128 && !(p.flags & MOCA_FORCE_SMALL_TILE);
+    if (use_big && big_bn == 128) {
+        if (p.a_mode == MOCA_A_LINEAR) rc = launch_gemm_glds<128, MOCA_A_LINEAR>(p, st);
+        else if (p.a_mode == MOCA_A_CONV3X3) rc = launch_gemm_glds<128, MOCA_A_CONV3X3>(p, st);
+        else rc = launch_gemm_glds<128, MOCA_A_TCONV3>(p, st);
+    } else if (use_big) {
+        if (p.a_mode == MOCA_A_LINEAR) rc = launch_gemm_glds<160, MOCA_A_LINEAR>(p, st);
+        else if (p.a_mode == MOCA_A_CONV3X3) rc = launch_gemm_glds<160, MOCA_A_CONV3X3>(p, st);
+        else rc = launch_gemm_glds<160, MOCA_A_TCONV3>(p, st);
+    } else if (wide) {
         if (p.a_mode == MOCA_A_LINEAR) rc = launch_gemm<128, MOCA_A_LINEAR>(p, st);
         else if (p.a_mode == MOCA_A_CONV3X3) rc = launch_gemm<128, MOCA_A_CONV3X3>(p, st);
         else rc = launch_gemm<128, MOCA_A_TCONV3>(p, st);

@@ -51,20 +51,20 @@ __global__ void gn_partial_kernel(const half_t* __restrict__ x, float* __restric
 }
 
 // ---- K2: finalize mean / rstd per (stat group, channel group) in fp64 --------
-// block = 256 threads = 32 groups x 8 lanes
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ meanrstd,
-                                                          int frames_per_stat, int nchunk, double inv_count, float eps) {
-    const int sg = blockIdx.x;
-    const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
+// one wavefront per (stat group, channel group): grid (stat groups, 32)
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ meanrstd,
+                                                         int frames_per_stat, int nchunk, double inv_count, float eps) {
+    const int sg = blockIdx.x, g = blockIdx.y, l = threadIdx.x;
     const int n = frames_per_stat * nchunk;
     const float* base = partial + (int64_t)sg * n * GN_GROUPS * 2;
     double a = 0.0, b = 0.0;
-    for (int i = l; i < n; i += 8) {
-        a += (double)base[((int64_t)i * GN_GROUPS + g) * 2];
-        b += (double)base[((int64_t)i * GN_GROUPS + g) * 2 + 1];
+    for (int i = l; i < n; i += 64) {
+        const float2 v = *reinterpret_cast<const float2*>(base + ((int64_t)i * GN_GROUPS + g) * 2);
+        a += (double)v.x;
+        b += (double)v.y;
     }
 #pragma unroll
-    for (int o = 4; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
     if (l == 0) {
         const double mean = a * inv_count;
         double var = b * inv_count - mean * mean;
@@ -187,7 +187,7 @@ extern "C" int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamm
     hipLaunchKernelGGL(gn_partial_kernel, grid, block, lds, st, reinterpret_cast<const half_t*>(x), partial, HW, C, nchunk);
     MOCA_CHECK_LAUNCH();
     const double inv_count = 1.0 / ((double)frames_per_stat * HW * (C / GN_GROUPS));
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(F / frames_per_stat), dim3(256), 0, st, partial, meanrstd,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(F / frames_per_stat, GN_GROUPS), dim3(64), 0, st, partial, meanrstd,
                        frames_per_stat, nchunk, inv_count, eps);
     MOCA_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, reinterpret_cast<const half_t*>(x), reinterpret_cast<half_t*>(y),
