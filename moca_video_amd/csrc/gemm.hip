@@ -383,7 +383,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const moca_gemm_para
 // the fragment reads.  Zero padding (conv halo, M/K tails) is a lane whose source is a
 // 16-byte zero page.
 // =====================================================================================
-__device__ __attribute__((aligned(16))) half_t g_zero_page[64];
+// zeros: long enough that `zero + per-tile k offset` of the fast gather path stays inside it
+constexpr int ZERO_PAGE_HALVES = 8192 + 64;
+__device__ __attribute__((aligned(16))) half_t g_zero_page[ZERO_PAGE_HALVES];
 
 typedef __attribute__((address_space(3))) char* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -462,90 +464,89 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
         w_row[g] = Wptr + (int64_t)n * p.ldw + lch * 8;
     }
 
-    // Gather addresses.  When C % 64 == 0 a 64-wide k-tile lies inside ONE tap, so the tap index is
-    // block-uniform (scalar) and the per-lane pixel offsets are recomputed only when the tap changes
-    // (every C/64 tiles) instead of per tile: the per-tile cost drops to one 64-bit add + select per row.
-    const bool tap_aligned = (AMODE != MOCA_A_LINEAR) && (p.C % BK == 0);
-    const int tiles_per_tap = tap_aligned ? p.C / BK : 1;
-    int64_t tap_off[4] = {0, 0, 0, 0};
-    bool tap_ok[4] = {false, false, false, false};
+    // ---- gather addressing ------------------------------------------------------------------
+    // Fast path (every layer of the UNet except the 4-channel input conv): a 64-wide k-tile lies inside
+    // ONE tap (C % 64 == 0) resp. inside K (K % 64 == 0), so per tile every lane just adds a block-uniform
+    // element offset to a per-row base pointer.  Rows that must read zeros (conv halo, t-1/t+1 outside the
+    // clip, M tail) have the zero page as base; the zero page is longer than any per-tile offset, so no
+    // per-tile select is needed.  Bases are recomputed only when the tap changes (every C/64 tiles).
+    const bool fast = (AMODE == MOCA_A_LINEAR) ? (p.K % BK == 0 && p.K <= 8192) : (p.C % BK == 0 && p.C <= 8192);
+    const int tiles_per_tap = (AMODE == MOCA_A_LINEAR || !fast) ? (1 << 30) : p.C / BK;
+    const half_t* a_base[4];
     int tap_cur = -1;
 
     auto set_tap = [&](int tap) {
         tap_cur = tap;
-        if (AMODE == MOCA_A_CONV3X3) {
+        if (AMODE == MOCA_A_LINEAR) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a_base[g] = row_ok[g] ? Aptr + row_off[g] + lch * 8 : zero;
+        } else if (AMODE == MOCA_A_CONV3X3) {
             const int ky = tap / 3, kx = tap - ky * 3;
             const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 int iy = row_y[g] + ky, ix = row_x[g] + kx;
-                tap_ok[g] = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+                const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
                 if (p.up) { iy >>= 1; ix >>= 1; }
-                tap_off[g] = (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + lch * 8;
+                const half_t* src = Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + lch * 8;
+                a_base[g] = ok ? src : zero;
             }
-        } else if (AMODE == MOCA_A_TCONV3) {
+        } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int tt = row_y[g] + tap - 1;
-                tap_ok[g] = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
-                tap_off[g] = (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + lch * 8;
+                const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
+                const half_t* src = Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + lch * 8;
+                a_base[g] = ok ? src : zero;
             }
         }
     };
 
-    auto issue = [&](int kt, int slot) {
-        const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
-        const lds_ptr sb = sa + A_BYTES;
-        // ---- A: 4 x 1 KiB ----
-        if (AMODE == MOCA_A_LINEAR) {
-            const int k = kt * BK + lch * 8;
-            const bool kok = k < p.K;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const half_t* src = (kok && row_ok[g]) ? Aptr + row_off[g] + k : zero;
-                __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (g * 8 + wave) * 1024, 16, 0, 0);
-            }
-        } else if (tap_aligned) {
-            const int tap = kt / tiles_per_tap;              // scalar
-            const int c0 = (kt - tap * tiles_per_tap) * BK;  // scalar
+    // per-tile state of the DMA stream (block-uniform): element offset added to every a_base
+    int a_koff = 0;
+    auto begin_tile = [&](int kt) {
+        if (fast) {
+            const int tap = kt / tiles_per_tap;
             if (tap != tap_cur) set_tap(tap);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const half_t* src = tap_ok[g] ? Aptr + tap_off[g] + c0 : zero;
-                __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (g * 8 + wave) * 1024, 16, 0, 0);
-            }
+            a_koff = (kt - tap * tiles_per_tap) * BK;
+        }
+    };
+    // generic (slow) source of row group g for tile kt: input conv (C = 8) and odd K only
+    auto slow_src = [&](int kt, int g) -> const half_t* {
+        const int k = kt * BK + lch * 8;
+        if (AMODE == MOCA_A_LINEAR) {
+            return (k < p.K && row_ok[g]) ? Aptr + row_off[g] + k : zero;
         } else if (AMODE == MOCA_A_CONV3X3) {
-            const int k = kt * BK + lch * 8;
             const int tap = k / p.C, c = k - tap * p.C;
             const int ky = tap / 3, kx = tap - ky * 3;
             const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
-            const bool kok = tap < 9;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int iy = row_y[g] + ky, ix = row_x[g] + kx;
-                const bool ok = kok && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
-                if (p.up) { iy >>= 1; ix >>= 1; }
-                const half_t* src = ok ? Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + c : zero;
-                __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (g * 8 + wave) * 1024, 16, 0, 0);
-            }
+            int iy = row_y[g] + ky, ix = row_x[g] + kx;
+            const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+            if (p.up) { iy >>= 1; ix >>= 1; }
+            return ok ? Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + c : zero;
         } else {
-            const int k = kt * BK + lch * 8;
             const int tap = k / p.C, c = k - tap * p.C;
-            const bool kok = tap < 3;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int tt = row_y[g] + tap - 1;
-                const bool ok = kok && row_ok[g] && tt >= 0 && tt < p.T;
-                const half_t* src = ok ? Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + c : zero;
-                __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (g * 8 + wave) * 1024, 16, 0, 0);
-            }
+            const int tt = row_y[g] + tap - 1;
+            const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
+            return ok ? Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + c : zero;
         }
-        // ---- W: BN/64 full rounds (+ half a round for BN = 160, waves 0-3) ----
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
+    };
+    // DMA piece j (0..3: A row groups, 4..6: W row groups) of tile kt into ring slot `slot`
+    auto dma_piece = [&](int kt, int slot, int j) {
+        const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
+        if (j < 4) {
+            const half_t* src = fast ? a_base[j] + a_koff : slow_src(kt, j);
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (j * 8 + wave) * 1024, 16, 0, 0);
+        } else {
+            const int g = j - 4;
             if (g * 8 + 7 < B_GROUPS || (g * 8 < B_GROUPS && wave < B_GROUPS - g * 8))
-                __builtin_amdgcn_global_load_lds((glb_ptr)(w_row[g] + kt * BK), sb + (g * 8 + wave) * 1024, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr)(w_row[g] + kt * BK), sa + A_BYTES + (g * 8 + wave) * 1024, 16, 0, 0);
         }
+    };
+    auto issue = [&](int kt, int slot) {
+        begin_tile(kt);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) dma_piece(kt, slot, j);
     };
 
     f32x4 acc[4][NT];
@@ -565,49 +566,83 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int row = wave_n * (BN / 2) + nt * 16 + fr;
-        b_row_b[nt] = row * ROW_BYTES;
+        b_row_b[nt] = A_BYTES + row * ROW_BYTES;
         b_swz[nt] = (row >> 1) & 7;
     }
 
     // number of DMA instructions this wave issues per k-tile (for the counted wait)
     const bool extra_w = (B_GROUPS % 8) != 0 && wave < (B_GROUPS % 8);
 
+    // ---- software-pipelined, hand-interleaved main loop ---------------------------------------
+    // Two fragment register sets.  Per k-tile i each wave runs
+    //   P0: MFMAs on set0 (k 0..31 of tile i), with the ds_reads of k 32..63 (-> set1) and the 6-7 DMA
+    //       instructions of tile i+2 dropped one at a time into the gaps between MFMA pairs
+    //   sync: counted vmcnt (tile i+1 landed), lgkmcnt(0), ONE s_barrier
+    //   P1: MFMAs on set1, with the ds_reads of k 0..31 of tile i+1 (-> set0) in the gaps
+    // sched_barrier(0) pins the interleave the source spells out.
+    half8v af0[4], bf0[NT], af1[4], bf1[NT];
+    auto read_one = [&](const char* st, int ks, int r, half8v (&af)[4], half8v (&bf)[NT]) {
+        const int ch = ks * 4 + fg;
+        if (r < 4) af[r] = *reinterpret_cast<const half8v*>(st + a_row_b[r] + ((ch ^ a_swz[r]) << 4));
+        else bf[r - 4] = *reinterpret_cast<const half8v*>(st + b_row_b[r - 4] + ((ch ^ b_swz[r - 4]) << 4));
+    };
+    auto wait_tile = [&](bool more_in_flight) {
+        // this wave's DMAs of the awaited tile are complete once at most one tile's worth is outstanding
+        if (more_in_flight) {
+            if (B_GROUPS % 8 == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else if (extra_w) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    constexpr int NMMA = 4 * NT;     // MFMAs per half k-tile
+    constexpr int NRD = 4 + NT;      // fragment reads per half k-tile
+
     if (nk > 0) issue(kt_begin, 0);
     if (nk > 1) issue(kt_begin + 1, 1);
-
+    if (nk > 0) {
+        wait_tile(nk > 1);
+#pragma unroll
+        for (int r = 0; r < NRD; ++r) read_one(smem, 0, r, af0, bf0);
+    }
     for (int i = 0; i < nk; ++i) {
-        // tile i has landed once at most one tile's worth of this wave's DMAs is still in flight
-        if (i + 1 < nk) {
-            if (B_GROUPS % 8 == 0) {
-                if (BN == 128) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else {
-                if (extra_w) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        const char* cur = smem + (i % 3) * STAGE;
+        const bool do_issue = i + 2 < nk;     // ring slot (i-1)%3: every wave passed sync(i-1) after its last read of it
+        const int kt2 = kt_begin + i + 2, slot2 = (i + 2) % 3;
+        if (do_issue) begin_tile(kt2);
+        // ---- P0 ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < NMMA; ++j) {
+            const int mt = j / NT, nt = j % NT;
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf0[nt], af0[mt], acc[mt][nt], 0, 0, 0);
+            if (j & 1) {
+                const int r = j >> 1;
+                if (r < NRD) read_one(cur, 1, r, af1, bf1);
+                if (r >= 1 && r <= 7 && do_issue) dma_piece(kt2, slot2, r - 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();     // every wave's part of tile i is in LDS; slot (i-1)%3 is free
-        if (i + 2 < nk) issue(kt_begin + i + 2, (i + 2) % 3);
-
-        const char* a = smem + (i % 3) * STAGE;
-        const char* b = a + A_BYTES;
+        __builtin_amdgcn_s_setprio(0);
+        // ---- sync ----
+        const bool has_next = i + 1 < nk;
+        if (has_next) wait_tile(do_issue);
+        const char* nxt = smem + ((has_next ? i + 1 : i) % 3) * STAGE;
+        // ---- P1 ----
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ch = ks * 4 + fg;
-            half8v af[4], bf[NT];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                af[mt] = *reinterpret_cast<const half8v*>(a + a_row_b[mt] + ((ch ^ a_swz[mt]) << 4));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                bf[nt] = *reinterpret_cast<const half8v*>(b + b_row_b[nt] + ((ch ^ b_swz[nt]) << 4));
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);   // D^T: lane = row m, regs = 4 consecutive n
+        for (int j = 0; j < NMMA; ++j) {
+            const int mt = j / NT, nt = j % NT;
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf1[nt], af1[mt], acc[mt][nt], 0, 0, 0);
+            if (j & 1) {
+                const int r = j >> 1;
+                if (r < NRD) read_one(nxt, 0, r, af0, bf0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();   // all fragment reads done before the ring is reused by the epilogue
 
