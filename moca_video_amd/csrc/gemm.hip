@@ -831,6 +831,10 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     if (p.ldo % 8 || (p.residual && p.ldr % 8) || (p.rowadd && (p.ld_rowadd % 8 || p.rowadd_div <= 0))) return MOCA_E_BADARG;
     if (p.splits > 1 && !p.splitk_ws) return MOCA_E_BADARG;
     if (p.splits > p.ldw / BK) p.splits = p.ldw / BK;
+    if (p.splits > 1) {   // no empty k range: every split writes its slab
+        const int nkt = p.ldw / BK, kts = (nkt + p.splits - 1) / p.splits;
+        p.splits = (nkt + kts - 1) / kts;
+    }
     switch (p.a_mode) {
         case MOCA_A_LINEAR:
             if (p.lda % 8 || p.lda < p.K) return MOCA_E_BADARG;

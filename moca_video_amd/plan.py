@@ -59,12 +59,16 @@ class _Plan:
             self.pool.put(b)
 
     def _splits(self, M, pw):
-        bn = 128 if pw.N % 128 == 0 else 64
-        tiles = ((M + 127) // 128) * (pw.N // bn)
+        """split-K factor: only when the launch cannot give every CU a tile (mirrors the C-side dispatch)."""
+        if M > 128 and (pw.N % 128 == 0 or pw.N % 160 == 0):
+            tm, bn = 256, (128 if pw.N % 128 == 0 else 160)
+        else:
+            tm, bn = 128, (128 if pw.N % 128 == 0 else 64)
+        tiles = ((M + tm - 1) // tm) * (pw.N // bn)
         nk = pw.w.shape[1] // 64
-        if tiles >= N_CU:
+        if tiles >= (N_CU * 3) // 4:
             return 1
-        return max(1, min((N_CU * 3 // 2) // tiles, nk // 8))
+        return max(1, min(N_CU // tiles, nk // 8))
 
     def _gemm(self, a, pw, M, *, out_cols=None, **kw):
         n_out = pw.n_out if pw.geglu else pw.N
@@ -115,9 +119,10 @@ class _Plan:
         """ResBlock._forward, openaimodel3d.py:208-234"""
         P, HW = self.P, x.H * x.W
         g1 = self.gn(x, P[id(mod.in_layers[0])], fps=1, eps=1e-5, silu=True)
-        emb_out = self.linear(self.emb_silu, self.BT, P[id(mod.emb_layers[1])])
+        off, width = self.model._emb_cols[id(mod)]
+        emb_out = self.emb_all[:, off:off + width]               # this block's columns of the fused emb_layers GEMM
         h1 = self.conv(_FMap(g1, x.F, x.H, x.W, x.C), P[id(mod.in_layers[2])], rowadd=emb_out, rowadd_div=HW)
-        self._release(g1, emb_out)
+        self._release(g1)
         g2 = self.gn(h1, P[id(mod.out_layers[0])], fps=1, eps=1e-5, silu=True)
         self._release(h1.buf)
         if isinstance(mod.skip_connection, torch.nn.Identity):
@@ -160,13 +165,13 @@ class _Plan:
         return o
 
     def _attn_cross(self, att, l, M, Cn, heads, F, HW):
-        pq, pkv = self.P[id(att)]
-        q = self.linear(l, M, pq)
-        kv = self.linear(self.ctx, self.B * self.L, pkv)         # one K/V per video (context.repeat_interleave, :547)
+        q = self.linear(l, M, self.P[id(att)])
+        off, inner = self.model._kv_cols[id(att)]                # one K/V per video (context.repeat_interleave, :547),
+        ld = self.kv_all.shape[1]                                # all layers' K|V projected by one GEMM up front
         o = self.pool.get(M, Cn)
-        self._emit(ops.attention, q, kv[:, :Cn], kv[:, Cn:], o, Bq=F, heads=heads, Nq=HW, Nk=self.L, ldq=Cn, ldk=2 * Cn,
-                   ldv=2 * Cn, ldo=Cn, kv_div=self.T, scale=att.dim_head ** -0.5)
-        self._release(q, kv)
+        self._emit(ops.attention, q, self.kv_all[:, off:off + inner], self.kv_all[:, off + inner:off + 2 * inner], o, Bq=F,
+                   heads=heads, Nq=HW, Nk=self.L, ldq=Cn, ldk=ld, ldv=ld, ldo=Cn, kv_div=self.T, scale=att.dim_head ** -0.5)
+        self._release(q)
         return o
 
     def tblock(self, blk, h, M, Cn, heads, spatial, F, HW):
@@ -243,6 +248,12 @@ class _Plan:
         self._emit(ops.silu_add_rows, emb, 1, femb, 1, self.emb_silu, rows=BT, Cn=emb.shape[1], silu=True)
         self._release(emb, femb)
         self._pinned.add(self.emb_silu.data_ptr())
+        self.emb_all = self.linear(self.emb_silu, BT, P["emb_all"])          # [BT][sum Cout]: every ResBlock's emb_layers
+        self._pinned.add(self.emb_all.data_ptr())
+        self.kv_all = None
+        if "ctx_kv_all" in P:
+            self.kv_all = self.linear(self.ctx, B * self.L, P["ctx_kv_all"])  # [B*L][sum 2C]: every cross-attention K|V
+            self._pinned.add(self.kv_all.data_ptr())
 
         x8 = self.pool.get(BT * H * W, 8)
         self._emit(ops.ncthw_to_nhwc, self.x_in, x8, B=B, Cin=m.in_channels, T=T, HW=H * W, Cpad=8)

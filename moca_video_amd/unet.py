@@ -321,7 +321,6 @@ class UNetModel(nn.Module):
                 P[id(c1)] = ops.pack_conv3x3(c1.weight.detach(), c1.bias.detach(), device=dev)
                 c2 = mod.out_layers[3]
                 P[id(c2)] = ops.pack_conv3x3(c2.weight.detach(), c2.bias.detach(), device=dev)
-                lin(mod.emb_layers[1])
                 if isinstance(mod.skip_connection, _Param):
                     s = mod.skip_connection
                     P[id(s)] = ops.pack_conv1x1(s.weight.detach(), s.bias.detach(), device=dev)
@@ -338,8 +337,7 @@ class UNetModel(nn.Module):
                     if att.is_self:
                         P[id(att)] = ops.pack_linear_cat([att.to_q.weight.detach(), att.to_k.weight.detach(), att.to_v.weight.detach()], device=dev)
                     else:
-                        P[id(att)] = (ops.pack_linear(att.to_q.weight.detach(), device=dev),
-                                      ops.pack_linear_cat([att.to_k.weight.detach(), att.to_v.weight.detach()], device=dev))
+                        P[id(att)] = ops.pack_linear(att.to_q.weight.detach(), device=dev)
                     lin(att.to_out[0])
                 g = mod.ff.net[0].proj
                 P[id(g)] = ops.pack_geglu(g.weight.detach().to(dev), g.bias.detach().to(dev), device=dev)
@@ -348,6 +346,25 @@ class UNetModel(nn.Module):
                 P[id(mod.op)] = ops.pack_conv3x3(mod.op.weight.detach(), mod.op.bias.detach(), device=dev)
             elif isinstance(mod, _Upsample):
                 P[id(mod.conv)] = ops.pack_conv3x3(mod.conv.weight.detach(), mod.conv.bias.detach(), device=dev)
+        # All ResBlock.emb_layers Linears share the input SiLU(emb) and all cross-attention to_k/to_v share the
+        # text context: fuse each family into ONE wide GEMM per forward (column offsets are multiples of 64).
+        res = [m for m in self.modules() if isinstance(m, _ResBlock)]
+        self._emb_cols, off = {}, 0
+        for m in res:
+            self._emb_cols[id(m)] = (off, m.cout)
+            off += m.cout
+        P["emb_all"] = ops.pack_linear_cat([m.emb_layers[1].weight.detach() for m in res],
+                                           [m.emb_layers[1].bias.detach() for m in res], device=dev)
+        cross = [b.attn2 for b in self.modules() if isinstance(b, _BasicTransformerBlock) and not b.attn2.is_self]
+        self._kv_cols, off = {}, 0
+        ws = []
+        for a in cross:
+            inner = a.to_k.weight.shape[0]
+            self._kv_cols[id(a)] = (off, inner)
+            off += 2 * inner
+            ws += [a.to_k.weight.detach(), a.to_v.weight.detach()]
+        if ws:
+            P["ctx_kv_all"] = ops.pack_linear_cat(ws, device=dev)
         for sq in (self.time_embed,) + ((self.fps_embedding,) if self.fps_cond else ()):
             lin(sq[0]); lin(sq[2])
         cin = self.input_blocks[0][0]
