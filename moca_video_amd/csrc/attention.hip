@@ -2,12 +2,17 @@
 //
 // moca_attention_f16: flash-style softmax(QK^T*scale)V for the spatial self / cross
 //   attention (N = H*W up to 2560 queries; 77/154 context keys).  256 threads = 4
-//   wavefronts x 32 query rows; K/V tiles of 64 keys staged in LDS (K row-major with
-//   an XOR swizzle, V transposed + key-permuted so that the P.V operand is one
-//   ds_read_b128).  The score tile is computed "swapped" (S^T = K.Q^T with
-//   v_mfma_f32_32x32x16_f16) so every lane owns ONE query column: the online-softmax
-//   row reduction is 31 in-lane max/adds plus one lane<->lane+32 exchange, and the
-//   S^T accumulator registers are directly the B operand of O^T += V^T.P^T.
+//   wavefronts x 32 query rows; K/V tiles of 64 keys double-buffered in LDS, both
+//   row-major as they come from HBM (16-byte coalesced staging): K XOR-swizzled for the
+//   ds_read_b128 fragment reads, V XOR-swizzled for ds_read_b64_tr_b16, the CDNA4
+//   transposing LDS read that delivers the V^T operand of P.V without any data movement.
+//   The score tile is computed "swapped" (S^T = K.Q^T with v_mfma_f32_32x32x16_f16) so
+//   every lane owns ONE query column: the online-softmax row reduction is 31 in-lane
+//   max/adds plus one lane<->lane+32 exchange, and the S^T accumulator registers are
+//   directly the B operand of O^T += V^T.P^T (k order of the accumulator-as-operand
+//   trick: key = 16s + 8(j>>2) + 4h + (j&3), matched by two 4-key transposed reads).
+//   One barrier per key tile; the accumulator rescale is skipped (wave-uniform branch)
+//   when no lane's running maximum moved.
 //
 // moca_temporal_attention_f16: attention over the frame axis (T <= 16) per
 //   (pixel, head): one wavefront per problem with v_mfma_f32_16x16x32_f16 (QK^T) and
@@ -23,19 +28,23 @@ constexpr int KT = 64;       // keys per LDS tile
 constexpr int QB = 128;      // queries per block
 constexpr int ROWB = 128;    // bytes per LDS row (64 halves)
 
-// position of key kk (0..63) inside a transposed V row so that the 8 keys one lane
-// needs for k-step (sub, s) and lane-half h are contiguous (see header comment)
-__device__ __forceinline__ int vpos(int key) {
-    const int sub = key >> 5, kk = key & 31;
-    const int s = kk >> 4, jhi = (kk >> 3) & 1, h = (kk >> 2) & 1, jlo = kk & 3;
-    return sub * 32 + (s * 2 + h) * 8 + jhi * 4 + jlo;
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
+
+// ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block of 16-bit elements and receives it
+// column-major (lane i gets column i of the 4 rows).  Lane i = 4q+p supplies the address of row q, columns 4p..4p+3.
+__device__ __forceinline__ half4v tr_read(const char* addr) {
+    const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)addr);
+    return __builtin_bit_cast(half4v, v);
 }
 
 __global__ __launch_bounds__(256, 2) void attention_kernel(
     const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, half_t* __restrict__ out,
     int heads, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, int kv_div, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) char sK[KT * ROWB];
-    __shared__ __attribute__((aligned(16))) char sVt[D * ROWB];
+    // double-buffered K / V tiles: K row-major [key][d] swizzled for ds_read_b128 (chunk ^ ((row>>1)&7)),
+    // V row-major [key][d] swizzled for the transposed reads (chunk ^ (((row>>1)&1)<<2))
+    __shared__ __attribute__((aligned(16))) char sK[2][KT * ROWB];
+    __shared__ __attribute__((aligned(16))) char sV[2][KT * ROWB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bq = blockIdx.y / heads, head = blockIdx.y % heads;
@@ -80,28 +89,34 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
             rk[i] = a; rv[i] = b;
         }
     };
-    auto store_kv = [&]() {
+    auto store_kv = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = r0 + 32 * i;
-            *reinterpret_cast<half8v*>(sK + row * ROWB + ((cc ^ ((row >> 1) & 7)) << 4)) = rk[i];
-            const int pos = vpos(row);
-            const int pch = pos >> 3, pin = pos & 7;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = cc * 8 + j;
-                *reinterpret_cast<half_t*>(sVt + d * ROWB + ((pch ^ ((d >> 1) & 7)) << 4) + pin * 2) = rv[i][j];
-            }
+            *reinterpret_cast<half8v*>(sK[buf] + row * ROWB + ((cc ^ ((row >> 1) & 7)) << 4)) = rk[i];
+            *reinterpret_cast<half8v*>(sV[buf] + row * ROWB + ((cc ^ (((row >> 1) & 1) << 2)) << 4)) = rv[i];
         }
     };
+    // per-lane constants of the transposed V reads: lane i = lane&15 = 4q+p of its 16-lane group
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int tcol16 = (lane >> 4) & 1;          // which 16-column half of the 32-wide d tile
+    const int tkey4 = 4 * fh;                     // lane half h selects keys +4
 
     const int nkt = (Nk + KT - 1) / KT;
     load_kv(0);
+    store_kv(0);
+    if (nkt > 1) load_kv(1);
+    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();   // previous tile's LDS reads are done
-        store_kv();
-        __syncthreads();
-        if (kt + 1 < nkt) load_kv(kt + 1);
+        const int cur = kt & 1;
+        // stage the next tile into the other buffer (its last readers passed the previous barrier),
+        // then fetch the tile after it into registers: both overlap the MFMA/softmax work below
+        if (kt + 1 < nkt) {
+            store_kv(cur ^ 1);
+            if (kt + 2 < nkt) load_kv(kt + 2);
+        }
+        const char* kbuf = sK[cur];
+        const char* vbuf = sV[cur];
 
         // ---- S^T = K . Q^T ----
         f32x16 s[2];
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int ch = ks * 2 + fh;
-                const half8v kf = *reinterpret_cast<const half8v*>(sK + row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4));
+                const half8v kf = *reinterpret_cast<const half8v*>(kbuf + row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4));
                 s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sub], 0, 0, 0);
             }
         }
@@ -135,7 +150,6 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
             for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[sub][r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f((m_run - m_new) * scale_log2e);
         const float mb = m_new * scale_log2e;
         float psum = 0.f;
         half8v pf[2][2];
@@ -143,29 +157,41 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[sub][r] * scale_log2e - mb);
+                const float pv = __builtin_amdgcn_exp2f(s[sub][r] * scale_log2e - mb);
                 psum += pv;
                 pf[sub][r >> 3][r & 7] = (half_t)pv;
             }
-        l_run = l_run * alpha + psum;
+        // rescale only when some lane's running max moved (wave-uniform branch; alpha == 1 otherwise)
+        if (__any(m_new > m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+        l_run += psum;
         m_run = m_new;
+        // ---- O^T += V^T . P^T ; V^T fragments by transposed LDS reads of the row-major V tile ----
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        // ---- O^T += V^T . P^T ----
+            for (int ss = 0; ss < 2; ++ss) {
+                const int krow0 = sub * 32 + ss * 16 + tkey4 + tq;     // row of the first 4-key block; second is +8
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const int drow = dt * 32 + fr;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int ss = 0; ss < 2; ++ss) {
-                    const int ch = sub * 4 + ss * 2 + fh;
-                    const half8v vf = *reinterpret_cast<const half8v*>(sVt + drow * ROWB + ((ch ^ ((drow >> 1) & 7)) << 4));
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int dcol = dt * 32 + tcol16 * 16 + 4 * tp;     // first of this lane's 4 address columns
+                    const int ch = dcol >> 3, within = (dcol & 7) * 2;
+                    const int ra = krow0, rb = krow0 + 8;
+                    const half4v lo = tr_read(vbuf + ra * ROWB + ((ch ^ (((ra >> 1) & 1) << 2)) << 4) + within);
+                    const half4v hi = tr_read(vbuf + rb * ROWB + ((ch ^ (((rb >> 1) & 1) << 2)) << 4) + within);
+                    half8v vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[sub][ss], o[dt], 0, 0, 0);
                 }
-        }
+            }
+        __syncthreads();   // everyone is done with buffers [cur]; the other buffers' stores are visible
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
