@@ -63,12 +63,46 @@ def cpu_baseline(dm, x, ctx, ts, threads):
     return dt, y
 
 
+def fifo_leg(dm, device, T, H, W, iters=3):
+    """Extra (not the headline value): one outer iteration of the MoCA FIFO loop (configs[2-3]) at full size --
+    8 diagonal windows x {cond (2 prompts = 154 tokens), uncond (77)} = 16 UNet-steps, evaluated as two batched
+    B=8 launches, + 8 MoCA ddim_steps with mask injection + queue shift with the FreeInit mix."""
+    import types
+    from moca_video_amd.fifo import fifo_ddim_sampling
+    from moca_video_amd.sampler import DDIMSampler
+    args = types.SimpleNamespace(num_inference_steps=64, video_length=T, lookahead_denoising=True, num_partitions=4,
+                                 new_video_length=100)
+    s = DDIMSampler(dm)
+    s.make_schedule(64, ddim_eta=1.0, verbose=False)
+    g = torch.Generator(device=device).manual_seed(7)
+    Q = 64 + T // 2
+    lat = torch.randn(1, 4, Q, H, W, device=device, generator=g)
+    cond = {"c_crossattn": [torch.randn(1, 77, 1024, device=device, generator=g), torch.randn(1, 77, 1024, device=device, generator=g)],
+            "fps": torch.tensor([10], device=device)}
+    uc_emb = torch.randn(1, 77, 1024, device=device, generator=g)
+    mask = torch.zeros(1, 1, Q, H, W, device=device)
+    mask[..., H // 4: 3 * H // 4, W // 4: 3 * W // 4] = 1.0
+    cimg = torch.rand(1, 4, 1, H, W, device=device, generator=g)
+    run = lambda n: fifo_ddim_sampling(args, dm, cond, (1, 4, T, H, W), s, cfg_scale=12.0, uc_emb=uc_emb, latents=lat,
+                                       conditioned_image=cimg, masks=mask, n_iterations=n, batch_windows=True)
+    run(2)      # eager + graph capture of the two B=8 plans
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(iters)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"iteration_ms": round(dt * 1e3, 2), "unet_steps_per_iteration": 16, "unet_steps_per_s": round(16 / dt, 2),
+            "projected_s_per_video_148_iterations": round(148 * dt, 1),
+            "note": "8 windows batched (B=8, 154-token cond + B=8, 77-token uncond), MoCA ddim_step + FreeInit shift included, VAE decode excluded"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fifo", action="store_true", help="skip the extra batched-FIFO-iteration measurement")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--height", type=int, default=40)
@@ -186,6 +220,8 @@ def main():
                                "conv/linear dominates), batch 2",
                      "flop_per_launch": flop_per_launch, "avg_launch_ms": round(avg_launch_ms, 3), "launches": len(unet_ms)},
     }
+    if world == 1 and not args.no_fifo:
+        res["fifo"] = fifo_leg(dm, device, T, H, W)
     if world == 1 and not args.no_cpu_baseline:
         threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share
         ts = torch.full((1,), int(sampler.ddim_timesteps[S - 1]), device=device, dtype=torch.long)

@@ -87,9 +87,11 @@ def fifo_windows(args):
 
 def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg_scale=1.0, uc_emb=None,
                        latents=None, latents_dir=None, conditioned_image=None, masks=None, gamma=0.5, emit=None,
-                       n_iterations=None, **kwargs):
+                       n_iterations=None, batch_windows=True, noises=None, shift_noises=None, **kwargs):
     """funcs.py:243-373: returns the list of emitted latent frames [B,4,1,h,w] (decode is the caller's).
-    `masks` [B,1,Q,h,w] (Q = queue length) plays the role of the DAVIS masks (:296-302,315)."""
+    `masks` [B,1,Q,h,w] (Q = queue length) plays the role of the DAVIS masks (:296-302,315).
+    batch_windows=True evaluates the 2n windows of an iteration as one batched UNet launch (SURVEY 8f N2);
+    `noises[i][w]` / `shift_noises[i]` optionally fix the per-window DDIM noise and the enqueued noise."""
     kwargs.update({"clean_cond": True})
     cond = conditioning
     uc = None
@@ -109,14 +111,27 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
     total = args.new_video_length + args.num_inference_steps - f if n_iterations is None else n_iterations
     frames = []
     for i in range(total):
-        for start, mid, end in fifo_windows(args):
+        wins = list(fifo_windows(args))
+        eps_list = None
+        if batch_windows:
+            # N2: all windows of this iteration as one batched UNet launch (they are independent, see unet_windows)
+            eps_list = ddim_sampler.unet_windows([latents[:, :, s0:e0].clone() for s0, _, e0 in wins], cond,
+                                                 [timesteps[s0:e0] for s0, _, e0 in wins],
+                                                 unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc, **kwargs)
+        for wi, (start, mid, end) in enumerate(wins):
             t, idx = timesteps[start:end], indices[start:end]
             input_latents = latents[:, :, start:end].clone()
             input_masks = masks[:, :, start:end].clone() if masks is not None else None
-            output_latents, _ = ddim_sampler.fifo_onestep(cond=cond, shape=noise_shape, latents=input_latents, timesteps=t,
-                                                          indices=idx, unconditional_guidance_scale=cfg_scale,
-                                                          unconditional_conditioning=uc, cond_image=conditioned_image,
-                                                          davis_masks=input_masks, gamma=gamma, **kwargs)
+            noise = None if noises is None else noises[i][wi]
+            if eps_list is not None:
+                ts_t = torch.as_tensor(np.asarray(t).copy(), device=latents.device).to(torch.long)
+                output_latents, _ = ddim_sampler.ddim_step(input_latents, eps_list[wi], idx, conditioned_image, None, ts_t,
+                                                           davis_masks=input_masks, noise=noise)
+            else:
+                output_latents, _ = ddim_sampler.fifo_onestep(cond=cond, shape=noise_shape, latents=input_latents, timesteps=t,
+                                                              indices=idx, unconditional_guidance_scale=cfg_scale,
+                                                              unconditional_conditioning=uc, cond_image=conditioned_image,
+                                                              davis_masks=input_masks, noise=noise, **kwargs)
             if args.lookahead_denoising:
                 latents[:, :, mid:end] = output_latents[:, :, -(f // 2):]
             else:
@@ -124,7 +139,7 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
         first = f // 2 if args.lookahead_denoising else 0
         frame = latents[:, :, [first]].clone()
         frames.append(frame if emit is None else emit(frame))
-        latents = shift_latents(latents)
+        latents = shift_latents(latents, noise=None if shift_noises is None else shift_noises[i])
         if masks is not None:
             masks[:, :, :-1] = masks[:, :, 1:].clone()
     return frames

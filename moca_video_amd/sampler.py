@@ -178,6 +178,45 @@ class DDIMSampler(object):
             torch.save(img, f"{latents_dir}/{total_steps}.pt")        # :249-250
         return img, {}
 
+    @torch.no_grad()
+    def unet_windows(self, windows, c, ts_list, unconditional_guidance_scale=1., unconditional_conditioning=None, **kwargs):
+        """CFG noise prediction for several independent FIFO windows in ONE batched UNet call.
+
+        The 2n windows of one outer FIFO iteration read only pre-iteration frames (funcs.py:305-352: rank r
+        writes [8r+8,8r+16) and rank r-1 reads [8r-8,8r+8)), so their UNet evaluations are independent; the
+        reference's own multi-GPU variant relies on the same fact (funcs_mp.py:207-221).  Windows become the
+        batch dimension with per-(window, frame) timesteps; with classifier-free guidance of equal context
+        length the unconditional branch doubles the batch (2 x 2n = 16 videos per launch).  Returns the list of
+        per-window eps tensors, equal to `self.unet(w, c, ts, ...)` per window."""
+        W = len(windows)
+        x = torch.cat(windows, 0)
+        t = torch.cat([torch.as_tensor(np.asarray(ts).copy(), device=x.device).to(torch.long).reshape(-1) for ts in ts_list], 0)
+        uc, scale = unconditional_conditioning, unconditional_guidance_scale
+        cc = torch.cat(c["c_crossattn"], 1).expand(W, -1, -1)
+        fps_c = c.get("fps", 16)
+
+        def fps_rows(f, n):
+            return f if isinstance(f, int) else torch.as_tensor(f, device=x.device).reshape(-1)[:1].expand(n)
+
+        if uc is None or scale == 1.:
+            e = self.model.apply_model(x, t, {"c_crossattn": [cc], "fps": fps_rows(fps_c, W)}, **kwargs)
+            return list(e.split(1, 0))
+        cu = torch.cat(uc["c_crossattn"], 1).expand(W, -1, -1)
+        fps_u = uc.get("fps", fps_c)
+        if cc.shape == cu.shape and isinstance(fps_c, int) == isinstance(fps_u, int):
+            fps2 = fps_c if isinstance(fps_c, int) else torch.cat([fps_rows(fps_c, W), fps_rows(fps_u, W)], 0)
+            e = self.model.apply_model(torch.cat([x, x], 0), torch.cat([t, t], 0),
+                                       {"c_crossattn": [torch.cat([cc, cu], 0)], "fps": fps2}, **kwargs)
+            e_c, e_u = e[:W], e[W:]
+        else:   # e.g. 154 conditional tokens (two prompts) vs 77 unconditional: two batched calls
+            e_c = self.model.apply_model(x, t, {"c_crossattn": [cc], "fps": fps_rows(fps_c, W)}, **kwargs)
+            e_u = self.model.apply_model(x, t, {"c_crossattn": [cu], "fps": fps_rows(fps_u, W)}, **kwargs)
+        e_c, e_u = _f32c(e_c), _f32c(e_u)
+        out = torch.empty_like(e_c)
+        _l.check(_l.load().moca_cfg_combine_f32(_l.ptr(e_c), _l.ptr(e_u), _l.ptr(out), float(scale), e_c.numel(), _st()),
+                 "moca_cfg_combine_f32")
+        return list(out.split(1, 0))
+
     # ---- MoCA FIFO step -----------------------------------------------------------------------
     @torch.no_grad()
     def fifo_onestep(self, cond, shape, latents=None, timesteps=None, indices=None, unconditional_guidance_scale=1.,

@@ -75,3 +75,39 @@ def test_unet_rejects_cpu_and_bad_shapes(reduced_model):
         reduced_model(x, torch.tensor([1]), context=torch.zeros(1, 77, 128))          # CPU tensor: no CPU path
     with pytest.raises(ValueError):
         reduced_model(x.cuda(), torch.tensor([1, 2, 3]).cuda(), context=torch.zeros(1, 77, 128).cuda())
+
+
+def test_fifo_batched_windows_equal_sequential():
+    """N2: one outer FIFO iteration with the 8 windows batched into one UNet launch equals the reference's
+    sequential window loop (funcs.py:305-355) -- same queue afterwards, same emitted frame."""
+    import types
+    from moca_video_amd import DenoiseModel
+    from moca_video_amd.fifo import fifo_ddim_sampling
+    from moca_video_amd.sampler import DDIMSampler
+    dm = DenoiseModel({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": REDUCED})
+    unet = dm.model.diffusion_model
+    unet.load_state_dict(state_dict_for(unet, 11), strict=True)
+    dm = dm.cuda()
+    args = types.SimpleNamespace(num_inference_steps=64, video_length=16, lookahead_denoising=True, num_partitions=4,
+                                 new_video_length=100)
+    h, w = 8, 8
+    cond = {"c_crossattn": [inp("fb.ctx", (1, 77, 128)).cuda()], "fps": torch.tensor([10]).cuda()}
+    uc_emb = inp("fb.uc", (1, 77, 128)).cuda()
+    q0 = inp("fb.queue", (1, 4, 72, h, w)).cuda()
+    noises = [[inp(f"fb.nz{i}.{wi}", (1, 4, 16, h, w)).cuda() for wi in range(8)] for i in range(2)]
+    shift = [inp(f"fb.sh{i}", (1, 4, h, w)).cuda() for i in range(2)]
+    mask = (inp("fb.mask", (1, 1, 72, h, w)) > 0.3).float().cuda()
+    cimg = inp("fb.cimg", (1, 4, 1, h, w)).cuda()
+    outs = []
+    for batched in (False, True):
+        s = DDIMSampler(dm)
+        s.make_schedule(64, ddim_eta=1.0, verbose=False)
+        lat = q0.clone()
+        frames = fifo_ddim_sampling(args, dm, cond, (1, 4, 16, h, w), s, cfg_scale=12.0, uc_emb=uc_emb, latents=lat,
+                                    conditioned_image=cimg, masks=mask.clone(), n_iterations=2, batch_windows=batched,
+                                    noises=noises, shift_noises=shift)
+        outs.append((lat, frames))
+    assert relerr(outs[1][0], outs[0][0]) < 5e-3
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert relerr(b, a) < 5e-3
+    assert not torch.equal(outs[0][0], q0)
