@@ -19,6 +19,9 @@
 
 namespace {
 
+struct yes_t { static constexpr bool value = true; };
+struct no_t { static constexpr bool value = false; };
+
 constexpr int BM = 128;
 constexpr int BK = 64;
 constexpr int ROW_BYTES = BK * 2;  // 128 B per LDS row
@@ -390,7 +393,7 @@ __device__ __attribute__((aligned(16))) half_t g_zero_page[ZERO_PAGE_HALVES];
 typedef __attribute__((address_space(3))) char* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
 
-template <int BN, int AMODE>
+template <int BN, int AMODE, bool FAST>
 __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_params p) {
     constexpr int TM = 256;
     constexpr int NT = BN / 32;                       // 16-wide n tiles per wave
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     // element offset to a per-row base pointer.  Rows that must read zeros (conv halo, t-1/t+1 outside the
     // clip, M tail) have the zero page as base; the zero page is longer than any per-tile offset, so no
     // per-tile select is needed.  Bases are recomputed only when the tap changes (every C/64 tiles).
-    const bool fast = (AMODE == MOCA_A_LINEAR) ? (p.K % BK == 0 && p.K <= 8192) : (p.C % BK == 0 && p.C <= 8192);
+    constexpr bool fast = FAST;   // host checks: LINEAR K % 64 == 0, CONV/TCONV C % 64 == 0 (both <= 8192)
     const int tiles_per_tap = (AMODE == MOCA_A_LINEAR || !fast) ? (1 << 30) : p.C / BK;
     const half_t* a_base[4];
     int tap_cur = -1;
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     // per-tile state of the DMA stream (block-uniform): element offset added to every a_base
     int a_koff = 0;
     auto begin_tile = [&](int kt) {
-        if (fast) {
+        if constexpr (fast) {
             const int tap = kt / tiles_per_tap;
             if (tap != tap_cur) set_tap(tap);
             a_koff = (kt - tap * tiles_per_tap) * BK;
@@ -535,7 +538,9 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     auto dma_piece = [&](int kt, int slot, int j) {
         const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
         if (j < 4) {
-            const half_t* src = fast ? a_base[j] + a_koff : slow_src(kt, j);
+            const half_t* src;
+            if constexpr (fast) src = a_base[j] + a_koff;
+            else src = slow_src(kt, j);
             __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (j * 8 + wave) * 1024, 16, 0, 0);
         } else {
             const int g = j - 4;
@@ -607,11 +612,13 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
 #pragma unroll
         for (int r = 0; r < NRD; ++r) read_one(smem, 0, r, af0, bf0);
     }
-    for (int i = 0; i < nk; ++i) {
-        const char* cur = smem + (i % 3) * STAGE;
-        const bool do_issue = i + 2 < nk;     // ring slot (i-1)%3: every wave passed sync(i-1) after its last read of it
-        const int kt2 = kt_begin + i + 2, slot2 = (i + 2) % 3;
-        if (do_issue) begin_tile(kt2);
+    int s_cur = 0, s_nxt = 1, s_far = 2;      // ring slots of tiles i, i+1, i+2 (rotated, no modulo in the loop)
+    // one k-tile step; ISSUE (compile time) = tile i+2 exists and its DMA pieces go into the gaps of P0
+    auto step = [&](auto issue_tag, int i, bool has_next) {
+        constexpr bool do_issue = decltype(issue_tag)::value;
+        const char* cur = smem + s_cur * STAGE;
+        const int kt2 = kt_begin + i + 2, slot2 = s_far;     // ring slot (i-1)%3: every wave passed sync(i-1) after its last read of it
+        if constexpr (do_issue) begin_tile(kt2);
         // ---- P0 ----
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -621,15 +628,14 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
             if (j & 1) {
                 const int r = j >> 1;
                 if (r < NRD) read_one(cur, 1, r, af1, bf1);
-                if (r >= 1 && r <= 7 && do_issue) dma_piece(kt2, slot2, r - 1);
+                if constexpr (do_issue) { if (r >= 1 && r <= 7) dma_piece(kt2, slot2, r - 1); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_s_setprio(0);
         // ---- sync ----
-        const bool has_next = i + 1 < nk;
         if (has_next) wait_tile(do_issue);
-        const char* nxt = smem + ((has_next ? i + 1 : i) % 3) * STAGE;
+        const char* nxt = smem + (has_next ? s_nxt : s_cur) * STAGE;
         // ---- P1 ----
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -643,7 +649,11 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
             }
         }
         __builtin_amdgcn_s_setprio(0);
-    }
+        { const int t = s_cur; s_cur = s_nxt; s_nxt = s_far; s_far = t; }
+    };
+    int i = 0;
+    for (; i + 2 < nk; ++i) step(yes_t{}, i, true);        // steady state: branch-free DMA issue
+    for (; i < nk; ++i) step(no_t{}, i, i + 1 < nk);       // last two tiles: nothing left to prefetch
     __syncthreads();   // all fragment reads done before the ring is reused by the epilogue
 
     // The MFMAs above compute the TRANSPOSED tile (W fragment as A operand), so accumulator element r
@@ -775,7 +785,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     }
 }
 
-template <int BN, int AMODE>
+template <int BN, int AMODE, bool FAST>
 int launch_gemm_glds(const moca_gemm_params& p, hipStream_t st) {
     const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / BN;
     const int nblk = tiles_m * tiles_n * p.splits;
@@ -784,12 +794,12 @@ int launch_gemm_glds(const moca_gemm_params& p, hipStream_t st) {
     constexpr int lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BN, AMODE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BN, AMODE, FAST>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MOCA_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<BN, AMODE>), dim3(nblk), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_glds_kernel<BN, AMODE, FAST>), dim3(nblk), dim3(512), lds, st, p);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
@@ -859,14 +869,15 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     // large-tile direct-to-LDS kernel whenever a 256-row tile is at least half full
     const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
     const bool use_big = big_bn != 0 && p.M > 128 && !(p.flags & MOCA_FORCE_SMALL_TILE);
+    const bool fastp = (p.a_mode == MOCA_A_LINEAR) ? (p.K % BK == 0 && p.K <= 8192) : (p.C % BK == 0 && p.C <= 8192);
     if (use_big && big_bn == 128) {
-        if (p.a_mode == MOCA_A_LINEAR) rc = launch_gemm_glds<128, MOCA_A_LINEAR>(p, st);
-        else if (p.a_mode == MOCA_A_CONV3X3) rc = launch_gemm_glds<128, MOCA_A_CONV3X3>(p, st);
-        else rc = launch_gemm_glds<128, MOCA_A_TCONV3>(p, st);
+        if (p.a_mode == MOCA_A_LINEAR) rc = fastp ? launch_gemm_glds<128, MOCA_A_LINEAR, true>(p, st) : launch_gemm_glds<128, MOCA_A_LINEAR, false>(p, st);
+        else if (p.a_mode == MOCA_A_CONV3X3) rc = fastp ? launch_gemm_glds<128, MOCA_A_CONV3X3, true>(p, st) : launch_gemm_glds<128, MOCA_A_CONV3X3, false>(p, st);
+        else rc = fastp ? launch_gemm_glds<128, MOCA_A_TCONV3, true>(p, st) : launch_gemm_glds<128, MOCA_A_TCONV3, false>(p, st);
     } else if (use_big) {
-        if (p.a_mode == MOCA_A_LINEAR) rc = launch_gemm_glds<160, MOCA_A_LINEAR>(p, st);
-        else if (p.a_mode == MOCA_A_CONV3X3) rc = launch_gemm_glds<160, MOCA_A_CONV3X3>(p, st);
-        else rc = launch_gemm_glds<160, MOCA_A_TCONV3>(p, st);
+        if (p.a_mode == MOCA_A_LINEAR) rc = fastp ? launch_gemm_glds<160, MOCA_A_LINEAR, true>(p, st) : launch_gemm_glds<160, MOCA_A_LINEAR, false>(p, st);
+        else if (p.a_mode == MOCA_A_CONV3X3) rc = fastp ? launch_gemm_glds<160, MOCA_A_CONV3X3, true>(p, st) : launch_gemm_glds<160, MOCA_A_CONV3X3, false>(p, st);
+        else rc = fastp ? launch_gemm_glds<160, MOCA_A_TCONV3, true>(p, st) : launch_gemm_glds<160, MOCA_A_TCONV3, false>(p, st);
     } else if (wide) {
         if (p.a_mode == MOCA_A_LINEAR) rc = launch_gemm<128, MOCA_A_LINEAR>(p, st);
         else if (p.a_mode == MOCA_A_CONV3X3) rc = launch_gemm<128, MOCA_A_CONV3X3>(p, st);
