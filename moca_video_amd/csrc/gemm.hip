@@ -19,6 +19,7 @@
 
 namespace {
 
+template <int V> struct int_c { static constexpr int value = V; };
 struct yes_t { static constexpr bool value = true; };
 struct no_t { static constexpr bool value = false; };
 
@@ -390,6 +391,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const moca_gemm_para
 constexpr int ZERO_PAGE_HALVES = 8192 + 64;
 __device__ __attribute__((aligned(16))) half_t g_zero_page[ZERO_PAGE_HALVES];
 
+#ifdef MOCA_STAMPS
+// diagnostic build only (-DMOCA_STAMPS): per-block s_memtime stamps, read back with moca_debug_stamps()
+constexpr int STAMP_SLOTS = 8, STAMP_BLOCKS = 16384;
+__device__ unsigned long long g_stamps[STAMP_BLOCKS * STAMP_SLOTS];
+#define MOCA_STAMP(k)                                                                              \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {                                       \
+            unsigned long long t__;                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
+            g_stamps[blockIdx.x * STAMP_SLOTS + (k)] = t__;                                        \
+        }                                                                                          \
+    } while (0)
+#else
+#define MOCA_STAMP(k) do {} while (0)
+#endif
+
+// q = n / d, r = n % d for 0 <= n < 2^24 via one float multiply and a +-1 fix-up (rd = 1.0f / d);
+// the row-descriptor set-up of a block does 8-12 of these and sits on its critical path
+__device__ __forceinline__ void divmod24(int n, int d, float rd, int& q, int& r) {
+    q = (int)((float)n * rd);
+    r = n - q * d;
+    if (r < 0) { r += d; --q; }
+    else if (r >= d) { r -= d; ++q; }
+}
+
 typedef __attribute__((address_space(3))) char* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
 
@@ -403,6 +429,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     constexpr int B_GROUPS = BN / 8;                  // 1 KiB row groups of the W tile (16 or 20)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MOCA_STAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -447,14 +474,27 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
             row_y[g] = row_x[g] = 0;
         } else if (AMODE == MOCA_A_CONV3X3) {
             const int ohw = p.outH * p.outW;
-            const int f = mm / ohw, rem = mm - f * ohw;
-            const int oy = rem / p.outW, ox = rem - oy * p.outW;
+            int f, rem, oy, ox;
+            if (p.M < (1 << 24)) {
+                divmod24(mm, ohw, 1.0f / (float)ohw, f, rem);
+                divmod24(rem, p.outW, 1.0f / (float)p.outW, oy, ox);
+            } else {
+                f = mm / ohw; rem = mm - f * ohw;
+                oy = rem / p.outW; ox = rem - oy * p.outW;
+            }
             row_off[g] = (int64_t)f * p.inH * p.inW;
             row_y[g] = oy * p.stride - 1;
             row_x[g] = ox * p.stride - 1;
         } else {
+            int frame, pix, vid, t;
+            if (p.M < (1 << 24)) {
+                divmod24(mm, p.HW, 1.0f / (float)p.HW, frame, pix);
+                divmod24(frame, p.T, 1.0f / (float)p.T, vid, t);
+            } else {
+                frame = mm / p.HW; t = frame % p.T;
+            }
             row_off[g] = mm;
-            row_y[g] = (mm / p.HW) % p.T;
+            row_y[g] = t;
             row_x[g] = 0;
         }
     }
@@ -607,8 +647,10 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
 
     if (nk > 0) issue(kt_begin, 0);
     if (nk > 1) issue(kt_begin + 1, 1);
+    MOCA_STAMP(1);
     if (nk > 0) {
         wait_tile(nk > 1);
+        MOCA_STAMP(2);
 #pragma unroll
         for (int r = 0; r < NRD; ++r) read_one(smem, 0, r, af0, bf0);
     }
@@ -654,6 +696,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     int i = 0;
     for (; i + 2 < nk; ++i) step(yes_t{}, i, true);        // steady state: branch-free DMA issue
     for (; i < nk; ++i) step(no_t{}, i, i + 1 < nk);       // last two tiles: nothing left to prefetch
+    MOCA_STAMP(3);
     __syncthreads();   // all fragment reads done before the ring is reused by the epilogue
 
     // The MFMAs above compute the TRANSPOSED tile (W fragment as A operand), so accumulator element r
@@ -731,9 +774,11 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const int row = wave_m * 64 + mt * 16 + fr;
+                    const f32x4 va = acc[mt][nt] + bv, ga = acc[mt][nt + 2] + bg;
+                    const f32x2 lo = moca_geglu2(f32x2{va[0], va[1]}, f32x2{ga[0], ga[1]});
+                    const f32x2 hi = moca_geglu2(f32x2{va[2], va[3]}, f32x2{ga[2], ga[3]});
                     half4v h;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h[r] = (half_t)((acc[mt][nt][r] + bv[r]) * moca_gelu(acc[mt][nt + 2][r] + bg[r]));
+                    h[0] = (half_t)lo[0]; h[1] = (half_t)lo[1]; h[2] = (half_t)hi[0]; h[3] = (half_t)hi[1];
                     *reinterpret_cast<half4v*>(smem + row * pitch + (wave_n * 32 + nt * 16 + 4 * fg) * 2) = h;
                 }
             }
@@ -755,6 +800,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
         }
     }
     __syncthreads();
+    MOCA_STAMP(4);
 
     const int chunks_per_row = out_bn / 8;
     const int total_chunks = TM * chunks_per_row;
@@ -783,7 +829,26 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
         }
         *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
     }
+    MOCA_STAMP(5);
+#ifdef MOCA_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_stamps[blockIdx.x * STAMP_SLOTS + 6] = hw;
+        g_stamps[blockIdx.x * STAMP_SLOTS + 7] = xcc;
+    }
+#endif
 }
+
+#ifdef MOCA_STAMPS
+}  // namespace
+extern "C" int moca_debug_stamps(unsigned long long* host_out, int n_blocks) {
+    if (n_blocks > STAMP_BLOCKS) n_blocks = STAMP_BLOCKS;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)n_blocks * STAMP_SLOTS * 8) == hipSuccess ? 0 : -2;
+}
+namespace {
+#endif
 
 template <int BN, int AMODE, bool FAST>
 int launch_gemm_glds(const moca_gemm_params& p, hipStream_t st) {

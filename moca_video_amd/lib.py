@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmoca_hip.so")
+# MOCA_HIP_LIB: diagnostic builds only (e.g. the -DMOCA_STAMPS library used by tools/stamps.py)
+LIB_PATH = os.environ.get("MOCA_HIP_LIB") or os.path.join(_HERE, "libmoca_hip.so")
 
 MOCA_A_LINEAR, MOCA_A_CONV3X3, MOCA_A_TCONV3 = 0, 1, 2
 MOCA_EP_GEGLU, MOCA_EP_OUT_F32 = 1, 2

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Per-category summary of a rocprofv3 --kernel-trace --stats CSV of bench.py (forwards = warmup + steps)."""
+import csv, glob, sys
+f = sys.argv[1]
+nfwd = float(sys.argv[2]) if len(sys.argv) > 2 else 6
+rows = list(csv.DictReader(open(f)))
+grp, cnt = {}, {}
+for r in rows:
+    n = r['Name']
+    if any(x in n for x in ('distribution_elementwise', 'rocclr', 'FillFunctor', 'direct_copy', 'float16_copy', 'CatArray', 'index_', 'arange', 'gather_kernel', 'reduce_kernel', 'AbsFunctor', 'CompareEq', 'MulFunctor', 'CUDAFunctorOnSelf')):
+        k = 'torch(init/host glue)'
+    elif 'gemm_glds' in n: k = 'gemm_glds'
+    elif 'gemm_f16' in n: k = 'gemm_small'
+    elif 'splitk' in n: k = 'splitk_reduce'
+    elif 'temporal_attention' in n: k = 'temporal_attn'
+    elif 'attention_kernel' in n: k = 'attention'
+    elif 'gn_partial' in n: k = 'gn_partial'
+    elif 'gn_apply' in n: k = 'gn_apply'
+    elif 'gn_final' in n: k = 'gn_finalize'
+    elif 'layernorm' in n: k = 'layernorm'
+    else: k = 'other moca kernels'
+    grp[k] = grp.get(k, 0) + float(r['TotalDurationNs']); cnt[k] = cnt.get(k, 0) + int(r['Calls'])
+tot = sum(v for k, v in grp.items() if not k.startswith('torch'))
+print(f"moca kernel time per forward: {tot/nfwd/1e6:.2f} ms")
+for k, v in sorted(grp.items(), key=lambda x: -x[1]):
+    print(f"{k:24s} {v/nfwd/1e6:7.2f} ms/fwd {100*v/tot:5.1f}%  launches/fwd {cnt[k]/nfwd:.0f}")
