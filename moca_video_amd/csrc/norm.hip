@@ -7,26 +7,13 @@ namespace {
 
 constexpr int GN_GROUPS = 32;
 
-// pixel chunks per frame of the statistics pass: enough blocks to fill the chip, but at most 128 partial
-// entries per statistics group (frames_per_stat * nchunk) so that every apply block can finalize its own
-// mean / rstd from them (no separate finalize launch)
-__host__ __device__ inline int gn_nchunk(int F, int HW, int frames_per_stat) {
+__host__ __device__ inline int gn_nchunk(int F, int HW) {
     int n = 2048 / (F > 0 ? F : 1);
     if (n < 1) n = 1;
-    const int cap = 128 / frames_per_stat > 0 ? 128 / frames_per_stat : 1;
-    if (n > cap) n = cap;
     const int maxc = (HW + 7) / 8;
     if (n > maxc) n = maxc;
     if (n < 1) n = 1;
     return n;
-}
-// pixel chunks per frame of the apply pass (independent of the statistics pass)
-__host__ __device__ inline int gn_apply_chunks(int F, int HW) {
-    int n = 2048 / (F > 0 ? F : 1);
-    if (n < 1) n = 1;
-    const int maxc = (HW + 7) / 8;
-    if (n > maxc) n = maxc;
-    return n < 1 ? 1 : n;
 }
 
 // ---- K1: per (frame, pixel-chunk) partial sums per group ---------------------
@@ -63,51 +50,50 @@ __global__ void gn_partial_kernel(const half_t* __restrict__ x, float* __restric
     }
 }
 
-// ---- K2: apply (x - mean) * rstd * gamma + beta, optional SiLU ------------------------
-// Every block first finalizes the 32 (mean, rstd) pairs of its statistics group from the <= 128 partial
-// entries (fp64, fixed order: deterministic), then streams its pixel chunk.
+// ---- K2: finalize mean / rstd per (stat group, channel group) in fp64 --------
+// one wavefront per (stat group, channel group): grid (stat groups, 32)
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ meanrstd,
+                                                         int frames_per_stat, int nchunk, double inv_count, float eps) {
+    const int sg = blockIdx.x, g = blockIdx.y, l = threadIdx.x;
+    const int n = frames_per_stat * nchunk;
+    const float* base = partial + (int64_t)sg * n * GN_GROUPS * 2;
+    double a = 0.0, b = 0.0;
+    for (int i = l; i < n; i += 64) {
+        const float2 v = *reinterpret_cast<const float2*>(base + ((int64_t)i * GN_GROUPS + g) * 2);
+        a += (double)v.x;
+        b += (double)v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (l == 0) {
+        const double mean = a * inv_count;
+        double var = b * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        meanrstd[((int64_t)sg * GN_GROUPS + g) * 2] = (float)mean;
+        meanrstd[((int64_t)sg * GN_GROUPS + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// ---- K3: apply (x - mean) * rstd * gamma + beta, optional SiLU ----------------
 __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                const float* __restrict__ partial, int HW, int C, int nchunk_apply,
-                                int frames_per_stat, int n_entries, double inv_count, float eps, int silu) {
-    __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
+                                const float* __restrict__ meanrstd, int HW, int C, int nchunk,
+                                int frames_per_stat, int silu) {
     const int f = blockIdx.x, chunk = blockIdx.y;
     const int cx = threadIdx.x, py = threadIdx.y, ppb = blockDim.y;
-    const int tid = py * blockDim.x + cx, nthreads = blockDim.x * blockDim.y;
-    const int sg = f / frames_per_stat;
-    {
-        const float* base = partial + (int64_t)sg * n_entries * GN_GROUPS * 2;
-        // thread (g, l): 8 lanes per channel group (the first 256 threads; blockDim >= 256 is not guaranteed)
-        const int lanes = nthreads >= 256 ? 8 : (nthreads >= 64 ? 2 : 1);
-        if (tid < GN_GROUPS * lanes) {
-            const int g = tid / lanes, l = tid - g * lanes;
-            double a = 0.0, b = 0.0;
-            for (int i = l; i < n_entries; i += lanes) {
-                const float2 v = *reinterpret_cast<const float2*>(base + ((int64_t)i * GN_GROUPS + g) * 2);
-                a += (double)v.x;
-                b += (double)v.y;
-            }
-            for (int o = lanes >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-            if (l == 0) {
-                const double mean = a * inv_count;
-                double var = b * inv_count - mean * mean;
-                if (var < 0.0) var = 0.0;
-                s_mean[g] = (float)mean;
-                s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
-            }
-        }
-    }
-    __syncthreads();
-    const int pc = (HW + nchunk_apply - 1) / nchunk_apply;
+    const int pc = (HW + nchunk - 1) / nchunk;
     const int p_begin = chunk * pc, p_end = min(p_begin + pc, HW);
     const int cpg = C / GN_GROUPS;
+    const int sg = f / frames_per_stat;
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = cx * 8 + j;
         const int g = c / cpg;
-        sc[j] = s_rstd[g] * gamma[c];
-        sh[j] = beta[c] - s_mean[g] * sc[j];
+        const float mean = meanrstd[((int64_t)sg * GN_GROUPS + g) * 2];
+        const float rstd = meanrstd[((int64_t)sg * GN_GROUPS + g) * 2 + 1];
+        sc[j] = rstd * gamma[c];
+        sh[j] = beta[c] - mean * sc[j];
     }
     const int64_t off = ((int64_t)f * HW) * C + cx * 8;
     for (int p = p_begin + py; p < p_end; p += ppb) {
@@ -179,8 +165,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 
 extern "C" int64_t moca_groupnorm_ws_bytes(int32_t F, int32_t HW, int32_t C) {
     (void)C;
-    const int nchunk = gn_nchunk(F, HW, 1);     // largest case (per-frame statistics)
-    return (int64_t)F * nchunk * GN_GROUPS * 2 * 4;
+    const int nchunk = gn_nchunk(F, HW);
+    return ((int64_t)F * nchunk * GN_GROUPS * 2 + (int64_t)F * GN_GROUPS * 2) * 4;
 }
 
 extern "C" int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma, const float* beta,
@@ -192,18 +178,20 @@ extern "C" int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamm
     if (nch8 > 1024) return MOCA_E_BADARG;
     int ppb = 256 / nch8;
     if (ppb < 1) ppb = 1;
-    const int nchunk = gn_nchunk(F, HW, frames_per_stat);
-    const int nchunk_apply = gn_apply_chunks(F, HW);
+    const int nchunk = gn_nchunk(F, HW);
     float* partial = ws;
+    float* meanrstd = ws + (int64_t)F * nchunk * GN_GROUPS * 2;
     hipStream_t st = moca_stream(stream);
-    const dim3 block(nch8, ppb);
+    const dim3 grid(F, nchunk), block(nch8, ppb);
     const size_t lds = (size_t)ppb * C * 2 * sizeof(float);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(F, nchunk), block, lds, st, reinterpret_cast<const half_t*>(x), partial, HW, C, nchunk);
+    hipLaunchKernelGGL(gn_partial_kernel, grid, block, lds, st, reinterpret_cast<const half_t*>(x), partial, HW, C, nchunk);
     MOCA_CHECK_LAUNCH();
     const double inv_count = 1.0 / ((double)frames_per_stat * HW * (C / GN_GROUPS));
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(F, nchunk_apply), block, 0, st, reinterpret_cast<const half_t*>(x),
-                       reinterpret_cast<half_t*>(y), gamma, beta, partial, HW, C, nchunk_apply, frames_per_stat,
-                       frames_per_stat * nchunk, inv_count, eps, silu);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(F / frames_per_stat, GN_GROUPS), dim3(64), 0, st, partial, meanrstd,
+                       frames_per_stat, nchunk, inv_count, eps);
+    MOCA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, reinterpret_cast<const half_t*>(x), reinterpret_cast<half_t*>(y),
+                       gamma, beta, meanrstd, HW, C, nchunk, frames_per_stat, silu);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
