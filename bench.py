@@ -31,6 +31,10 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_UNET_STEP = 12.581e12      # FlopCounterMode on the reference UNet, [1,4,16,40,64], L=77
 PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
+# L2<->fabric bytes of one batched (B=2) UNet forward launch, from separate rocprofv3 --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE passes over this same command (profiles/r01_pmc_traffic_per_forward.txt; FETCH_SIZE doubled
+# per the gfx950 correction in MI355X_MICROARCH.md; Infinity-Cache hits are included in these counters)
+TRAFFIC_BYTES_PER_LAUNCH = 118.4e9
 
 FULL = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
             channel_mult=[1, 2, 4, 4], num_head_channels=64, transformer_depth=1, context_dim=1024, use_linear=True,
@@ -103,6 +107,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fifo", action="store_true", help="skip the extra batched-FIFO-iteration measurement")
+    ap.add_argument("--cfg-mode", default="batched", choices=["batched", "concurrent"],
+                    help="cond+uncond as one B=2 launch, or as two concurrent B=1 hipGraphs on two streams")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--height", type=int, default=40)
@@ -125,6 +131,7 @@ def main():
         nbytes = mdist.broadcast_parameters(dm.model.diffusion_model, src=0)     # C1 (RCCL over xGMI)
     unet = dm.model.diffusion_model
     sampler = DDIMSampler(dm)
+    sampler.cfg_mode = args.cfg_mode
     S = 50
     sampler.make_schedule(S, ddim_eta=1.0, verbose=False)
 
@@ -148,23 +155,27 @@ def main():
     for i in range(max(args.warmup, 2)):       # >= 2: eager pass + hipGraph capture pass
         img = ddim_step(i, img)
     torch.cuda.synchronize()
-    plan = next(iter(unet._plans.values()))
-    graph_on = plan.graph is not None
+    plans = list(unet._plans.values())
+    graph_on = all(pl.graph is not None for pl in plans)
 
-    # HIP events on the stream the UNet graph is launched on (torch.cuda.Event would only see
-    # torch's current stream): brackets each UNet graph launch inside the timed region.
+    # HIP events on the stream(s) the UNet graphs are launched on (torch.cuda.Event would only see
+    # torch's current stream): bracket every UNet graph launch inside the timed region.
     ev = []
-    handle = C.c_void_p(plan.stream.cuda_stream)
-    orig_launch = plan._launch
 
-    def timed_launch(h):
-        a, b = C.c_void_p(), C.c_void_p()
-        lib.moca_event_create(C.byref(a)); lib.moca_event_create(C.byref(b))
-        lib.moca_event_record(a, handle)
-        orig_launch(h)
-        lib.moca_event_record(b, handle)
-        ev.append((a, b))
-    plan._launch = timed_launch
+    def hook(pl):
+        handle = C.c_void_p(pl.stream.cuda_stream)
+        orig = pl._launch
+
+        def timed_launch(h):
+            a, b = C.c_void_p(), C.c_void_p()
+            lib.moca_event_create(C.byref(a)); lib.moca_event_create(C.byref(b))
+            lib.moca_event_record(a, handle)
+            orig(h)
+            lib.moca_event_record(b, handle)
+            ev.append((a, b))
+        pl._launch = timed_launch
+        return orig
+    originals = [hook(pl) for pl in plans]
 
     mdist.barrier()
     torch.cuda.synchronize()
@@ -176,7 +187,8 @@ def main():
     mdist.barrier()
     dt = time.perf_counter() - t0
     dt = mdist.max_over_ranks(dt, device)
-    plan._launch = orig_launch
+    for pl, orig in zip(plans, originals):
+        pl._launch = orig
 
     unet_ms = []
     for a, b in ev:
@@ -191,9 +203,17 @@ def main():
         return
     unet_steps = 2 * args.steps * world
     value = unet_steps / dt
+    concurrent = args.cfg_mode == "concurrent"
     avg_launch_ms = sum(unet_ms) / max(len(unet_ms), 1)
-    flop_per_launch = 2 * FLOP_PER_UNET_STEP * (T * H * W) / (16 * 40 * 64)   # one launch = batched cond+uncond forward
-    achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+    flop_unit = FLOP_PER_UNET_STEP * (T * H * W) / (16 * 40 * 64)
+    if concurrent:
+        # two B=1 graphs run overlapped on two streams: a launch's own span includes time it shares with the
+        # other chain, so the rate is taken over both launches of a step: 2 units / mean(span of the pair)
+        flop_per_launch = flop_unit
+        achieved = 2 * flop_unit / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+    else:
+        flop_per_launch = 2 * flop_unit            # one launch = batched cond+uncond forward
+        achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
     name, cus = mlib.device_info()
     res = {
         "metric": "denoising UNet-steps/sec @16x320x512 fp16",
@@ -212,12 +232,12 @@ def main():
                                "per GPU; step = 1 DDIM step = 2 UNet-steps (batched cond+uncond) + CFG + DDIM update" % (T, H, W),
                    "unet_steps_per_step": 2, "context_tokens": 77, "weights": "random-init, 1.41B params, fp16 packed",
                    "parallelism": f"dp{world} (independent prompts, no collective in the loop)",
-                   "hipgraph_replay": graph_on, "device": name, "compute_units": cus, "output_finite": finite},
+                   "hipgraph_replay": graph_on, "cfg_mode": args.cfg_mode, "device": name, "compute_units": cus, "output_finite": finite},
         "achieved_tflops": round(value / world * FLOP_PER_UNET_STEP / 1e12, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
-                     "kernel": "UNet forward launch sequence (hipGraph of ~1.1k launches; gemm_f16_kernel = implicit-GEMM "
-                               "conv/linear dominates), batch 2",
+                     "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH if not concurrent else None,
+                     "kernel": "UNet forward launch sequence (hipGraph of ~1.0k launches; gemm_glds_kernel = implicit-GEMM "
+                               "conv/linear is 72% of it)" + (", two B=1 graphs on two streams" if concurrent else ", batch 2"),
                      "flop_per_launch": flop_per_launch, "avg_launch_ms": round(avg_launch_ms, 3), "launches": len(unet_ms)},
     }
     if world == 1 and not args.no_fifo:

@@ -289,8 +289,8 @@ class _Plan:
         for s in self.steps:
             s()
 
-    def run(self, x, t_rows, fps_rows, context):
-        cur = torch.cuda.current_stream(self.device)
+    def launch_async(self, x, t_rows, fps_rows, context, cur):
+        """enqueue one forward on this plan's stream (ordered after `cur`); the caller joins"""
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             self.x_in.copy_(x, non_blocking=True)
@@ -304,9 +304,14 @@ class _Plan:
             finally:
                 ops.set_stream(None)
             out = self.out.clone()
+        self.n_runs += 1
+        return out
+
+    def run(self, x, t_rows, fps_rows, context):
+        cur = torch.cuda.current_stream(self.device)
+        out = self.launch_async(x, t_rows, fps_rows, context, cur)
         out.record_stream(cur)
         cur.wait_stream(self.stream)
-        self.n_runs += 1
         return out
 
     def _launch(self, handle):

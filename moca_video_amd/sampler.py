@@ -64,6 +64,8 @@ class DDIMSampler(object):
         self.counter = 0
         self.use_self_attention = use_self_attention
         self.reference_index_quirk = True    # see ddim_step
+        self.cfg_mode = "batched"            # "batched": cond+uncond as one B=2 launch; "concurrent": two B=1
+                                             # hipGraphs on two streams (UNetModel.forward_concurrent)
         self.beta = 0.9                      # momentum decay (ddim.py:397)
 
     # ---- schedule (host) ---------------------------------------------------------------
@@ -91,7 +93,12 @@ class DDIMSampler(object):
             cc = torch.cat(c["c_crossattn"], 1)
             cu = torch.cat(uc["c_crossattn"], 1)
             batched = cc.shape == cu.shape and set(c.keys()) == set(uc.keys()) <= {"c_crossattn", "fps"}
-        if batched:
+        unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+        if batched and self.cfg_mode == "concurrent" and hasattr(unet, "forward_concurrent") and not kwargs.get("no_concurrent"):
+            f_c, f_u = c.get("fps", 16), uc.get("fps", 16)
+            e_c, e_u = unet.forward_concurrent([dict(x=x, timesteps=t, context=cc, fps=f_c),
+                                                dict(x=x, timesteps=t, context=cu, fps=f_u)])
+        elif batched:
             B = x.shape[0]
             cond = {"c_crossattn": [torch.cat([cc, cu], 0)]}
             if "fps" in c:

@@ -374,11 +374,8 @@ class UNetModel(nn.Module):
         self._packed = P
 
     # ---- forward -----------------------------------------------------------------------
-    @torch.no_grad()
-    def forward(self, x, timesteps, context=None, features_adapter=None, fps=16, **kwargs):
-        """openaimodel3d.py:534-578.  x [B,C,T,h,w]; timesteps int64 [B] (or [T] with B == 1: the
-        FIFO per-frame-timestep path, :535; or [B*T] per-(b,t), an extension); context [B,L,ctx];
-        fps int or [B]; unknown kwargs (clean_cond, gamma, ...) are ignored exactly as upstream."""
+    def _prepare(self, x, timesteps, context, features_adapter, fps):
+        """argument checks + per-(b,t) timestep / fps rows shared by forward() and forward_concurrent()"""
         if features_adapter is not None:
             raise NotImplementedError("features_adapter is always None on the MoCA path")
         if context is None:
@@ -415,13 +412,41 @@ class UNetModel(nn.Module):
                 raise ValueError("fps must be an int or a tensor of B entries")
         if context.shape[0] != B:
             raise ValueError("context batch must equal x batch")
-        L = context.shape[1]
-        key = (B, T, H, W, L, x.dtype, x.device.index)
+        return t_rows, fps_rows
+
+    def _plan_for(self, x, L, replica=0):
+        B, _, T, H, W = x.shape
+        key = (B, T, H, W, L, x.dtype, x.device.index, replica)
         plan = self._plans.get(key)
         if plan is None:
             plan = _Plan(self, B, T, H, W, L, x.dtype, x.device)
             self._plans[key] = plan
-        return plan.run(x, t_rows, fps_rows, context)
+        return plan
+
+    @torch.no_grad()
+    def forward(self, x, timesteps, context=None, features_adapter=None, fps=16, **kwargs):
+        """openaimodel3d.py:534-578.  x [B,C,T,h,w]; timesteps int64 [B] (or [T] with B == 1: the
+        FIFO per-frame-timestep path, :535; or [B*T] per-(b,t), an extension); context [B,L,ctx];
+        fps int or [B]; unknown kwargs (clean_cond, gamma, ...) are ignored exactly as upstream."""
+        t_rows, fps_rows = self._prepare(x, timesteps, context, features_adapter, fps)
+        return self._plan_for(x, context.shape[1]).run(x, t_rows, fps_rows, context)
+
+    @torch.no_grad()
+    def forward_concurrent(self, calls):
+        """Several independent forwards (e.g. the conditional and unconditional CFG branch) launched as
+        separate hipGraphs on separate streams so the GPU overlaps them: one chain's partial last round of
+        tiles, kernel prologues/epilogues and launch gaps are filled by the other chain's kernels.
+        calls: list of dicts(x, timesteps, context, fps).  Returns the list of outputs (same values as forward)."""
+        prepared = []
+        for i, c in enumerate(calls):
+            t_rows, fps_rows = self._prepare(c["x"], c["timesteps"], c["context"], None, c.get("fps", 16))
+            prepared.append((self._plan_for(c["x"], c["context"].shape[1], replica=i), c["x"], t_rows, fps_rows, c["context"]))
+        cur = torch.cuda.current_stream(prepared[0][1].device)
+        outs = [pl.launch_async(x, t, f, ctx, cur) for pl, x, t, f, ctx in prepared]
+        for (pl, *_), o in zip(prepared, outs):
+            cur.wait_stream(pl.stream)
+            o.record_stream(cur)
+        return outs
 
 
 from .plan import _Plan  # noqa: E402  (split for readability; needs the classes above)

@@ -111,3 +111,19 @@ def test_fifo_batched_windows_equal_sequential():
     for a, b in zip(outs[0][1], outs[1][1]):
         assert relerr(b, a) < 5e-3
     assert not torch.equal(outs[0][0], q0)
+
+
+def test_forward_concurrent_equals_forward(reduced_model):
+    """two forwards launched as separate hipGraphs on separate streams return what forward() returns"""
+    g = golden("unet_reduced")
+    x = inp("reduced.uniform.x", (1, 4, 8, 16, 16)).cuda()
+    c1 = inp("reduced.uniform.ctx", (1, 77, 128)).cuda()
+    c2 = inp("fresh.ctx2", (1, 77, 128)).cuda()
+    t = torch.from_numpy(g["uniform__t"]).cuda()
+    ref1 = reduced_model(x, t, context=c1, fps=16)
+    ref2 = reduced_model(x, t, context=c2, fps=16)
+    for _ in range(3):   # eager, capture, replay of the two replica plans
+        o1, o2 = reduced_model.forward_concurrent([dict(x=x, timesteps=t, context=c1, fps=16),
+                                                   dict(x=x, timesteps=t, context=c2, fps=16)])
+        assert torch.equal(o1, ref1) and torch.equal(o2, ref2)
+    assert relerr(o1.cpu(), torch.from_numpy(g["uniform"])) < TOL_UNET
