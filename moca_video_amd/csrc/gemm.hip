@@ -16,6 +16,7 @@
 // fp32 LDS tile so that bias / time-embedding / residual are applied in fp32 and the
 // result leaves as full 16-byte coalesced stores.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -850,6 +851,355 @@ extern "C" int moca_debug_stamps(unsigned long long* host_out, int n_blocks) {
 namespace {
 #endif
 
+
+// =====================================================================================
+// "g4" kernel: 256 x 128 x 32 block tile, 256 threads = 4 wavefronts (2 x 2), wave tile 128 x 64 as 8 x 4
+// v_mfma_f32_16x16x32_f16 accumulators, 3-slot direct-to-LDS ring of 24 KiB k-tiles = 72 KiB per block, so
+// TWO blocks are resident per CU (8 waves, 2 per SIMD, <= 256 VGPRs each).  The two blocks run different
+// tiles out of phase: one block's prologue (first-DMA latency), barriers and epilogue (bias/GEGLU/stores)
+// sit under the other block's MFMAs -- the structural stall of the 8-wave kernel above, where the single
+// resident block leaves the matrix pipe idle in those phases (s_memtime stamps: main loop only 35-42 % of a
+// K = 320 tile).  One 32-deep k-tile = one MFMA k-step: per tile 32 MFMAs, 12 fragment ds_read_b128 and 6 DMA
+// pieces per wave, one s_barrier; fragments are double-buffered in registers, the DMA runs three tiles ahead.
+// LDS rows are 64 B; chunk swizzle phys = chunk ^ f((row>>2)&3), f = {0,2,3,1} (conflict-free for the four
+// 16-lane groups of ds_read_b128 on the 16x16x32 operand map; derivation in DESIGN.md).
+// =====================================================================================
+template <int AMODE, bool FAST>
+__global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params p) {
+    constexpr int TM = 256, BN = 128, KS = 32;
+    constexpr int RB = KS * 2;                         // 64-byte LDS rows
+    constexpr int MT = 8, NT = 4;
+    constexpr int A_BYTES = TM * RB;                   // 16 KiB
+    constexpr int B_BYTES = BN * RB;                   // 8 KiB
+    constexpr int STAGE = A_BYTES + B_BYTES;           // 24 KiB
+    constexpr int NMMA = MT * NT, NRD = MT + NT;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    const int tiles_m = (p.M + TM - 1) / TM;
+    const int tiles_n = p.N / BN;
+    const int nblk = tiles_m * tiles_n * p.splits;
+    int logical;
+    remap_block<BN>(nblk, logical);
+    const int split = logical % p.splits;
+    const int tile = logical / p.splits;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int m0 = tile_m * TM, n0 = tile_n * BN;
+
+    const int nk_total = p.ldw / KS;                   // ldw % 64 == 0 -> even
+    const int kts = (nk_total + p.splits - 1) / p.splits;
+    const int kt_begin = split * kts;
+    const int nk = min(kt_begin + kts, nk_total) - kt_begin;
+
+    const half_t* __restrict__ Aptr = reinterpret_cast<const half_t*>(p.a);
+    const half_t* __restrict__ Wptr = reinterpret_cast<const half_t*>(p.w);
+    const half_t* zero = g_zero_page;
+
+    // DMA piece = 1 KiB = 16 rows x 64 B: lane -> row (lane>>2), physical chunk lane&3; A piece g of this
+    // wave covers rows (g*4 + wave)*16 .. +15 (g = 0..3), W piece g rows (g*4 + wave)*16 .. (g = 0..1)
+    const int lrow = lane >> 2, pch = lane & 3;
+    const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);     // logical chunk fetched into this lane's slot
+    int64_t row_off[4];
+    int row_y[4], row_x[4];
+    bool row_ok[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int m = m0 + (g * 4 + wave) * 16 + lrow;
+        row_ok[g] = m < p.M;
+        const int mm = row_ok[g] ? m : 0;
+        if (AMODE == MOCA_A_LINEAR) {
+            row_off[g] = (int64_t)mm * p.lda;
+            row_y[g] = row_x[g] = 0;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int ohw = p.outH * p.outW;
+            int f, rem, oy, ox;
+            if (p.M < (1 << 24)) {
+                divmod24(mm, ohw, 1.0f / (float)ohw, f, rem);
+                divmod24(rem, p.outW, 1.0f / (float)p.outW, oy, ox);
+            } else {
+                f = mm / ohw; rem = mm - f * ohw;
+                oy = rem / p.outW; ox = rem - oy * p.outW;
+            }
+            row_off[g] = (int64_t)f * p.inH * p.inW;
+            row_y[g] = oy * p.stride - 1;
+            row_x[g] = ox * p.stride - 1;
+        } else {
+            int frame, pix, vid, t;
+            if (p.M < (1 << 24)) {
+                divmod24(mm, p.HW, 1.0f / (float)p.HW, frame, pix);
+                divmod24(frame, p.T, 1.0f / (float)p.T, vid, t);
+            } else {
+                frame = mm / p.HW; t = frame % p.T;
+            }
+            row_off[g] = mm;
+            row_y[g] = t;
+            row_x[g] = 0;
+        }
+    }
+    const half_t* w_row[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int n = n0 + (g * 4 + wave) * 16 + lrow;
+        w_row[g] = Wptr + (int64_t)n * p.ldw + lch * 8;
+    }
+
+    constexpr bool fast = FAST;      // host checks: LINEAR K % 64 == 0, CONV/TCONV C % 64 == 0 (both <= 8192)
+    const int tiles_per_tap = (AMODE == MOCA_A_LINEAR || !fast) ? (1 << 30) : p.C / KS;
+    const half_t* a_base[4];
+    int tap_cur = -1;
+    auto set_tap = [&](int tap) {
+        tap_cur = tap;
+        if (AMODE == MOCA_A_LINEAR) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a_base[g] = row_ok[g] ? Aptr + row_off[g] + lch * 8 : zero;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int iy = row_y[g] + ky, ix = row_x[g] + kx;
+                const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+                if (p.up) { iy >>= 1; ix >>= 1; }
+                const half_t* src = Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + lch * 8;
+                a_base[g] = ok ? src : zero;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int tt = row_y[g] + tap - 1;
+                const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
+                const half_t* src = Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + lch * 8;
+                a_base[g] = ok ? src : zero;
+            }
+        }
+    };
+    int a_koff = 0;
+    auto begin_tile = [&](int kt) {
+        if constexpr (fast) {
+            const int tap = kt / tiles_per_tap;
+            if (tap != tap_cur) set_tap(tap);
+            a_koff = (kt - tap * tiles_per_tap) * KS;
+        }
+    };
+    auto slow_src = [&](int kt, int g) -> const half_t* {
+        const int k = kt * KS + lch * 8;
+        if (AMODE == MOCA_A_LINEAR) {
+            return (k < p.K && row_ok[g]) ? Aptr + row_off[g] + k : zero;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int tap = k / p.C, c = k - tap * p.C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
+            int iy = row_y[g] + ky, ix = row_x[g] + kx;
+            const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+            if (p.up) { iy >>= 1; ix >>= 1; }
+            return ok ? Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + c : zero;
+        } else {
+            const int tap = k / p.C, c = k - tap * p.C;
+            const int tt = row_y[g] + tap - 1;
+            const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
+            return ok ? Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + c : zero;
+        }
+    };
+    // DMA piece j (0..3: A, 4..5: W) of tile kt into ring slot `slot`
+    auto dma_piece = [&](int kt, int slot, int j) {
+        const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
+        if (j < 4) {
+            const half_t* src;
+            if constexpr (fast) src = a_base[j] + a_koff;
+            else src = slow_src(kt, j);
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (j * 4 + wave) * 1024, 16, 0, 0);
+        } else {
+            const int g = j - 4;
+            __builtin_amdgcn_global_load_lds((glb_ptr)(w_row[g] + kt * KS), sa + A_BYTES + (g * 4 + wave) * 1024, 16, 0, 0);
+        }
+    };
+    auto issue = [&](int kt, int slot) {
+        begin_tile(kt);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dma_piece(kt, slot, j);
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    // fragment byte offsets inside a slot (row base + swizzled chunk): constant per lane
+    int a_off[MT], b_off[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = wave_m * 128 + mt * 16 + fr;
+        a_off[mt] = row * RB + ((fg ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 4);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int row = wave_n * 64 + nt * 16 + fr;
+        b_off[nt] = A_BYTES + row * RB + ((fg ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 4);
+    }
+
+    // ONE fragment set: the LDS-read latency at the head of a phase is covered by the co-resident block's
+    // wave on the same SIMD (the two blocks of a CU run out of phase), not by a second register set --
+    // 128 accumulator + 48 fragment registers leave room for two blocks per CU.
+    half8v af[MT], bf[NT];
+    // n_after = DMA groups allowed to stay in flight (each 6 instructions of this wave)
+    auto sync = [&](int n_after) {
+        if (n_after >= 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    int s0 = 0, s1 = 1, s2 = 2;                 // ring slots of tiles i, i+1, i+2 (rotating registers, no modulo)
+    // phase i: read tile i's fragments, 32 MFMAs with the 6 DMA pieces of tile i+2 in the gaps (its slot held
+    // tile i-1, whose reads every wave finished before the barrier that ended phase i-1)
+    auto phase = [&](auto issue_tag, int i) {
+        constexpr bool do_issue = decltype(issue_tag)::value;
+        const char* cur = smem + s0 * STAGE;
+        const int kt2 = kt_begin + i + 2;
+        if constexpr (do_issue) begin_tile(kt2);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const half8v*>(cur + a_off[mt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const half8v*>(cur + b_off[nt]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < NMMA; ++j) {
+            const int mt = j / NT, nt = j % NT;
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);   // D^T: lane = row m
+            if constexpr (do_issue) {
+                if ((j & 3) == 3 && (j >> 2) < 6) {
+                    dma_piece(kt2, s2, j >> 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        { const int t = s0; s0 = s1; s1 = s2; s2 = t; }
+    };
+
+    // ---- prologue: two tiles in flight ----
+    if (nk > 0) issue(kt_begin, 0);
+    if (nk > 1) issue(kt_begin + 1, 1);
+    if (nk > 0) sync(nk > 1 ? 1 : 0);             // tile 0 landed
+    int i = 0;
+    for (; i + 2 < nk; ++i) {
+        phase(yes_t{}, i);
+        sync(1);                                   // tile i+1 landed (tile i+2 may fly); everyone has read tile i
+    }
+    for (; i < nk; ++i) {
+        phase(no_t{}, i);
+        if (i + 1 < nk) sync(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // all fragment reads done before the ring is reused by the epilogue
+
+    // ---- epilogue (same scheme as the 8-wave kernel): lane owns 4 consecutive columns of row
+    //      m = wave_m*128 + mt*16 + fr: column n = wave_n*64 + nt*16 + 4*fg + r ----
+    if (p.splits > 1) {
+        float* ws = p.splitk_ws + (int64_t)split * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = m0 + wave_m * 128 + mt * 16 + fr;
+            if (row < p.M) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = n0 + wave_n * 64 + nt * 16 + 4 * fg;
+                    *reinterpret_cast<f32x4*>(ws + (int64_t)row * p.N + col) = acc[mt][nt];
+                }
+            }
+        }
+        return;
+    }
+    const bool geglu = (p.flags & MOCA_EP_GEGLU) != 0;
+    const int out_bn = geglu ? BN / 2 : BN;
+    const int on0 = geglu ? n0 / 2 : n0;
+    const int pitch = out_bn * 2 + 16;
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    if (geglu) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int ncol = n0 + wave_n * 64 + nt * 16 + 4 * fg;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) { bv = *reinterpret_cast<const f32x4*>(p.bias + ncol); bg = *reinterpret_cast<const f32x4*>(p.bias + ncol + 32); }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = wave_m * 128 + mt * 16 + fr;
+                const f32x4 va = acc[mt][nt] + bv, ga = acc[mt][nt + 2] + bg;
+                const f32x2 lo = moca_geglu2(f32x2{va[0], va[1]}, f32x2{ga[0], ga[1]});
+                const f32x2 hi = moca_geglu2(f32x2{va[2], va[3]}, f32x2{ga[2], ga[3]});
+                half4v h;
+                h[0] = (half_t)lo[0]; h[1] = (half_t)lo[1]; h[2] = (half_t)hi[0]; h[3] = (half_t)hi[1];
+                *reinterpret_cast<half4v*>(smem + row * pitch + (wave_n * 32 + nt * 16 + 4 * fg) * 2) = h;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = wave_n * 64 + nt * 16 + 4 * fg;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = wave_m * 128 + mt * 16 + fr;
+                half4v h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[mt][nt][r] + bv[r]);
+                *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = h;
+            }
+        }
+    }
+    __syncthreads();
+    const int chunks_per_row = out_bn / 8;
+    const int total_chunks = TM * chunks_per_row;
+    for (int idx = tid; idx < total_chunks; idx += 256) {
+        const int row = idx / chunks_per_row, ch = idx - row * chunks_per_row;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        const int col = on0 + ch * 8;
+        half8v h = *reinterpret_cast<const half8v*>(smem + row * pitch + ch * 16);
+        if (rowadd || resid) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+            if (rowadd) {
+                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            }
+            if (resid) {
+                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+        }
+        *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
+    }
+}
+
+template <int AMODE, bool FAST>
+int launch_gemm_g4(const moca_gemm_params& p, hipStream_t st) {
+    const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / 128;
+    const int nblk = tiles_m * tiles_n * p.splits;
+    constexpr int lds = 3 * (256 + 128) * 64;       // 72 KiB ring; the fp16 epilogue tile (256 x 272 B) fits inside it
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g4_kernel<AMODE, FAST>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MOCA_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_g4_kernel<AMODE, FAST>), dim3(nblk), dim3(256), lds, st, p);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
 template <int BN, int AMODE, bool FAST>
 int launch_gemm_glds(const moca_gemm_params& p, hipStream_t st) {
     const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / BN;
@@ -935,7 +1285,16 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
     const bool use_big = big_bn != 0 && p.M > 128 && !(p.flags & MOCA_FORCE_SMALL_TILE);
     const bool fastp = (p.a_mode == MOCA_A_LINEAR) ? (p.K % BK == 0 && p.K <= 8192) : (p.C % BK == 0 && p.C <= 8192);
-    if (use_big && big_bn == 128) {
+    // g4 (4 waves, two blocks per CU) wins where the epilogue is VALU-heavy and K is short (GEGLU at C = 320 / 640:
+    // one block's erf-GELU epilogue runs under the other block's MFMAs, -5 % on the same device); the 8-wave kernel's
+    // deeper pipeline wins everywhere else (K >= 1280: 1137 vs 880 TFLOP/s).  MOCA_GEMM_G4=0/2 forces never/always.
+    static const int g4_mode = [] { const char* e = getenv("MOCA_GEMM_G4"); return e ? atoi(e) : 1; }();
+    const bool use_g4 = !(p.flags & MOCA_EP_OUT_F32) && (g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640));
+    if (use_big && big_bn == 128 && use_g4) {
+        if (p.a_mode == MOCA_A_LINEAR) rc = fastp ? launch_gemm_g4<MOCA_A_LINEAR, true>(p, st) : launch_gemm_g4<MOCA_A_LINEAR, false>(p, st);
+        else if (p.a_mode == MOCA_A_CONV3X3) rc = fastp ? launch_gemm_g4<MOCA_A_CONV3X3, true>(p, st) : launch_gemm_g4<MOCA_A_CONV3X3, false>(p, st);
+        else rc = fastp ? launch_gemm_g4<MOCA_A_TCONV3, true>(p, st) : launch_gemm_g4<MOCA_A_TCONV3, false>(p, st);
+    } else if (use_big && big_bn == 128) {
         if (p.a_mode == MOCA_A_LINEAR) rc = fastp ? launch_gemm_glds<128, MOCA_A_LINEAR, true>(p, st) : launch_gemm_glds<128, MOCA_A_LINEAR, false>(p, st);
         else if (p.a_mode == MOCA_A_CONV3X3) rc = fastp ? launch_gemm_glds<128, MOCA_A_CONV3X3, true>(p, st) : launch_gemm_glds<128, MOCA_A_CONV3X3, false>(p, st);
         else rc = fastp ? launch_gemm_glds<128, MOCA_A_TCONV3, true>(p, st) : launch_gemm_glds<128, MOCA_A_TCONV3, false>(p, st);
