@@ -109,6 +109,82 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
     }
 }
 
+// ---- single-launch GroupNorm for small tensors ------------------------------------
+// A statistics slab = (statistics group sg, channel group g): R = frames_per_stat*HW consecutive rows x cpg channels.
+// S blocks share one slab: each of them reduces the WHOLE slab (redundantly -- a slab is at most a few hundred KB and
+// its S blocks are placed on the same XCD, so the repeats are L2 hits) and then normalises its own 1/S of the rows.
+// No inter-block hand-off, so the three launches of the streaming path become one and x is fetched from HBM once.
+// Used when the tensor is small enough that the streaming path is bound by its launches rather than by HBM.
+template <int VEC>
+__global__ __launch_bounds__(256) void gn_slab_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int R, int C, int cpg, int S, int xcd_map, double inv_count,
+                                                      float eps, int silu) {
+    typedef _Float16 vec_t __attribute__((ext_vector_type(VEC)));
+    __shared__ float s_red[2][4];
+    __shared__ float s_sc[128], s_sh[128];               // cpg <= 128
+    const int tid = threadIdx.x, L = blockIdx.x;
+    int slab, split;
+    if (xcd_map) { const int w = L >> 3; slab = (L & 7) + 8 * (w / S); split = w % S; }   // consecutive ids go round-robin over the 8 XCDs
+    else { slab = L / S; split = L % S; }
+    const int sg = slab / GN_GROUPS, g = slab % GN_GROUPS;
+    const int vpr = cpg / VEC;                            // vectors per row
+    const int dr = 256 / vpr, dv = 256 % vpr;             // advancing a flat index by 256 = dr rows + dv vectors
+    const int64_t base = (int64_t)sg * R * C + g * cpg;
+    const half_t* xs = x + base;
+    // ---- pass 1: sum / sum of squares of the whole slab ----
+    float s = 0.f, q = 0.f;
+    {
+        int row = tid / vpr, v = tid % vpr;
+#pragma unroll 4
+        for (; row < R;) {
+            const vec_t d = *reinterpret_cast<const vec_t*>(xs + (int64_t)row * C + v * VEC);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { const float a = (float)d[j]; s += a; q += a * a; }
+            row += dr; v += dv;
+            if (v >= vpr) { v -= vpr; ++row; }
+        }
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = s; s_red[1][tid >> 6] = q; }
+    __syncthreads();
+    if (tid < cpg) {
+        const double a = (double)s_red[0][0] + (double)s_red[0][1] + (double)s_red[0][2] + (double)s_red[0][3];
+        const double b = (double)s_red[1][0] + (double)s_red[1][1] + (double)s_red[1][2] + (double)s_red[1][3];
+        const double mean = a * inv_count;
+        double var = b * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const int c = g * cpg + tid;
+        const float sc = rstd * gamma[c];
+        s_sc[tid] = sc;
+        s_sh[tid] = beta[c] - (float)mean * sc;
+    }
+    __syncthreads();
+    // ---- pass 2: normalise rows [r0, r1) of the slab ----
+    const int rps = (R + S - 1) / S;
+    const int r0 = split * rps, r1 = min(R, r0 + rps);
+    half_t* ys = y + base;
+    {
+        int row = r0 + tid / vpr, v = tid % vpr;
+#pragma unroll 2
+        for (; row < r1;) {
+            const int64_t o = (int64_t)row * C + v * VEC;
+            const vec_t d = *reinterpret_cast<const vec_t*>(xs + o);
+            vec_t r;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float a = (float)d[j] * s_sc[v * VEC + j] + s_sh[v * VEC + j];
+                if (silu) a = moca_silu(a);
+                r[j] = (half_t)a;
+            }
+            *reinterpret_cast<vec_t*>(ys + o) = r;
+            row += dr; v += dv;
+            if (v >= vpr) { v -= vpr; ++row; }
+        }
+    }
+}
+
 // ---- LayerNorm: one wavefront per row, row kept in registers -------------------
 template <int MAXCH>  // max 16-byte chunks per lane
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
@@ -182,11 +258,41 @@ extern "C" int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamm
     float* partial = ws;
     float* meanrstd = ws + (int64_t)F * nchunk * GN_GROUPS * 2;
     hipStream_t st = moca_stream(stream);
+    const double inv_count = 1.0 / ((double)frames_per_stat * HW * (C / GN_GROUPS));
+    {   // small tensors: one launch (gn_slab_kernel)
+        const char* e_slab = getenv("MOCA_GN_SLAB");     // 0: always the streaming path, 2: always the slab path (tests / A-B)
+        const int slab_mode = e_slab ? atoi(e_slab) : 1;
+        const int cpg = C / GN_GROUPS;
+        const int64_t bytes = (int64_t)F * HW * C * 2;
+        const int64_t R64 = (int64_t)frames_per_stat * HW;
+        if (slab_mode && cpg % 2 == 0 && cpg <= 128 && R64 < (1 << 24) &&
+            (slab_mode == 2 || bytes <= (8 << 20) || (frames_per_stat == 1 && HW <= 160 && bytes <= (28 << 20)))) {
+            // (measured on the bench workload, profiles/r01_plan_profile_*.txt: the slab kernel's 20..160-byte row segments
+            //  lose to the streaming path's full-row reads as soon as the tensor is more than a few MB)
+            const int R = (int)R64;
+            const int n_slabs = (F / frames_per_stat) * GN_GROUPS;
+            int S = 1024 / n_slabs;
+            if (S > 16) S = 16;
+            if (S > R) S = R;
+            if (S < 1) S = 1;
+            const int xcd_map = (n_slabs % 8 == 0) ? 1 : 0;
+            const dim3 g1(n_slabs * S), b1(256);
+            const half_t* xi = reinterpret_cast<const half_t*>(x);
+            half_t* yo = reinterpret_cast<half_t*>(y);
+            if (cpg % 8 == 0)
+                hipLaunchKernelGGL(gn_slab_kernel<8>, g1, b1, 0, st, xi, yo, gamma, beta, R, C, cpg, S, xcd_map, inv_count, eps, silu);
+            else if (cpg % 4 == 0)
+                hipLaunchKernelGGL(gn_slab_kernel<4>, g1, b1, 0, st, xi, yo, gamma, beta, R, C, cpg, S, xcd_map, inv_count, eps, silu);
+            else
+                hipLaunchKernelGGL(gn_slab_kernel<2>, g1, b1, 0, st, xi, yo, gamma, beta, R, C, cpg, S, xcd_map, inv_count, eps, silu);
+            MOCA_CHECK_LAUNCH();
+            return MOCA_OK;
+        }
+    }
     const dim3 grid(F, nchunk), block(nch8, ppb);
     const size_t lds = (size_t)ppb * C * 2 * sizeof(float);
     hipLaunchKernelGGL(gn_partial_kernel, grid, block, lds, st, reinterpret_cast<const half_t*>(x), partial, HW, C, nchunk);
     MOCA_CHECK_LAUNCH();
-    const double inv_count = 1.0 / ((double)frames_per_stat * HW * (C / GN_GROUPS));
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(F / frames_per_stat, GN_GROUPS), dim3(64), 0, st, partial, meanrstd,
                        frames_per_stat, nchunk, inv_count, eps);
     MOCA_CHECK_LAUNCH();

@@ -133,7 +133,9 @@ def test_gemm_tconv(B, T, HW, C, N):
                                                    (16, 40, 1280, 16, False, 1e-6), (2, 2560, 320, 1, False, 1e-6),
                                                    (3, 37, 64, 1, True, 1e-5), (2, 64, 2560, 1, True, 1e-5),
                                                    (8, 64, 960, 8, True, 1e-5)])
-def test_groupnorm(Fr, HW, C, fps, silu, eps):
+@pytest.mark.parametrize("path", ["0", "2"])     # MOCA_GN_SLAB: 0 = three-launch streaming path, 2 = single-launch slab path
+def test_groupnorm(Fr, HW, C, fps, silu, eps, path, monkeypatch):
+    monkeypatch.setenv("MOCA_GN_SLAB", path)
     x = (rnd(Fr, HW, C) * 1.5 + 0.7).half()
     g = rnd(C, dtype=torch.float32) * 0.2 + 1.0
     b = rnd(C, dtype=torch.float32) * 0.2

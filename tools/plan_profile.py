@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Time every recorded launch of one UNet plan (bench workload, B=2 batched CFG) in isolation with HIP events and
+print the total per (op, shape).  Each step is replayed `REP` times back to back between two events, so the figure
+is the steady-state launch-to-launch time of that step alone (no inter-kernel overlap, warm caches).
+
+    python tools/plan_profile.py [B] > gpurun_out/plan_profile.txt
+"""
+import os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from moca_video_amd import ops, lib as L
+
+REP = 5
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dm = bench.build_model(dev, seed=321)
+unet = dm.model.diffusion_model
+g = torch.Generator(device=dev).manual_seed(1)
+x = torch.randn(B, 4, 16, 40, 64, device=dev, generator=g)
+ctx = torch.randn(B, 77, 1024, device=dev, generator=g)
+ts = torch.full((B,), 500, device=dev, dtype=torch.long)
+with torch.no_grad():
+    for _ in range(2):
+        unet(x, ts, ctx, fps=torch.tensor([10] * B, device=dev))
+torch.cuda.synchronize()
+plan = next(iter(unet._plans.values())) if hasattr(unet, "_plans") else None
+assert plan is not None
+st = plan.stream
+ops.set_stream(st.cuda_stream)
+rows = collections.OrderedDict()
+tot = 0.0
+with torch.cuda.stream(st):
+    for s in plan.steps:
+        fn, kw = s.func.__name__, s.keywords
+        if fn == "gemm":
+            pw = s.args[1]
+            mode = {0: "lin", 1: "conv", 2: "tconv"}[kw.get("mode", 0)]
+            key = f"gemm {mode:5s} M={kw['M']:6d} N={pw.N:5d} K={pw.K:5d}" + (" geglu" if pw.geglu else "") + \
+                  (" +res" if kw.get("residual") is not None else "") + (" +rowadd" if kw.get("rowadd") is not None else "") + \
+                  (f" splits={kw['splits']}" if kw.get("splits", 1) > 1 else "") + (" f32" if kw.get("out_f32") else "")
+            flop = 2.0 * kw["M"] * pw.N * pw.w.shape[1]
+            if kw.get("conv") is not None and kw["conv"][6]:
+                pass
+        elif fn == "groupnorm":
+            key = f"groupnorm F={kw['F']} HW={kw['HW']} C={kw['Cn']} fps={kw['frames_per_stat']}"
+            flop = 0
+        elif fn == "layernorm":
+            key = f"layernorm M={kw['M']} C={kw['Cn']}"
+            flop = 0
+        elif fn == "attention":
+            key = f"attention Bq={kw['Bq']} h={kw['heads']} Nq={kw['Nq']} Nk={kw['Nk']}"
+            flop = 4.0 * kw["Bq"] * kw["heads"] * kw["Nq"] * kw["Nk"] * 64
+        elif fn == "temporal_attention":
+            key = f"temporal_attention B={kw['B']} T={kw['T']} HW={kw['HW']} h={kw['heads']}"
+            flop = 0
+        else:
+            key = fn
+            flop = 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s()
+        e0.record(st)
+        for _ in range(REP):
+            s()
+        e1.record(st)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / REP
+        r = rows.setdefault(key, [0, 0.0, flop])
+        r[0] += 1
+        r[1] += us
+        tot += us
+ops.set_stream(None)
+print(f"# B={B}: {len(plan.steps)} steps, sum of isolated step times {tot / 1e3:.2f} ms")
+print(f"{'total_us':>9s} {'n':>3s} {'each_us':>8s} {'TF/s':>6s}  step")
+for key, (n, us, flop) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+    tf = flop * n / us / 1e6 if flop else 0.0
+    print(f"{us:9.1f} {n:3d} {us / n:8.1f} {tf:6.0f}  {key}")
