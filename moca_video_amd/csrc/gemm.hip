@@ -1183,6 +1183,357 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     }
 }
 
+
+// =====================================================================================
+// "w80" kernel: 320 x 160 x 32 block tile, 512 threads = 8 wavefronts (4 x 2, two per SIMD), wave tile 80 x 80 as
+// 5 x 5 v_mfma_f32_16x16x32_f16 accumulators.
+//
+// Why this shape.  (1) Every layer of this UNet has M = 5 * 2^a rows and N = 5 * 2^b columns, so 320 x 160 tiles
+// give power-of-two tile counts -- whole rounds of the 256 CUs; the 256 x 128 tiling leaves 400 tiles (1.56 rounds)
+// at the 640-channel level and 640 (2.5 rounds) for the N = 320 layers.  (2) LDS traffic: a 64 x 64 wave tile needs 8
+// ds_read_b128 per 16 MFMAs, an 80 x 80 tile 10 per 25 -- 20 % fewer reads per flop out of the LDS array that the
+// ring's DMA writes also go through.  (3) tools/micro/mfma_peak.hip: back-to-back v_mfma_f32_16x16x32_f16 from ONE
+// wave per SIMD top out at 58-63 % of the matrix peak (1.44-1.58 PFLOP/s), two waves per SIMD reach 90 %; a
+// one-wave-per-SIMD variant of this kernel with 160 x 80 register tiles measured 20 % slower than the 8-wave kernel.
+// So: two waves per SIMD, <= 256 registers each (100 accumulators + 2 x 40 fragment registers).
+//
+// Pipeline: k-tiles of 32 (64-byte LDS rows, swizzle and DMA image of g4), 5-slot direct-to-LDS ring of 30 KiB tiles,
+// DMA five tiles ahead; fragments double-buffered in registers: phase i runs the 25 MFMAs of tile i from set (i & 1)
+// while the 10 ds_reads of tile i+1 fill the other set and this wave's 4 DMA instructions of tile i+5 go out,
+// hand-interleaved; one counted s_waitcnt + s_barrier per phase.  Every phase issues exactly 4 DMA instructions per
+// wave (past the end of the k range the last tile is fetched again into a slot nobody reads; the two left-over W
+// pieces are fetched twice), so one vmcnt immediate is right for every wave in every phase.
+// =====================================================================================
+template <int AMODE, bool FAST>
+__global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params p) {
+    constexpr int MT = 5, NT = 5, BN = 160, KS = 32, RB = 64;
+    constexpr int TM = 320;
+    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB;     // 20 + 10 KiB
+    constexpr int NS = 5;
+    constexpr int PPW = 4;                               // DMA instructions per wave per k-tile (30 pieces + 2 repeats)
+    constexpr int NAP = 3;                               // A piece slots per wave (the third one only for waves 0..3)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    const int tiles_m = (p.M + TM - 1) / TM;
+    const int tiles_n = p.N / BN;
+    const int nblk = tiles_m * tiles_n * p.splits;
+    int logical;
+    remap_block<BN>(nblk, logical);
+    const int split = logical % p.splits;
+    const int tile = logical / p.splits;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int m0 = tile_m * TM, n0 = tile_n * BN;
+
+    const int nk_total = p.ldw / KS;
+    const int kts = 2 * ((p.ldw / 64 + p.splits - 1) / p.splits);      // split in 64-deep units, as the host sizes it
+    const int kt_begin = split * kts;
+    const int nk = min(kt_begin + kts, nk_total) - kt_begin;
+
+    const half_t* __restrict__ Aptr = reinterpret_cast<const half_t*>(p.a);
+    const half_t* __restrict__ Wptr = reinterpret_cast<const half_t*>(p.w);
+    const half_t* zero = g_zero_page;
+
+    // DMA piece = 16 rows x 64 B: lane -> row (lane >> 2), physical chunk lane & 3.  Wave w moves
+    //   j = 0: A piece w        j = 1: A piece 8 + w
+    //   j = 2: A piece 16 + w (w < 4)  or  W piece w - 4 (w >= 4)
+    //   j = 3: W piece 4 + w (w < 6)   or  W piece 2 + w (w = 6, 7: a repeat of what waves 4, 5 fetch)
+    const int lrow = lane >> 2, pch = lane & 3;
+    const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
+    const bool flex_is_a = wave < 4;
+    int64_t row_off[NAP];
+    int row_y[NAP], row_x[NAP];
+    bool row_ok[NAP];
+#pragma unroll
+    for (int g = 0; g < NAP; ++g) {
+        const int piece = g < 2 ? g * 8 + wave : 16 + (wave & 3);
+        const int m = m0 + piece * 16 + lrow;
+        row_ok[g] = m < p.M;
+        const int mm = row_ok[g] ? m : 0;
+        if (AMODE == MOCA_A_LINEAR) {
+            row_off[g] = (int64_t)mm * p.lda;
+            row_y[g] = row_x[g] = 0;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int ohw = p.outH * p.outW;
+            int f, rem, oy, ox;
+            if (p.M < (1 << 24)) {
+                divmod24(mm, ohw, 1.0f / (float)ohw, f, rem);
+                divmod24(rem, p.outW, 1.0f / (float)p.outW, oy, ox);
+            } else {
+                f = mm / ohw; rem = mm - f * ohw;
+                oy = rem / p.outW; ox = rem - oy * p.outW;
+            }
+            row_off[g] = (int64_t)f * p.inH * p.inW;
+            row_y[g] = oy * p.stride - 1;
+            row_x[g] = ox * p.stride - 1;
+        } else {
+            int frame, pix, vid, t;
+            if (p.M < (1 << 24)) {
+                divmod24(mm, p.HW, 1.0f / (float)p.HW, frame, pix);
+                divmod24(frame, p.T, 1.0f / (float)p.T, vid, t);
+            } else {
+                frame = mm / p.HW; t = frame % p.T;
+            }
+            row_off[g] = mm;
+            row_y[g] = t;
+            row_x[g] = 0;
+        }
+    }
+    const int w_piece0 = wave & 3;                        // j = 2 (waves 4..7)
+    const int w_piece1 = wave < 6 ? 4 + wave : 2 + wave;  // j = 3
+    const half_t* w_row[2];
+    w_row[0] = Wptr + (int64_t)(n0 + w_piece0 * 16 + lrow) * p.ldw + lch * 8;
+    w_row[1] = Wptr + (int64_t)(n0 + w_piece1 * 16 + lrow) * p.ldw + lch * 8;
+
+    constexpr bool fast = FAST;
+    const int tiles_per_tap = (AMODE == MOCA_A_LINEAR || !fast) ? (1 << 30) : p.C / KS;
+    const half_t* a_base[NAP];
+    int tap_cur = -1;
+    auto set_tap = [&](int tap) {
+        tap_cur = tap;
+        if (AMODE == MOCA_A_LINEAR) {
+#pragma unroll
+            for (int g = 0; g < NAP; ++g) a_base[g] = row_ok[g] ? Aptr + row_off[g] + lch * 8 : zero;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
+#pragma unroll
+            for (int g = 0; g < NAP; ++g) {
+                int iy = row_y[g] + ky, ix = row_x[g] + kx;
+                const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+                if (p.up) { iy >>= 1; ix >>= 1; }
+                const half_t* src = Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + lch * 8;
+                a_base[g] = ok ? src : zero;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < NAP; ++g) {
+                const int tt = row_y[g] + tap - 1;
+                const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
+                const half_t* src = Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + lch * 8;
+                a_base[g] = ok ? src : zero;
+            }
+        }
+    };
+    int a_koff = 0;
+    auto begin_tile = [&](int kt) {
+        if constexpr (fast) {
+            const int tap = kt / tiles_per_tap;
+            if (tap != tap_cur) set_tap(tap);
+            a_koff = (kt - tap * tiles_per_tap) * KS;
+        }
+    };
+    auto slow_src = [&](int kt, int g) -> const half_t* {
+        const int k = kt * KS + lch * 8;
+        if (AMODE == MOCA_A_LINEAR) {
+            return (k < p.K && row_ok[g]) ? Aptr + row_off[g] + k : zero;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int tap = k / p.C, c = k - tap * p.C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
+            int iy = row_y[g] + ky, ix = row_x[g] + kx;
+            const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+            if (p.up) { iy >>= 1; ix >>= 1; }
+            return ok ? Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + c : zero;
+        } else {
+            const int tap = k / p.C, c = k - tap * p.C;
+            const int tt = row_y[g] + tap - 1;
+            const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
+            return ok ? Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + c : zero;
+        }
+    };
+    auto a_src = [&](int kt, int g) -> const half_t* {
+        if constexpr (fast) return a_base[g] + a_koff;
+        else return slow_src(kt, g);
+    };
+    // DMA instruction j (0..3) of this wave for absolute k-tile kt into ring slot `slot`
+    auto dma_piece = [&](int kt, int slot, int j) {
+        const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
+        if (j < 2) {
+            __builtin_amdgcn_global_load_lds((glb_ptr)a_src(kt, j), sa + (j * 8 + wave) * 1024, 16, 0, 0);
+        } else if (j == 2) {
+            const half_t* sA = a_src(kt, 2);
+            const half_t* sw = w_row[0] + kt * KS;
+            const half_t* src = flex_is_a ? sA : sw;
+            const lds_ptr dst = flex_is_a ? sa + (16 + (wave & 3)) * 1024 : sa + A_BYTES + w_piece0 * 1024;
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, dst, 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((glb_ptr)(w_row[1] + kt * KS), sa + A_BYTES + w_piece1 * 1024, 16, 0, 0);
+        }
+    };
+    auto issue = [&](int kt, int slot) {
+        begin_tile(kt);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) dma_piece(kt, slot, j);
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    // fragment byte offsets inside a slot; tile rows advance in steps of 16, which leaves the swizzle term unchanged
+    const int swz = (fg ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
+    const int a_off0 = (wave_m * 80 + fr) * RB + swz;
+    const int b_off0 = A_BYTES + (wave_n * 80 + fr) * RB + swz;
+
+    half8v af[2][MT], bf[2][NT];
+    auto read_frag = [&](auto set_tag, int slot, int r) {      // r-th fragment read of a tile: W first, then A
+        constexpr int S = decltype(set_tag)::value;
+        const char* cur = smem + slot * STAGE;
+        if (r < NT) bf[S][r] = *reinterpret_cast<const half8v*>(cur + b_off0 + r * 1024);
+        else af[S][r - NT] = *reinterpret_cast<const half8v*>(cur + a_off0 + (r - NT) * 1024);
+    };
+    auto sync_tiles = [&](auto n_tag) {      // at most n younger DMA groups of this wave in flight, then barrier
+        constexpr int n = decltype(n_tag)::value;
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n * PPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    const int kt_last = kt_begin + nk - 1;
+    int s_cur = 0, s_nxt = 1;          // ring slots of tiles i and i+1 (tile i's slot is where tile i+NS goes)
+    constexpr int NMMA = MT * NT, NRD = MT + NT;
+    // phase i: MFMAs of tile i from fragment set S; reads of tile i+1 into the other set; DMA of tile i+NS into tile i's slot
+    auto phase = [&](auto set_tag, int i) {
+        constexpr int S = decltype(set_tag)::value;
+        const int ktn = min(kt_begin + i + NS, kt_last);
+        begin_tile(ktn);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < NMMA; ++j) {
+            const int mt = j / NT, nt = j % NT;
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[S][nt], af[S][mt], acc[mt][nt], 0, 0, 0);   // D^T: lane = row m
+            // (the fences keep the first read BEHIND MFMA 0: the compiler cannot see the inline-asm waits, so it puts an
+            //  lgkmcnt(0) of its own in front of the first use of the fragment registers -- free while nothing is in flight)
+            if (j % 2 == 0 && j / 2 < NRD) {
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef W80_NO_READ
+                read_frag(int_c<1 - S>{}, s_nxt, j / 2);      // (past the last tile this reads a never-used slot into the idle set)
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (j % 6 == 3 && j / 6 < PPW) {
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef W80_NO_DMA
+                dma_piece(ktn, s_cur, j / 6);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        s_cur = s_nxt;
+        s_nxt = (s_nxt + 1 == NS) ? 0 : s_nxt + 1;
+    };
+
+    // ---- prologue: NS tiles in flight, fragments of tile 0 in set 0, tile 1 landed ----
+#pragma unroll
+    for (int t = 0; t < NS; ++t) issue(min(kt_begin + t, kt_last), t);
+    sync_tiles(int_c<NS - 1>{});                     // tile 0 landed
+#pragma unroll
+    for (int r = 0; r < NRD; ++r) read_frag(int_c<0>{}, 0, r);
+    sync_tiles(int_c<NS - 2>{});                     // tile 1 landed, everyone has read tile 0
+    // after phase i (which issued tile i+NS) tile i+2 must have landed: tiles i+3 .. i+NS stay in flight
+    int i = 0;
+    for (; i + 1 < nk; i += 2) {
+        phase(int_c<0>{}, i);
+        sync_tiles(int_c<NS - 2>{});
+        phase(int_c<1>{}, i + 1);
+        sync_tiles(int_c<NS - 2>{});
+    }
+    if (i < nk) phase(int_c<0>{}, i);
+    sync_tiles(int_c<0>{});            // every DMA (incl. the repeats) and fragment read is done: the ring is free for the epilogue
+
+    // ---- epilogue: lane owns 4 consecutive columns n = wave_n*80 + nt*16 + 4*fg + r of row m = wave_m*80 + mt*16 + fr ----
+    if (p.splits > 1) {
+        float* ws = p.splitk_ws + (int64_t)split * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = m0 + wave_m * 80 + mt * 16 + fr;
+            if (row < p.M) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = n0 + wave_n * 80 + nt * 16 + 4 * fg;
+                    *reinterpret_cast<f32x4*>(ws + (int64_t)row * p.N + col) = acc[mt][nt];
+                }
+            }
+        }
+        return;
+    }
+    constexpr int pitch = BN * 2 + 16;
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = wave_n * 80 + nt * 16 + 4 * fg;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = wave_m * 80 + mt * 16 + fr;
+            half4v h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[mt][nt][r] + bv[r]);
+            *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = h;
+        }
+    }
+    __syncthreads();
+    constexpr int chunks_per_row = BN / 8;
+    constexpr int total_chunks = TM * chunks_per_row;
+    for (int idx = tid; idx < total_chunks; idx += 512) {
+        const int row = idx / chunks_per_row, ch = idx - row * chunks_per_row;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        const int col = n0 + ch * 8;
+        half8v h = *reinterpret_cast<const half8v*>(smem + row * pitch + ch * 16);
+        if (rowadd || resid) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+            if (rowadd) {
+                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            }
+            if (resid) {
+                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+        }
+        *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
+    }
+}
+
+template <int AMODE, bool FAST>
+int launch_gemm_w80(const moca_gemm_params& p, hipStream_t st) {
+    const int tiles_m = (p.M + 319) / 320, tiles_n = p.N / 160;
+    const int nblk = tiles_m * tiles_n * p.splits;
+    constexpr int lds = 5 * (320 + 160) * 64;       // 150 KiB ring; the fp16 epilogue tile (320 x 336 B) fits inside it
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w80_kernel<AMODE, FAST>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MOCA_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_w80_kernel<AMODE, FAST>), dim3(nblk), dim3(512), lds, st, p);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+int launch_gemm_w80_mode(const moca_gemm_params& p, bool fastp, hipStream_t st) {
+    if (p.a_mode == MOCA_A_LINEAR) return fastp ? launch_gemm_w80<MOCA_A_LINEAR, true>(p, st) : launch_gemm_w80<MOCA_A_LINEAR, false>(p, st);
+    if (p.a_mode == MOCA_A_CONV3X3) return fastp ? launch_gemm_w80<MOCA_A_CONV3X3, true>(p, st) : launch_gemm_w80<MOCA_A_CONV3X3, false>(p, st);
+    return fastp ? launch_gemm_w80<MOCA_A_TCONV3, true>(p, st) : launch_gemm_w80<MOCA_A_TCONV3, false>(p, st);
+}
+
 template <int AMODE, bool FAST>
 int launch_gemm_g4(const moca_gemm_params& p, hipStream_t st) {
     const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / 128;
@@ -1290,7 +1641,15 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     // deeper pipeline wins everywhere else (K >= 1280: 1137 vs 880 TFLOP/s).  MOCA_GEMM_G4=0/2 forces never/always.
     static const int g4_mode = [] { const char* e = getenv("MOCA_GEMM_G4"); return e ? atoi(e) : 1; }();
     const bool use_g4 = !(p.flags & MOCA_EP_OUT_F32) && (g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640));
-    if (use_big && big_bn == 128 && use_g4) {
+    // w80 (320 x 160 tiles, 80 x 80 wave tiles): every non-GEGLU contraction whose N is a multiple of 160 and whose
+    // 320-row tiles fill the chip.  MOCA_GEMM_W80=0 disables it (A/B against the 256-row kernel), 2 drops the tile-count rule.
+    static const int w80_mode = [] { const char* e = getenv("MOCA_GEMM_W80"); return e ? atoi(e) : 1; }();
+    const int tiles320 = ((p.M + 319) / 320) * (p.N / 160);
+    const bool use_w80 = w80_mode && p.N % 160 == 0 && !geglu && !(p.flags & (MOCA_EP_OUT_F32 | MOCA_FORCE_SMALL_TILE)) &&
+                         p.M > 160 && (tiles320 * p.splits >= 200 || w80_mode == 2);
+    if (use_w80) {
+        rc = launch_gemm_w80_mode(p, fastp, st);
+    } else if (use_big && big_bn == 128 && use_g4) {
         if (p.a_mode == MOCA_A_LINEAR) rc = fastp ? launch_gemm_g4<MOCA_A_LINEAR, true>(p, st) : launch_gemm_g4<MOCA_A_LINEAR, false>(p, st);
         else if (p.a_mode == MOCA_A_CONV3X3) rc = fastp ? launch_gemm_g4<MOCA_A_CONV3X3, true>(p, st) : launch_gemm_g4<MOCA_A_CONV3X3, false>(p, st);
         else rc = fastp ? launch_gemm_g4<MOCA_A_TCONV3, true>(p, st) : launch_gemm_g4<MOCA_A_TCONV3, false>(p, st);

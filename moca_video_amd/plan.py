@@ -25,6 +25,25 @@ from .unet import (_BasicTransformerBlock, _Downsample, _FMap, _Pool, _ResBlock,
 N_CU = 256
 
 
+def gemm_splits(M, pw):
+    """split-K factor: only when the launch cannot give every CU a tile (mirrors the tile choice of moca_gemm_f16)."""
+    nk = pw.w.shape[1] // 64
+    tiles = 0
+    if pw.N % 160 == 0 and not pw.geglu and M > 160:        # w80 kernel: 320 x 160 tiles when they fill the chip
+        tiles = ((M + 319) // 320) * (pw.N // 160)
+        if tiles < 200:
+            tiles = 0
+    if tiles == 0:
+        if M > 128 and (pw.N % 128 == 0 or pw.N % 160 == 0):
+            tm, bn = 256, (128 if pw.N % 128 == 0 else 160)
+        else:
+            tm, bn = 128, (128 if pw.N % 128 == 0 else 64)
+        tiles = ((M + tm - 1) // tm) * (pw.N // bn)
+    if tiles >= (N_CU * 3) // 4:
+        return 1
+    return max(1, min(N_CU // tiles, nk // 8))
+
+
 class _Plan:
     def __init__(self, model, B, T, H, W, L, in_dtype, device):
         self.model, self.B, self.T, self.H, self.W, self.L = model, B, T, H, W, L
@@ -59,16 +78,7 @@ class _Plan:
             self.pool.put(b)
 
     def _splits(self, M, pw):
-        """split-K factor: only when the launch cannot give every CU a tile (mirrors the C-side dispatch)."""
-        if M > 128 and (pw.N % 128 == 0 or pw.N % 160 == 0):
-            tm, bn = 256, (128 if pw.N % 128 == 0 else 160)
-        else:
-            tm, bn = 128, (128 if pw.N % 128 == 0 else 64)
-        tiles = ((M + tm - 1) // tm) * (pw.N // bn)
-        nk = pw.w.shape[1] // 64
-        if tiles >= (N_CU * 3) // 4:
-            return 1
-        return max(1, min(N_CU // tiles, nk // 8))
+        return gemm_splits(M, pw)
 
     def _gemm(self, a, pw, M, *, out_cols=None, **kw):
         n_out = pw.n_out if pw.geglu else pw.N

@@ -12,7 +12,12 @@ F = B * T
 LV = {0: (40, 64), 1: (20, 32), 2: (10, 16), 3: (5, 8)}
 
 
+FILTER = [a for a in sys.argv[1:]]
+
+
 def run(name, fn, flops, iters=20):
+    if FILTER and not any(f in name for f in FILTER):
+        return 0.0
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -26,12 +31,8 @@ def run(name, fn, flops, iters=20):
 
 
 def splits_for(M, pw):
-    bn = 128 if pw.N % 128 == 0 else 64
-    tiles = ((M + 127) // 128) * (pw.N // bn)
-    nk = pw.w.shape[1] // 64
-    if tiles >= 256:
-        return 1
-    return max(1, min(384 // tiles, nk // 8))
+    from moca_video_amd.plan import gemm_splits
+    return gemm_splits(M, pw)
 
 
 def conv(lv, cin, cout, splits=None):
