@@ -100,6 +100,36 @@ def fifo_leg(dm, device, T, H, W, iters=3):
             "note": "8 windows batched (B=8, 154-token cond + B=8, 77-token uncond), MoCA ddim_step + FreeInit shift included, VAE decode excluded"}
 
 
+VAE_DD = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)          # configs/inference_t2v_512_v2.0.yaml:56-70
+VAE_FLOP_PER_FRAME = 1.5635e12      # conv/linear/bmm MACs x 2 of AutoencoderKL.decode on [1,4,40,64] (FlopCounterMode on the oracle)
+
+
+def vae_leg(device, H, W, frames=8, iters=5):
+    """Extra: AutoencoderKL.decode of `frames` emitted latent frames [frames,4,40,64] -> [frames,3,320,512]
+    (funcs.py:360 decodes one frame per FIFO iteration, 148 per video)."""
+    from moca_video_amd import AutoencoderKL
+    from moca_video_amd.weightgen import init_random_
+    with torch.device(device):
+        ae = AutoencoderKL(ddconfig=VAE_DD, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4)
+    ae = ae.to(device)
+    init_random_(ae, 123)
+    g = torch.Generator(device=device).manual_seed(11)
+    z = torch.randn(frames, 4, H, W, device=device, generator=g) / 0.18215
+    for _ in range(2):
+        out = ae.decode(z)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = ae.decode(z)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    assert out.shape == (frames, 3, 8 * H, 8 * W) and bool(torch.isfinite(out).all())
+    return {"ms_per_frame": round(dt / frames * 1e3, 3), "frames_per_launch": frames,
+            "tflops": round(VAE_FLOP_PER_FRAME * frames / dt / 1e12, 1),
+            "s_per_video_148_frames": round(148 * dt / frames, 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +272,9 @@ def main():
     }
     if world == 1 and not args.no_fifo:
         res["fifo"] = fifo_leg(dm, device, T, H, W)
+        res["vae_decode"] = vae_leg(device, H, W)
+        res["fifo"]["projected_s_per_video_incl_vae_decode"] = round(
+            res["fifo"]["projected_s_per_video_148_iterations"] + res["vae_decode"]["s_per_video_148_frames"], 1)
     if world == 1 and not args.no_cpu_baseline:
         threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share
         ts = torch.full((1,), int(sampler.ddim_timesteps[S - 1]), device=device, dtype=torch.long)

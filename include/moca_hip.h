@@ -131,6 +131,18 @@ int moca_timestep_embedding_f16(const int64_t* t, void* out, int32_t n, int32_t 
 int moca_silu_add_rows_f16(const void* a, int32_t div_a, const void* b, int32_t div_b, void* out,
                            int32_t rows, int32_t C, int32_t apply_silu, void* stream);
 
+/* ---- VAE decoder helpers (next row N1: AutoencoderKL.decode, lvdm/models/autoencoder.py:104-107) ---- */
+/* out[(b*T+t)*HW+p][co] = bias[co] + sum_ci w[co][ci] * z[b][ci][t][p] * inv_scale  (co < Cout; zero up to Cpad).
+ * Replaces `z = 1/scale_factor * z` (ddpm3d.py:559) + `post_quant_conv` (autoencoder.py:105) + the NCHW -> channels-last
+ * shuffle in one pass; Cin <= 8, w fp32 [Cout][Cin]. */
+int moca_channel_mix_f16(const void* z, int32_t z_is_f32, const float* w, const float* bias, void* out,
+                         int32_t B, int32_t Cin, int32_t T, int32_t HW, int32_t Cout, int32_t Cpad,
+                         float inv_scale, void* stream);
+/* p[r][0:N] = softmax(scale * s[r][0:N]) for R rows, fp32 logits in, fp16 probabilities out; N, lds, ldp % 4 == 0.
+ * Replaces `w_ = w_ * c**-0.5; softmax(w_, dim=2)` of AttnBlock.forward (ae_modules.py:66-68). */
+int moca_softmax_rows_f16(const float* s, void* p, int64_t R, int32_t N, int64_t lds, int64_t ldp, float scale,
+                          void* stream);
+
 /* ---- sampler arithmetic (fp32) -------------------------------------------------- */
 /* e = e_u + s (e_c - e_u): ddim.py:304,372 */
 int moca_cfg_combine_f32(const float* e_c, const float* e_u, float* out, float scale,

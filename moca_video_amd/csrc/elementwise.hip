@@ -87,6 +87,60 @@ inline int grid_for(int64_t total) {
     return (int)g;
 }
 
+// ---- VAE: z / scale_factor -> post_quant_conv (1x1, <= 8 channels) -> channels-last fp16 ---------------
+// out[(b*T+t)*HW + p][co] = bias[co] + sum_ci w[co][ci] * (z[b][ci][t][p] * inv_scale), co < Cout; 0 for Cout <= co < Cpad
+template <typename TIN>
+__global__ void channel_mix_kernel(const TIN* __restrict__ z, const float* __restrict__ w, const float* __restrict__ bias,
+                                   half_t* __restrict__ out, int B, int Cin, int T, int HW, int Cout, int Cpad, float inv_scale) {
+    const int64_t total = (int64_t)B * T * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const int64_t bt = i / HW;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        float v[8];
+        for (int ci = 0; ci < Cin; ++ci) v[ci] = (float)z[(((int64_t)b * Cin + ci) * T + t) * HW + p] * inv_scale;
+        for (int co = 0; co < Cpad; ++co) {
+            float a = 0.f;
+            if (co < Cout) {
+                a = bias ? bias[co] : 0.f;
+                for (int ci = 0; ci < Cin; ++ci) a += w[co * Cin + ci] * v[ci];
+            }
+            out[i * Cpad + co] = (half_t)a;
+        }
+    }
+}
+
+// ---- row softmax: p[r][:] = softmax(scale * s[r][:]) , fp32 in, fp16 out; one wavefront per row -------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, half_t* __restrict__ pr, int64_t R,
+                                                           int N, int64_t lds_, int64_t ldp, float scale_log2e) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* x = s + row * lds_;
+    float m = -INFINITY;
+    for (int j = lane * 4; j < N; j += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + j);
+        m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane * 4; j < N; j += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum += exp2f((v[q] - m) * scale_log2e);
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    half_t* o = pr + row * ldp;
+    for (int j = lane * 4; j < N; j += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + j);
+        half4v h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = (half_t)(exp2f((v[q] - m) * scale_log2e) * inv);
+        *reinterpret_cast<half4v*>(o + j) = h;
+    }
+}
+
 }  // namespace
 
 extern "C" int moca_ncthw_to_nhwc_f16(const void* x, int32_t x_is_f32, void* y, int32_t B, int32_t Cin,
@@ -144,6 +198,32 @@ extern "C" int moca_silu_add_rows_f16(const void* a, int32_t div_a, const void* 
     hipLaunchKernelGGL(silu_add_rows_kernel, dim3(g), dim3(256), 0, moca_stream(stream), reinterpret_cast<const half_t*>(a),
                        div_a, reinterpret_cast<const half_t*>(b), div_b > 0 ? div_b : 1, reinterpret_cast<half_t*>(out),
                        rows, C, apply_silu);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_channel_mix_f16(const void* z, int32_t z_is_f32, const float* w, const float* bias, void* out,
+                                    int32_t B, int32_t Cin, int32_t T, int32_t HW, int32_t Cout, int32_t Cpad,
+                                    float inv_scale, void* stream) {
+    if (!z || !w || !out || B <= 0 || T <= 0 || HW <= 0 || Cin <= 0 || Cin > 8 || Cout <= 0 || Cout > Cpad) return MOCA_E_BADARG;
+    const int g = grid_for((int64_t)B * T * HW);
+    if (z_is_f32)
+        hipLaunchKernelGGL(channel_mix_kernel<float>, dim3(g), dim3(256), 0, moca_stream(stream), reinterpret_cast<const float*>(z),
+                           w, bias, reinterpret_cast<half_t*>(out), B, Cin, T, HW, Cout, Cpad, inv_scale);
+    else
+        hipLaunchKernelGGL(channel_mix_kernel<half_t>, dim3(g), dim3(256), 0, moca_stream(stream), reinterpret_cast<const half_t*>(z),
+                           w, bias, reinterpret_cast<half_t*>(out), B, Cin, T, HW, Cout, Cpad, inv_scale);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_softmax_rows_f16(const float* s, void* p, int64_t R, int32_t N, int64_t lds, int64_t ldp, float scale,
+                                     void* stream) {
+    if (!s || !p || R <= 0 || N <= 0 || N % 4 || lds % 4 || ldp % 4 || lds < N || ldp < N) return MOCA_E_BADARG;
+    const int64_t blocks = (R + 3) / 4;
+    if (blocks > 0x7fffffff) return MOCA_E_BADARG;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, moca_stream(stream), s,
+                       reinterpret_cast<half_t*>(p), R, N, lds, ldp, scale * 1.4426950408889634f);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

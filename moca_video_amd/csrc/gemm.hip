@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const moca_gemm_params
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int nk_total = p.ldw / BK;
+    const int nk_total = (p.K + BK - 1) / BK;      // (W rows are readable and zero beyond K up to the next multiple of 64)
     const int kts = (nk_total + p.splits - 1) / p.splits;
     const int kt_begin = split * kts;
     const int kt_end = min(kt_begin + kts, nk_total);
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int m0 = tile_m * TM, n0 = tile_n * BN;
 
-    const int nk_total = p.ldw / BK;
+    const int nk_total = (p.K + BK - 1) / BK;      // (W rows are readable and zero beyond K up to the next multiple of 64)
     const int kts = (nk_total + p.splits - 1) / p.splits;
     const int kt_begin = split * kts;
     const int kt_end = min(kt_begin + kts, nk_total);
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int m0 = tile_m * TM, n0 = tile_n * BN;
 
-    const int nk_total = p.ldw / KS;                   // ldw % 64 == 0 -> even
+    const int nk_total = 2 * ((p.K + 63) / 64);        // 64-deep units -> even
     const int kts = (nk_total + p.splits - 1) / p.splits;
     const int kt_begin = split * kts;
     const int nk = min(kt_begin + kts, nk_total) - kt_begin;
@@ -1229,8 +1229,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int m0 = tile_m * TM, n0 = tile_n * BN;
 
-    const int nk_total = p.ldw / KS;
-    const int kts = 2 * ((p.ldw / 64 + p.splits - 1) / p.splits);      // split in 64-deep units, as the host sizes it
+    const int nk_total = 2 * ((p.K + 63) / 64);
+    const int kts = 2 * (((p.K + 63) / 64 + p.splits - 1) / p.splits);      // split in 64-deep units, as the host sizes it
     const int kt_begin = split * kts;
     const int nk = min(kt_begin + kts, nk_total) - kt_begin;
 
@@ -1601,14 +1601,14 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     if (p.splits < 1) p.splits = 1;
     if (!p.a || !p.w || !p.out) return MOCA_E_BADARG;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MOCA_E_BADARG;
-    if (p.N % 64 || p.K % 8 || p.ldw % BK || p.ldw < p.K) return MOCA_E_BADARG;
+    if (p.N % 64 || p.K % 8 || p.ldw % BK || p.ldw < ((p.K + BK - 1) / BK) * BK) return MOCA_E_BADARG;
     const bool geglu = p.flags & MOCA_EP_GEGLU;
     if (geglu && p.N % 128) return MOCA_E_BADARG;
     if (p.ldo % 8 || (p.residual && p.ldr % 8) || (p.rowadd && (p.ld_rowadd % 8 || p.rowadd_div <= 0))) return MOCA_E_BADARG;
     if (p.splits > 1 && !p.splitk_ws) return MOCA_E_BADARG;
-    if (p.splits > p.ldw / BK) p.splits = p.ldw / BK;
+    if (p.splits > (p.K + BK - 1) / BK) p.splits = (p.K + BK - 1) / BK;
     if (p.splits > 1) {   // no empty k range: every split writes its slab
-        const int nkt = p.ldw / BK, kts = (nkt + p.splits - 1) / p.splits;
+        const int nkt = (p.K + BK - 1) / BK, kts = (nkt + p.splits - 1) / p.splits;
         p.splits = (nkt + kts - 1) / kts;
     }
     switch (p.a_mode) {

@@ -87,8 +87,11 @@ def fifo_windows(args):
 
 def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg_scale=1.0, uc_emb=None,
                        latents=None, latents_dir=None, conditioned_image=None, masks=None, gamma=0.5, emit=None,
-                       n_iterations=None, batch_windows=True, noises=None, shift_noises=None, **kwargs):
-    """funcs.py:243-373: returns the list of emitted latent frames [B,4,1,h,w] (decode is the caller's).
+                       n_iterations=None, batch_windows=True, noises=None, shift_noises=None, decode=False, decode_batch=8,
+                       **kwargs):
+    """funcs.py:243-373: returns the list of emitted latent frames [B,4,1,h,w]; with decode=True (and a model built with
+    `first_stage_config`) the list of decoded frames [B,3,1,8h,8w] instead -- `model.decode_first_stage_2DAE` of funcs.py:360,
+    run on `decode_batch` emitted frames at a time rather than once per iteration.
     `masks` [B,1,Q,h,w] (Q = queue length) plays the role of the DAVIS masks (:296-302,315).
     batch_windows=True evaluates the 2n windows of an iteration as one batched UNet launch (SURVEY 8f N2);
     `noises[i][w]` / `shift_noises[i]` optionally fix the per-window DDIM noise and the enqueued noise."""
@@ -109,7 +112,7 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
         timesteps = np.concatenate([np.full((f // 2,), timesteps[0]), timesteps])
         indices = np.concatenate([np.full((f // 2,), 0), indices])
     total = args.new_video_length + args.num_inference_steps - f if n_iterations is None else n_iterations
-    frames = []
+    frames, pending = [], []
     for i in range(total):
         wins = list(fifo_windows(args))
         eps_list = None
@@ -138,8 +141,37 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
                 latents[:, :, start:end] = output_latents
         first = f // 2 if args.lookahead_denoising else 0
         frame = latents[:, :, [first]].clone()
-        frames.append(frame if emit is None else emit(frame))
+        if decode:
+            pending.append(frame)
+            if len(pending) == decode_batch:
+                frames.extend(decode_frames(model, pending))
+                pending = []
+        else:
+            frames.append(frame if emit is None else emit(frame))
         latents = shift_latents(latents, noise=None if shift_noises is None else shift_noises[i])
         if masks is not None:
             masks[:, :, :-1] = masks[:, :, 1:].clone()
+    if pending:
+        frames.extend(decode_frames(model, pending))
     return frames
+
+
+def decode_frames(model, latent_frames):
+    """`model.decode_first_stage_2DAE` (ddpm3d.py:556-562) over a list of emitted latent frames [B,4,1,h,w]:
+    one recorded decoder launch for all of them; returns the list of [B,3,1,8h,8w] tensors."""
+    z = torch.cat(latent_frames, dim=2)
+    img = model.decode_first_stage_2DAE(z)
+    return [img[:, :, [i]] for i in range(img.shape[2])]
+
+
+def tensor2image(batch_tensors):
+    """funcs.py:630-640: [1,3,1,H,W] in [-1,1] -> uint8 [H,W,3] (a PIL image when Pillow is importable)"""
+    img = torch.squeeze(batch_tensors).detach().cpu()
+    img = torch.clamp(img.float(), -1., 1.)
+    img = (img + 1.0) / 2.0
+    arr = (img * 255).to(torch.uint8).permute(1, 2, 0).numpy()
+    try:
+        from PIL import Image
+        return Image.fromarray(arr)
+    except ImportError:
+        return arr

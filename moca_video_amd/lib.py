@@ -54,6 +54,8 @@ SIGNATURES = {
     "moca_concat_channels_f16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "moca_timestep_embedding_f16": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _vp]),
     "moca_silu_add_rows_f16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "moca_channel_mix_f16": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "moca_softmax_rows_f16": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _i64, _f32, _vp]),
     "moca_cfg_combine_f32": (C.c_int, [_vp, _vp, _vp, _f32, _i64, _vp]),
     "moca_ddim_update_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i64, _vp]),
     "moca_fifo_ddim_step_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -123,7 +123,7 @@ def gemm(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd
     p.splitk_ws = splitk_ws.data_ptr() if splitk_ws is not None else None
     p.M, p.N, p.K = M, pw.N, pw.K
     p.lda = lda if lda is not None else (a.stride(-2) if a.dim() >= 2 else pw.K)
-    p.ldw = pw.w.shape[1]
+    p.ldw = pw.w.stride(0)
     p.ldo = out.stride(-2)
     p.ldr = residual.stride(-2) if residual is not None else 0
     p.ld_rowadd = rowadd.stride(-2) if rowadd is not None else 0
@@ -196,3 +196,15 @@ def silu_add_rows(a, div_a, b, div_b, out, *, rows, Cn, silu):
     _l.check(_l.load().moca_silu_add_rows_f16(_l.ptr(a), div_a, _l.ptr(b), div_b, _l.ptr(out), rows, Cn,
                                               1 if silu else 0, _st()), "moca_silu_add_rows_f16")
     return out
+
+
+def channel_mix(z, w, bias, out, *, B, Cin, T, HW, Cout, Cpad, inv_scale):
+    _l.check(_l.load().moca_channel_mix_f16(_l.ptr(z), 1 if z.dtype == torch.float32 else 0, _l.ptr(w), _l.ptr(bias), _l.ptr(out),
+                                            B, Cin, T, HW, Cout, Cpad, inv_scale, _st()), "moca_channel_mix_f16")
+    return out
+
+
+def softmax_rows(s, p, *, R, N, scale):
+    _l.check(_l.load().moca_softmax_rows_f16(_l.ptr(s), _l.ptr(p), R, N, s.stride(-2), p.stride(-2), scale, _st()),
+             "moca_softmax_rows_f16")
+    return p

@@ -44,10 +44,11 @@ def gemm_splits(M, pw):
     return max(1, min(N_CU // tiles, nk // 8))
 
 
-class _Plan:
-    def __init__(self, model, B, T, H, W, L, in_dtype, device):
-        self.model, self.B, self.T, self.H, self.W, self.L = model, B, T, H, W, L
-        self.BT = B * T
+class _PlanBase:
+    """pool + recorded launch list + hipGraph capture/replay, shared by the UNet plan and the VAE-decoder plan"""
+
+    def __init__(self, model, device):
+        self.model = model
         self.device = device
         self.P = model._packed
         self.pool = _Pool(device)
@@ -57,13 +58,6 @@ class _Plan:
         self.graph = None
         self.graph_failed = False
         self.n_runs = 0
-        m = model
-        self.x_in = torch.empty(B, m.in_channels, T, H, W, dtype=in_dtype, device=device)
-        self.t_rows = torch.empty(self.BT, dtype=torch.int64, device=device)
-        self.fps_rows = torch.empty(self.BT, dtype=torch.int64, device=device)
-        self.ctx = torch.empty(B * L, m.context_dim, dtype=torch.float16, device=device)
-        self.out = torch.empty(B, m.out_channels, T, H, W, dtype=in_dtype, device=device)
-        self._build()
 
     # ------------------------------------------------------------------ emit helpers
     def _emit(self, fn, *args, **kw):
@@ -123,6 +117,53 @@ class _Plan:
         y = self.pool.get(M, Cn)
         self._emit(ops.layernorm, x, y, gb[0], gb[1], M=M, Cn=Cn, eps=1e-5)
         return y
+
+    def _run_steps(self):
+        for s in self.steps:
+            s()
+
+    def _launch(self, handle):
+        lib = _l.load()
+        if self.graph is not None:
+            _l.check(lib.moca_graph_launch(self.graph, C.c_void_p(handle)), "moca_graph_launch")
+            return
+        use_graph = self.model.use_graph and not self.graph_failed
+        if self.n_runs == 0 or not use_graph:
+            self._run_steps()          # first pass eager: surfaces argument errors outside of capture
+            return
+        # second pass: record the same launch sequence into a hipGraph, then replay it
+        rc = lib.moca_graph_begin(C.c_void_p(handle))
+        if rc != 0:
+            self.graph_failed = True
+            warnings.warn("moca_video_amd: hipStreamBeginCapture failed; staying on eager HIP launches")
+            self._run_steps()
+            return
+        try:
+            self._run_steps()
+        finally:
+            g = C.c_void_p()
+            rc = lib.moca_graph_end(C.c_void_p(handle), C.byref(g))
+        if rc != 0 or not g.value:
+            self.graph_failed = True
+            warnings.warn("moca_video_amd: hipGraph instantiate failed; staying on eager HIP launches")
+            self._run_steps()
+            return
+        self.graph = g
+        _l.check(lib.moca_graph_launch(self.graph, C.c_void_p(handle)), "moca_graph_launch")
+
+
+class _Plan(_PlanBase):
+    def __init__(self, model, B, T, H, W, L, in_dtype, device):
+        super().__init__(model, device)
+        self.B, self.T, self.H, self.W, self.L = B, T, H, W, L
+        self.BT = B * T
+        m = model
+        self.x_in = torch.empty(B, m.in_channels, T, H, W, dtype=in_dtype, device=device)
+        self.t_rows = torch.empty(self.BT, dtype=torch.int64, device=device)
+        self.fps_rows = torch.empty(self.BT, dtype=torch.int64, device=device)
+        self.ctx = torch.empty(B * L, m.context_dim, dtype=torch.float16, device=device)
+        self.out = torch.empty(B, m.out_channels, T, H, W, dtype=in_dtype, device=device)
+        self._build()
 
     # ------------------------------------------------------------------ blocks
     def res_block(self, mod, x):
@@ -295,10 +336,6 @@ class _Plan:
         self._emit(ops.nhwc_to_ncthw, o.buf, o.C, self.out, B=B, Cout=m.out_channels, T=T, HW=H * W)
         self._release(o.buf)
 
-    def _run_steps(self):
-        for s in self.steps:
-            s()
-
     def launch_async(self, x, t_rows, fps_rows, context, cur):
         """enqueue one forward on this plan's stream (ordered after `cur`); the caller joins"""
         self.stream.wait_stream(cur)
@@ -324,31 +361,3 @@ class _Plan:
         cur.wait_stream(self.stream)
         return out
 
-    def _launch(self, handle):
-        lib = _l.load()
-        if self.graph is not None:
-            _l.check(lib.moca_graph_launch(self.graph, C.c_void_p(handle)), "moca_graph_launch")
-            return
-        use_graph = self.model.use_graph and not self.graph_failed
-        if self.n_runs == 0 or not use_graph:
-            self._run_steps()          # first pass eager: surfaces argument errors outside of capture
-            return
-        # second pass: record the same launch sequence into a hipGraph, then replay it
-        rc = lib.moca_graph_begin(C.c_void_p(handle))
-        if rc != 0:
-            self.graph_failed = True
-            warnings.warn("moca_video_amd: hipStreamBeginCapture failed; staying on eager HIP launches")
-            self._run_steps()
-            return
-        try:
-            self._run_steps()
-        finally:
-            g = C.c_void_p()
-            rc = lib.moca_graph_end(C.c_void_p(handle), C.byref(g))
-        if rc != 0 or not g.value:
-            self.graph_failed = True
-            warnings.warn("moca_video_amd: hipGraph instantiate failed; staying on eager HIP launches")
-            self._run_steps()
-            return
-        self.graph = g
-        _l.check(lib.moca_graph_launch(self.graph, C.c_void_p(handle)), "moca_graph_launch")

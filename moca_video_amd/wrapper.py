@@ -15,8 +15,14 @@ from .unet import UNetModel
 
 # `target:` strings of the reference YAML resolve to our classes, so an unmodified
 # configs/inference_t2v_512_v2.0.yaml instantiates the MI355X path.
+def _vae_cls(**kw):
+    from .vae import AutoencoderKL
+    return AutoencoderKL(**kw)
+
+
 _TARGET_ALIASES = {
     "lvdm.modules.networks.openaimodel3d.UNetModel": UNetModel,
+    "lvdm.models.autoencoder.AutoencoderKL": _vae_cls,
 }
 
 
@@ -81,7 +87,7 @@ class DenoiseModel(nn.Module):
 
     def __init__(self, unet_config, timesteps=1000, linear_start=0.00085, linear_end=0.012, conditioning_key="crossattn",
                  use_scale=True, scale_a=1, scale_b=0.7, mid_step=400, fix_scale_bug=False, parameterization="eps",
-                 uncond_type="empty_seq", **ignored):
+                 uncond_type="empty_seq", first_stage_config=None, scale_factor=1.0, **ignored):
         super().__init__()
         self.parameterization = parameterization
         self.uncond_type = uncond_type
@@ -104,6 +110,20 @@ class DenoiseModel(nn.Module):
             scale_step = self.num_timesteps - mid_step if fix_scale_bug else self.num_timesteps
             scale_arr = np.concatenate((np.linspace(scale_a, scale_b, mid_step), np.full(scale_step, scale_b)))
             self.register_buffer('scale_arr', to_torch(scale_arr))
+        # first stage (ddpm3d.py:383,386,431-437): only the decode side is on the MoCA path (funcs.py:360)
+        self.scale_factor = scale_factor
+        self.first_stage_model = instantiate_from_config(first_stage_config) if first_stage_config is not None else None
+
+    @torch.no_grad()
+    def decode_first_stage_2DAE(self, z, **kwargs):
+        """ddpm3d.py:556-562: z [b,c,t,h,w] latents -> [b,3,t,8h,8w]; the reference decodes one frame per call, here
+        all b*t frames go through the recorded decoder in groups of `AutoencoderKL.max_frames_per_launch`."""
+        if self.first_stage_model is None:
+            raise RuntimeError("DenoiseModel was built without first_stage_config")
+        b, c, t, h, w = z.shape
+        zf = (1. / self.scale_factor * z).permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+        out = self.first_stage_model.decode(zf, **kwargs)
+        return out.reshape(b, t, *out.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()
 
     @property
     def device(self):

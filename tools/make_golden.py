@@ -302,6 +302,29 @@ def fifo_cases():
     save("fifo_queue", prepared=lat, shifted=shifted, n_noise_prepare=np.asarray(n_prep), n_noise_total=np.asarray(len(noises)))
 
 
+
+VAE_DD = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)          # configs/inference_t2v_512_v2.0.yaml:56-70
+
+
+def vae_cases():
+    """AutoencoderKL.decode / decode_first_stage_2DAE of the real reference (autoencoder.py:104-107, ddpm3d.py:556-562):
+    a reduced-width decoder (ch=64) on 3 frames of 8x8 latents and the full-width YAML decoder on one 8x8 latent."""
+    from lvdm.models.autoencoder import AutoencoderKL
+    with torch.no_grad():
+        for tag, ch, shape in (("vae_reduced", 64, (1, 4, 3, 8, 8)), ("vae_full_small", 128, (1, 4, 1, 8, 8))):
+            dd = dict(VAE_DD, ch=ch)
+            ae = AutoencoderKL(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4).eval()
+            fill(ae, seed=5)
+            z = inp(tag + ":z", shape, seed=5)
+            scale = 0.18215
+            t0 = time.time()
+            zz = 1.0 / scale * z
+            out = torch.cat([ae.decode(zz[:, :, i]).unsqueeze(2) for i in range(zz.shape[2])], dim=2)   # ddpm3d.py:559-560
+            print(f"{tag}: {time.time() - t0:.1f}s out {tuple(out.shape)} std {out.std():.3f}")
+            save(tag, ch=np.asarray(ch), z_shape=np.asarray(shape), scale_factor=np.asarray(scale), out=out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -309,12 +332,13 @@ def main():
     a = ap.parse_args()
     torch.set_num_threads(8)
     om, att = import_reference()
-    todo = a.only.split(",") if a.only else ["blocks", "reduced", "sampler", "freeinit", "fifo"] + (["full"] if a.full else [])
+    todo = a.only.split(",") if a.only else ["blocks", "reduced", "sampler", "freeinit", "fifo", "vae"] + (["full"] if a.full else [])
     if "blocks" in todo: blocks(om, att)
     if "reduced" in todo: unet_reduced(om)
     if "sampler" in todo: sampler_cases()
     if "freeinit" in todo: freeinit_cases()
     if "fifo" in todo: fifo_cases()
+    if "vae" in todo: vae_cases()
     if "full" in todo: unet_full(om)
 
 
