@@ -56,7 +56,8 @@ def shift_latents(latents, noise=None):
 
 def base_ddim_sampling(model, cond, noise_shape, ddim_steps=50, ddim_eta=1.0, cfg_scale=1.0, uc_emb=None,
                        latents_dir=None, x_T=None, noises=None):
-    """funcs.py:177-241 without the VAE decode (:239).  `uc_emb` replaces
+    """funcs.py:177-241: returns (batch_images, ddim_sampler, samples) like the reference; batch_images is the VAE
+    decode of the samples (:239) when the model was built with `first_stage_config`, else None.  `uc_emb` replaces
     model.get_learned_conditioning([""]) (the text encoder is out of scope)."""
     sampler = DDIMSampler(model)
     uc = None
@@ -72,7 +73,8 @@ def base_ddim_sampling(model, cond, noise_shape, ddim_steps=50, ddim_eta=1.0, cf
     samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=noise_shape[0], shape=noise_shape[1:],
                                 verbose=False, unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc,
                                 eta=ddim_eta, x_T=x_T, latents_dir=latents_dir, noises=noises)
-    return sampler, samples
+    images = model.decode_first_stage_2DAE(samples) if getattr(model, "first_stage_model", None) is not None else None
+    return images, sampler, samples
 
 
 def fifo_windows(args):

@@ -1,0 +1,136 @@
+"""Prompt-file / hand-off formats either side of the hot path: the reference's prompt CSV
+(`scripts/evaluation/funcs.py:506-535`), its rank striding (`videocrafter_main.py:179-181`), the output/latent
+directory convention (`videocrafter_main.py:25-55`; the `{0,N}.pt` latent cache itself is written by
+`DDIMSampler.ddim_sampling` and read by `prepare_latents`, sampler.py / fifo.py), the frame/GIF writers
+(`funcs.py:614-640`) and the prompt-mode driver loop (`videocrafter_main.py:176-232`) with the two external models --
+text encoder and Grounded-SAM-2 -- replaced by caller-supplied callables (both are out of scope).
+Host-side Python, as in the reference; nothing here computes on the GPU except through the drop-in classes.
+"""
+from __future__ import annotations
+
+import csv
+import os
+
+import torch
+
+from .fifo import base_ddim_sampling, fifo_ddim_sampling, tensor2image
+from .sampler import DDIMSampler
+
+_FIELDS = ("prompt", "conditioned_object", "conditioned_image_path", "conditioned_prompt", "gamma")
+
+
+def load_prompts(prompt_file, prompt_index=None):
+    """funcs.py:506-535: rows of `prompt,conditioned_object,conditioned_image_path,conditioned_prompt,gamma`;
+    `conditioned_prompt` gets a trailing '.', `gamma` is a float; `prompt_index` selects one row (ValueError past the end)."""
+    def row_to_dict(row):
+        return {"prompt": row["prompt"].strip(), "conditioned_object": row["conditioned_object"].strip(),
+                "conditioned_image_path": row["conditioned_image_path"].strip(),
+                "conditioned_prompt": row["conditioned_prompt"].strip() + ".", "gamma": float(row["gamma"].strip())}
+    with open(prompt_file, "r") as f:
+        reader = csv.DictReader(f)
+        if prompt_index is not None:
+            for i, row in enumerate(reader):
+                if i == prompt_index:
+                    return [row_to_dict(row)]
+            raise ValueError(f"Prompt index {prompt_index} exceeds number of available prompts")
+        return [row_to_dict(row) for row in reader]
+
+
+def shard_indices(num_samples, rank, num_processes):
+    """videocrafter_main.py:179-181: `indices[rank::num_processes]`"""
+    return list(range(num_samples))[rank::num_processes]
+
+
+def set_directory(args, prompt, conditioned_image_path=None, root="."):
+    """videocrafter_main.py:25-55 (prompt mode): returns (output_dir, latents_dir), both created"""
+    p = prompt[:100]
+    if getattr(args, "output_dir", None) is None:
+        out = f"results/videocraft_v2_fifo/random_noise/{'self_attention' if getattr(args, 'use_self_attention', False) else 'sam2'}/{p}"
+        if args.eta != 1.0:
+            out += f"/eta{args.eta}"
+        if args.new_video_length != 100:
+            out += f"/{args.new_video_length}frames"
+        if not args.lookahead_denoising:
+            out = out.replace(p, f"{p}/no_lookahead_denoising")
+        if args.num_partitions != 4:
+            out = out.replace(p, f"{p}/n={args.num_partitions}")
+        if args.video_length != 16:
+            out = out.replace(p, f"{p}/f={args.video_length}")
+    else:
+        out = args.output_dir
+    lat = f"results/videocraft_v2_fifo/latents/{args.num_inference_steps}steps/{p}/eta{args.eta}"
+    out, lat = os.path.join(root, out), os.path.join(root, lat)
+    os.makedirs(out, exist_ok=True)
+    os.makedirs(lat, exist_ok=True)
+    return out, lat
+
+
+def frames_to_uint8(batch_tensors):
+    """funcs.py:614-622: [1,3,f,H,W] in [-1,1] -> uint8 [f,H,W,3]"""
+    video = torch.squeeze(batch_tensors, 0) if batch_tensors.dim() == 5 else batch_tensors
+    video = torch.clamp(video.detach().cpu().float(), -1., 1.).permute(1, 0, 2, 3)
+    video = (video + 1.0) / 2.0
+    return (video * 255).to(torch.uint8).permute(0, 2, 3, 1).numpy()
+
+
+def save_gif(batch_tensors, savedir, name, duration_ms=100):
+    """funcs.py:614-628 (imageio.mimsave -> Pillow, which this image has)"""
+    from PIL import Image
+    arr = frames_to_uint8(batch_tensors)
+    imgs = [Image.fromarray(a) for a in arr]
+    path = os.path.join(savedir, f"{name}.gif")
+    imgs[0].save(path, save_all=True, append_images=imgs[1:], duration=duration_ms, loop=0)
+    return path
+
+
+def save_frames(images, savedir, ext="png"):
+    """`{i}.png` per FIFO iteration (funcs.py:362-364); `images` = PIL images or uint8 arrays"""
+    from PIL import Image
+    os.makedirs(savedir, exist_ok=True)
+    for i, im in enumerate(images):
+        (im if hasattr(im, "save") else Image.fromarray(im)).save(os.path.join(savedir, f"{i}.{ext}"))
+
+
+def run_prompts(args, model, embed_text, cond_image_fn=None, mask_fn=None, root=".", uc_emb=None, decode=True, rank=None,
+                num_processes=None, n_iterations=None):
+    """The prompt-mode loop of videocrafter_main.py:176-232 on the drop-in classes.
+
+    embed_text(str) -> [1,77,1024] replaces `model.get_learned_conditioning` (OpenCLIP, out of scope);
+    cond_image_fn(row) -> conditioned-image latents [1,4,1,h,w]; mask_fn(row, shape) -> masks [1,1,Q,h,w] (the
+    Grounded-SAM-2 output).  Rows go to `rank` by `indices[rank::num_processes]`.  Returns {row index: output path}."""
+    rows = load_prompts(args.prompt_file, getattr(args, "prompt_index", None))
+    rank = getattr(args, "rank", 0) if rank is None else rank
+    nproc = getattr(args, "num_processes", 1) if num_processes is None else num_processes
+    h, w = args.height // 8, args.width // 8
+    done = {}
+    for idx in shard_indices(len(rows), rank, nproc):
+        data = rows[idx]
+        out_dir, lat_dir = set_directory(args, data["prompt"], data["conditioned_image_path"], root=root)
+        noise_shape = [1, 4, args.video_length, h, w]
+        fps = torch.tensor([args.fps], device=model.device).long()
+        cond = {"c_crossattn": [embed_text(data["prompt"])], "fps": fps}
+        cached = os.path.exists(f"{lat_dir}/{args.num_inference_steps}.pt") and os.path.exists(f"{lat_dir}/0.pt")
+        if cached:
+            sampler = DDIMSampler(model)
+            sampler.make_schedule(ddim_num_steps=args.num_inference_steps, ddim_eta=args.eta, verbose=False)
+        else:
+            base, sampler, _ = base_ddim_sampling(model, cond, noise_shape, args.num_inference_steps, args.eta,
+                                                  args.unconditional_guidance_scale, uc_emb=uc_emb, latents_dir=lat_dir)
+            if decode and base is not None:
+                save_gif(base, out_dir, "origin")
+        if data["conditioned_prompt"]:
+            cond["c_crossattn"].append(embed_text(data["conditioned_prompt"]))
+        Q = args.num_inference_steps + (args.video_length // 2 if args.lookahead_denoising else 0)
+        cimg = cond_image_fn(data) if cond_image_fn is not None else None
+        masks = mask_fn(data, (1, 1, Q, h, w)) if mask_fn is not None else None
+        frames = fifo_ddim_sampling(args, model, cond, noise_shape, sampler, args.unconditional_guidance_scale, uc_emb=uc_emb,
+                                    latents_dir=lat_dir, conditioned_image=cimg, masks=masks, gamma=data["gamma"],
+                                    decode=decode, n_iterations=n_iterations)
+        keep = frames[-(args.new_video_length // 2):]                        # videocrafter_main.py:228-230
+        if decode:
+            path = save_gif(torch.cat(keep, dim=2), out_dir, "fifo", duration_ms=int(1000 / args.output_fps))
+        else:
+            path = os.path.join(out_dir, "fifo_latents.pt")
+            torch.save(torch.cat(keep, dim=2).cpu(), path)
+        done[idx] = path
+    return done

@@ -1,0 +1,69 @@
+"""CPU: the prompt CSV / rank striding / directory / GIF helpers of moca_video_amd.io against the reference's format
+(`prompts/prompts.csv` header and quoting, funcs.py:506-535; videocrafter_main.py:25-55,179-181)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+CSV = '''prompt,conditioned_object,conditioned_image_path,conditioned_prompt,gamma
+"An astronaut floating in space, wearing a detailed white spacesuit, Earth visible",astronaut,"assets/robot.jpg","the condition is a robot", 2
+"A superhero in a dynamic pose against a city skyline, cape flowing in the wind",superhero,"assets/eagle.jpg","the condition is an eagle",1.5
+plain prompt,obj , assets/x.jpg ,,0.5
+'''
+
+
+def _csv(tmp_path):
+    p = tmp_path / "prompts.csv"
+    p.write_text(CSV)
+    return str(p)
+
+
+def test_load_prompts_format(tmp_path):
+    from moca_video_amd.io import load_prompts
+    rows = load_prompts(_csv(tmp_path))
+    assert len(rows) == 3
+    assert rows[0]["prompt"].startswith("An astronaut floating in space, wearing")          # quoted commas survive
+    assert rows[0] == {"prompt": rows[0]["prompt"], "conditioned_object": "astronaut", "conditioned_image_path": "assets/robot.jpg",
+                       "conditioned_prompt": "the condition is a robot.", "gamma": 2.0}
+    assert rows[1]["gamma"] == 1.5 and rows[2]["conditioned_object"] == "obj" and rows[2]["conditioned_prompt"] == "."
+    assert load_prompts(_csv(tmp_path), prompt_index=1) == [rows[1]]
+    with pytest.raises(ValueError):
+        load_prompts(_csv(tmp_path), prompt_index=3)
+
+
+def test_rank_striding_partitions_every_prompt_once():
+    from moca_video_amd.io import shard_indices
+    for n, world in ((64, 8), (10, 4), (3, 8)):
+        parts = [shard_indices(n, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        assert parts[1] == list(range(n))[1::world]
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_set_directory_convention(tmp_path):
+    from moca_video_amd.io import set_directory
+    a = types.SimpleNamespace(output_dir=None, use_self_attention=False, eta=1.0, new_video_length=100, lookahead_denoising=True,
+                              num_partitions=4, video_length=16, num_inference_steps=64)
+    out, lat = set_directory(a, "a cat", root=str(tmp_path))
+    assert out.endswith("results/videocraft_v2_fifo/random_noise/sam2/a cat")
+    assert lat.endswith("results/videocraft_v2_fifo/latents/64steps/a cat/eta1.0")
+    a.eta, a.new_video_length, a.num_partitions = 0.5, 60, 8
+    out, _ = set_directory(a, "a cat", root=str(tmp_path))
+    assert out.endswith("sam2/a cat/n=8/eta0.5/60frames")
+
+
+def test_gif_and_frame_writers(tmp_path):
+    from PIL import Image
+    from moca_video_amd.fifo import tensor2image
+    from moca_video_amd.io import frames_to_uint8, save_frames, save_gif
+    v = torch.linspace(-1.5, 1.5, 3 * 5 * 8 * 12).reshape(1, 3, 5, 8, 12)
+    u8 = frames_to_uint8(v)
+    assert u8.shape == (5, 8, 12, 3) and u8.dtype == np.uint8 and u8.min() == 0 and u8.max() == 255
+    path = save_gif(v, str(tmp_path), "clip", duration_ms=100)
+    im = Image.open(path)
+    assert im.n_frames == 5 and im.size == (12, 8)
+    img = tensor2image(v[:, :, [2]])
+    assert np.array_equal(np.asarray(img), u8[2])
+    save_frames([img, u8[0]], str(tmp_path / "frames"))
+    assert Image.open(str(tmp_path / "frames" / "1.png")).size == (12, 8)

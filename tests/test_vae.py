@@ -97,3 +97,45 @@ def test_decode_rejects_bad_inputs():
         m.decode(torch.zeros(1, 4, 5, 8, device="cuda"))
     with pytest.raises(NotImplementedError):
         m.encode(torch.zeros(1, 3, 64, 64, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_prompt_mode_driver_end_to_end(tmp_path):
+    """moca_video_amd.io.run_prompts = the prompt-mode loop of videocrafter_main.py:176-232 on the drop-in classes:
+    CSV -> rank striding -> base DDIM sampling (writes the {0,N}.pt latent cache) -> MoCA FIFO with mask injection ->
+    VAE decode of the emitted frames -> GIF; a second run must find the latent cache and skip the base sampling."""
+    import os
+    import types
+    from PIL import Image
+    from moca_video_amd import DenoiseModel
+    from moca_video_amd.io import run_prompts
+    from helpers import REDUCED
+    dm = DenoiseModel({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": REDUCED},
+                      first_stage_config={"target": "lvdm.models.autoencoder.AutoencoderKL",
+                                          "params": {"embed_dim": 4, "ddconfig": dict(VAE_DD, ch=64), "lossconfig": {"target": "torch.nn.Identity"}}},
+                      scale_factor=0.18215)
+    dm.model.diffusion_model.load_state_dict(state_dict_for(dm.model.diffusion_model, 11), strict=True)
+    dm.first_stage_model.load_state_dict(state_dict_for(dm.first_stage_model, 5), strict=True)
+    dm = dm.cuda()
+    csv = tmp_path / "p.csv"
+    csv.write_text('prompt,conditioned_object,conditioned_image_path,conditioned_prompt,gamma\n'
+                   '"a cat, sitting",cat,assets/a.jpg,"the condition is a dog",2\n'
+                   'second prompt,obj,assets/b.jpg,"the condition is a bird",1.5\n'
+                   'third prompt,obj,assets/c.jpg,"the condition is a fish",1.5\n')
+    args = types.SimpleNamespace(prompt_file=str(csv), prompt_index=None, rank=1, num_processes=2, height=64, width=64, fps=10,
+                                 video_length=16, num_partitions=4, num_inference_steps=64, new_video_length=8,
+                                 lookahead_denoising=True, eta=1.0, unconditional_guidance_scale=12.0, output_dir=None,
+                                 use_self_attention=False, output_fps=10)
+    embed = lambda text: inp("txt:" + text, (1, 77, 128)).cuda()
+    cimg = lambda row: inp("cimg:" + row["conditioned_object"], (1, 4, 1, 8, 8)).cuda()
+    mask = lambda row, shape: (inp("mask:" + row["prompt"], shape) > 0.3).float().cuda()
+    done = run_prompts(args, dm, embed, cimg, mask, root=str(tmp_path), uc_emb=embed(""), n_iterations=6)
+    assert list(done) == [1]                                       # rank 1 of 2 owns row 1 only
+    im = Image.open(done[1])
+    assert im.n_frames == 4 and im.size == (64, 64)                # last new_video_length//2 emitted frames, 8x latents
+    lat = os.path.join(str(tmp_path), "results/videocraft_v2_fifo/latents/64steps/second prompt/eta1.0")
+    assert os.path.exists(lat + "/0.pt") and os.path.exists(lat + "/64.pt")
+    assert os.path.exists(os.path.dirname(done[1]) + "/origin.gif")
+    os.remove(os.path.dirname(done[1]) + "/origin.gif")
+    done2 = run_prompts(args, dm, embed, cimg, mask, root=str(tmp_path), uc_emb=embed(""), n_iterations=2)
+    assert not os.path.exists(os.path.dirname(done2[1]) + "/origin.gif")      # latent cache hit: no base sampling
