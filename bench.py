@@ -32,9 +32,9 @@ sys.path.insert(0, ROOT)
 FLOP_PER_UNET_STEP = 12.581e12      # FlopCounterMode on the reference UNet, [1,4,16,40,64], L=77
 PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
 # L2<->fabric bytes of one batched (B=2) UNet forward launch, from separate rocprofv3 --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE passes over this same command (profiles/r01_pmc_traffic_per_forward.txt; FETCH_SIZE doubled
+# --pmc WRITE_SIZE passes over this same command (profiles/r01_pmc_traffic_per_forward_final.txt; FETCH_SIZE doubled
 # per the gfx950 correction in MI355X_MICROARCH.md; Infinity-Cache hits are included in these counters)
-TRAFFIC_BYTES_PER_LAUNCH = 118.4e9
+TRAFFIC_BYTES_PER_LAUNCH = 113.6e9
 
 FULL = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
             channel_mult=[1, 2, 4, 4], num_head_channels=64, transformer_depth=1, context_dim=1024, use_linear=True,
@@ -266,8 +266,8 @@ def main():
         "achieved_tflops": round(value / world * FLOP_PER_UNET_STEP / 1e12, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH if not concurrent else None,
-                     "kernel": "UNet forward launch sequence (hipGraph of ~1.0k launches; gemm_glds_kernel = implicit-GEMM "
-                               "conv/linear is 72% of it)" + (", two B=1 graphs on two streams" if concurrent else ", batch 2"),
+                     "kernel": "UNet forward launch sequence (hipGraph of ~0.9k launches; the implicit-GEMM conv/linear kernels "
+                               "gemm_w80/gemm_glds/gemm_g4 are 75% of it)" + (", two B=1 graphs on two streams" if concurrent else ", batch 2"),
                      "flop_per_launch": flop_per_launch, "avg_launch_ms": round(avg_launch_ms, 3), "launches": len(unet_ms)},
     }
     if world == 1 and not args.no_fifo:

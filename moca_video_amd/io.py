@@ -65,6 +65,18 @@ def set_directory(args, prompt, conditioned_image_path=None, root="."):
     return out, lat
 
 
+def load_cond_image(path, height, width, device="cuda"):
+    """videocrafter_main.py:89-98: the conditioning image is NOT VAE-encoded in prompt mode -- it is the RGBA image
+    resized to the latent grid (PIL bilinear, as torchvision.transforms.Resize does on a PIL image; the CenterCrop to
+    the same size is a no-op), scaled to [0,1] (ToTensor) and used as a 4-channel latent frame [1,4,1,h/8,w/8]."""
+    import numpy as np
+    from PIL import Image
+    h, w = height // 8, width // 8
+    img = Image.open(path).convert("RGBA").resize((w, h), Image.BILINEAR)
+    t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0)
+    return t.unsqueeze(1).unsqueeze(0).to(device)
+
+
 def frames_to_uint8(batch_tensors):
     """funcs.py:614-622: [1,3,f,H,W] in [-1,1] -> uint8 [f,H,W,3]"""
     video = torch.squeeze(batch_tensors, 0) if batch_tensors.dim() == 5 else batch_tensors

@@ -67,3 +67,16 @@ def test_gif_and_frame_writers(tmp_path):
     assert np.array_equal(np.asarray(img), u8[2])
     save_frames([img, u8[0]], str(tmp_path / "frames"))
     assert Image.open(str(tmp_path / "frames" / "1.png")).size == (12, 8)
+
+
+def test_load_cond_image_is_rgba_resized_to_latent_grid(tmp_path):
+    from PIL import Image
+    from moca_video_amd.io import load_cond_image
+    rgb = (np.arange(96 * 128 * 3) % 251).astype(np.uint8).reshape(96, 128, 3)
+    Image.fromarray(rgb).save(str(tmp_path / "c.png"))
+    t = load_cond_image(str(tmp_path / "c.png"), 320, 512, device="cpu")
+    assert t.shape == (1, 4, 1, 40, 64) and t.dtype == torch.float32
+    assert float(t.min()) >= 0.0 and float(t.max()) <= 1.0
+    assert torch.all(t[0, 3] == 1.0)                         # opaque alpha from convert("RGBA")
+    ref = np.asarray(Image.fromarray(rgb).convert("RGBA").resize((64, 40), Image.BILINEAR), dtype=np.float32) / 255.0
+    assert np.allclose(t[0, :, 0].permute(1, 2, 0).numpy(), ref)
