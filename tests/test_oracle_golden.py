@@ -81,3 +81,20 @@ def test_unet_reduced(case, B):
     y = UO.unet_forward(sd, x, t, ctx, fps=fps)
     assert y.shape == g[case].shape
     assert relerr(y, g[case]) < TOL
+
+
+def test_unet_full_width_cfg0():
+    """The oracle at the full 1.41 B-parameter width against the REAL reference UNet's output on the config[0] shape
+    (`tools/make_golden.py --only full`); ~1.5 min: 46 s of weight generation + two forwards."""
+    import os
+    from helpers import FULL, GOLD
+    if not os.path.exists(os.path.join(GOLD, "unet_full.npz")):
+        pytest.skip("full-width goldens not generated")
+    g = golden("unet_full")
+    sd = state_dict_for(_unet_skeleton(FULL), 11)
+    for case in ("cfg0_uniform", "cfg0_fifo"):
+        L = int(g[case + "__L"])
+        x = inp(f"full.{case}.x", (1, 4, 8, 32, 32))
+        ctx = inp(f"full.{case}.ctx", (1, L, 1024))
+        y = UO.unet_forward(sd, x, torch.from_numpy(g[case + "__t"]), ctx, fps=torch.from_numpy(np.atleast_1d(g[case + "__fps"])))
+        assert relerr(y, g[case]) < TOL, case
