@@ -288,4 +288,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        from moca_video_amd import dist as _mdist
+        _mdist.shutdown()

@@ -100,3 +100,9 @@ def max_over_ranks(x: float, device) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def shutdown():
+    """tear the process group down (every rank, after its last collective; no barrier: a failed rank must not hang the rest)"""
+    if dist.is_initialized():
+        dist.destroy_process_group()
