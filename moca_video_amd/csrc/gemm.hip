@@ -1214,6 +1214,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
     constexpr int NAP = 3;                               // A piece slots per wave (the third one only for waves 0..3)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MOCA_STAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1433,7 +1434,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
     // ---- prologue: NS tiles in flight, fragments of tile 0 in set 0, tile 1 landed ----
 #pragma unroll
     for (int t = 0; t < NS; ++t) issue(min(kt_begin + t, kt_last), t);
+    MOCA_STAMP(1);
     sync_tiles(int_c<NS - 1>{});                     // tile 0 landed
+    MOCA_STAMP(2);
 #pragma unroll
     for (int r = 0; r < NRD; ++r) read_frag(int_c<0>{}, 0, r);
     sync_tiles(int_c<NS - 2>{});                     // tile 1 landed, everyone has read tile 0
@@ -1447,6 +1450,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
     }
     if (i < nk) phase(int_c<0>{}, i);
     sync_tiles(int_c<0>{});            // every DMA (incl. the repeats) and fragment read is done: the ring is free for the epilogue
+    MOCA_STAMP(3);
 
     // ---- epilogue: lane owns 4 consecutive columns n = wave_n*80 + nt*16 + 4*fg + r of row m = wave_m*80 + mt*16 + fr ----
     if (p.splits > 1) {
@@ -1482,6 +1486,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
         }
     }
     __syncthreads();
+    MOCA_STAMP(4);
     constexpr int chunks_per_row = BN / 8;
     constexpr int total_chunks = TM * chunks_per_row;
     for (int idx = tid; idx < total_chunks; idx += 512) {
@@ -1509,6 +1514,16 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
         }
         *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
     }
+    MOCA_STAMP(5);
+#ifdef MOCA_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_stamps[blockIdx.x * STAMP_SLOTS + 6] = hw;
+        g_stamps[blockIdx.x * STAMP_SLOTS + 7] = xcc;
+    }
+#endif
 }
 
 template <int AMODE, bool FAST>

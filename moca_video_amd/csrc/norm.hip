@@ -185,54 +185,72 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const half_t* __restrict__
     }
 }
 
-// ---- LayerNorm: one wavefront per row, row kept in registers -------------------
-template <int MAXCH>  // max 16-byte chunks per lane
+// ---- LayerNorm: one wavefront per row, row kept in registers; every wave keeps LN_ROWS rows in flight ------
+// (one row per wave leaves a CU with ~20 KB of loads in flight -- 3.6 TB/s chip-wide at C = 320; with four rows per
+//  wave the loads of all four are issued before the first reduction)
+template <int MAXCH, int LN_ROWS>  // max 16-byte chunks per lane; rows per wave (4 when there are enough rows to fill the chip)
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int M, int C, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= M) return;
+    const int row0 = (blockIdx.x * 4 + wave) * LN_ROWS;
+    if (row0 >= M) return;
     const int nch = C / 8;
-    const half_t* xr = x + (int64_t)row * C;
-    half8v v[MAXCH];
-    float s = 0.f;
+    half8v v[LN_ROWS][MAXCH];
 #pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nch) {
-            v[i] = *reinterpret_cast<const half8v*>(xr + ch * 8);
+    for (int r = 0; r < LN_ROWS; ++r) {
+        const int row = min(row0 + r, M - 1);            // (rows past the end repeat the last row; their store is skipped)
+        const half_t* xr = x + (int64_t)row * C;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+        for (int i = 0; i < MAXCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) v[r][i] = *reinterpret_cast<const half8v*>(xr + ch * 8);
         }
     }
-    s = wave_sum(s);
-    const float mean = s / (float)C;
-    float q = 0.f;
+    float mean[LN_ROWS], rstd[LN_ROWS];
 #pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nch) {
+    for (int r = 0; r < LN_ROWS; ++r) {
+        float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = (float)v[i][j] - mean; q += d * d; }
+        for (int i = 0; i < MAXCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += (float)v[r][i][j];
+            }
         }
+        s = wave_sum(s);
+        mean[r] = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = (float)v[r][i][j] - mean[r]; q += d * d; }
+            }
+        }
+        q = wave_sum(q);
+        rstd[r] = rsqrtf(q / (float)C + eps);
     }
-    q = wave_sum(q);
-    const float rstd = rsqrtf(q / (float)C + eps);
-    half_t* yr = y + (int64_t)row * C;
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch * 8), b1 = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
-            half8v o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[j] = (half_t)(((float)v[i][j] - mean) * rstd * g0[j] + b0[j]);
-                o[4 + j] = (half_t)(((float)v[i][4 + j] - mean) * rstd * g1[j] + b1[j]);
+            for (int r = 0; r < LN_ROWS; ++r) {
+                if (row0 + r < M) {
+                    half8v o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = (half_t)(((float)v[r][i][j] - mean[r]) * rstd[r] * g0[j] + b0[j]);
+                        o[4 + j] = (half_t)(((float)v[r][i][4 + j] - mean[r]) * rstd[r] * g1[j] + b1[j]);
+                    }
+                    *reinterpret_cast<half8v*>(y + (int64_t)(row0 + r) * C + ch * 8) = o;
+                }
             }
-            *reinterpret_cast<half8v*>(yr + ch * 8) = o;
         }
     }
 }
@@ -307,14 +325,24 @@ extern "C" int moca_layernorm_f16(const void* x, void* y, const float* gamma, co
     if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || C % 8) return MOCA_E_BADARG;
     const int nch = C / 8;
     hipStream_t st = moca_stream(stream);
-    const dim3 grid((M + 3) / 4), block(256);
     const half_t* xi = reinterpret_cast<const half_t*>(x);
     half_t* yo = reinterpret_cast<half_t*>(y);
-    if (nch <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, xi, yo, gamma, beta, M, C, eps);
-    else if (nch <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, xi, yo, gamma, beta, M, C, eps);
-    else if (nch <= 192) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, xi, yo, gamma, beta, M, C, eps);
-    else if (nch <= 320) hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, st, xi, yo, gamma, beta, M, C, eps);
-    else return MOCA_E_BADARG;
+    const dim3 block(256);
+#define MOCA_LN(MAXCH, ROWS) hipLaunchKernelGGL((layernorm_kernel<MAXCH, ROWS>), dim3((M + 4 * ROWS - 1) / (4 * ROWS)), block, 0, st, xi, yo, gamma, beta, M, C, eps)
+    if (M >= 16384) {
+        if (nch <= 64) MOCA_LN(1, 4);
+        else if (nch <= 128) MOCA_LN(2, 4);
+        else if (nch <= 192) MOCA_LN(3, 4);
+        else if (nch <= 320) MOCA_LN(5, 4);
+        else return MOCA_E_BADARG;
+    } else {
+        if (nch <= 64) MOCA_LN(1, 1);
+        else if (nch <= 128) MOCA_LN(2, 1);
+        else if (nch <= 192) MOCA_LN(3, 1);
+        else if (nch <= 320) MOCA_LN(5, 1);
+        else return MOCA_E_BADARG;
+    }
+#undef MOCA_LN
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

@@ -151,7 +151,8 @@ def test_groupnorm(Fr, HW, C, fps, silu, eps, path, monkeypatch):
     check(y, ref, TOL16, "groupnorm")
 
 
-@pytest.mark.parametrize("M,C", [(500, 320), (333, 640), (200, 1280), (64, 512), (10, 2560)])
+@pytest.mark.parametrize("M,C", [(500, 320), (333, 640), (200, 1280), (64, 512), (10, 2560),
+                                 (16390, 320), (16385, 1280), (20001, 2560)])     # >= 16384 rows: four rows per wave (+ tails)
 def test_layernorm(M, C):
     x = (rnd(M, C) * 2 + 0.5).half()
     g = rnd(C, dtype=torch.float32) * 0.2 + 1.0

@@ -10,10 +10,11 @@ import numpy as np, torch
 import bench_gemm as B
 from moca_video_amd import lib as L
 B.ops.set_stream(None)
+B.FILTER = []          # (bench_gemm filters by argv; this tool passes a shape key instead)
 which = sys.argv[1] if len(sys.argv) > 1 else "qkv0"
 shapes = {"qkv0": lambda: B.linear(0, 320, 960), "geglu0": lambda: B.linear(0, 320, 1280, geglu=True),
           "lin0": lambda: B.linear(0, 320, 320), "ff2_0": lambda: B.linear(0, 1280, 320), "conv0": lambda: B.conv(0, 320, 320),
-          "conv2": lambda: B.conv(2, 1280, 1280)}
+          "conv2": lambda: B.conv(2, 1280, 1280), "conv1": lambda: B.conv(1, 640, 640), "qkv1": lambda: B.linear(1, 640, 1920)}
 dt = shapes[which]()
 torch.cuda.synchronize()
 lib = L.load()
