@@ -1372,13 +1372,18 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
         for (int j = 0; j < PPW; ++j) dma_piece(kt, slot, j);
     };
 
+    const int fr = lane & 15, fg = lane >> 4;
+    // accumulators start from the bias of their 4 columns (n = wave_n*80 + nt*16 + 4*fg + r): the epilogue is then a pure
+    // fp32 -> fp16 conversion.  With split-k the bias is added once, by the reduce kernel.
     f32x4 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && p.splits == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + wave_n * 80 + nt * 16 + 4 * fg);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
+    }
 
-    const int fr = lane & 15, fg = lane >> 4;
     // fragment byte offsets inside a slot; tile rows advance in steps of 16, which leaves the swizzle term unchanged
     const int swz = (fg ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
     const int a_off0 = (wave_m * 80 + fr) * RB + swz;
@@ -1474,15 +1479,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = wave_n * 80 + nt * 16 + 4 * fg;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int row = wave_m * 80 + mt * 16 + fr;
-            half4v h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[mt][nt][r] + bv[r]);
-            *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = h;
+            *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = __builtin_convertvector(acc[mt][nt], half4v);
         }
     }
     __syncthreads();
