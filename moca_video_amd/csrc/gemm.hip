@@ -1200,9 +1200,10 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
 // Pipeline: k-tiles of 32 (64-byte LDS rows, swizzle and DMA image of g4), 5-slot direct-to-LDS ring of 30 KiB tiles,
 // DMA five tiles ahead; fragments double-buffered in registers: phase i runs the 25 MFMAs of tile i from set (i & 1)
 // while the 10 ds_reads of tile i+1 fill the other set and this wave's 4 DMA instructions of tile i+5 go out,
-// hand-interleaved; one counted s_waitcnt + s_barrier per phase.  Every phase issues exactly 4 DMA instructions per
-// wave (past the end of the k range the last tile is fetched again into a slot nobody reads; the two left-over W
-// pieces are fetched twice), so one vmcnt immediate is right for every wave in every phase.
+// hand-interleaved; one counted s_waitcnt + s_barrier per phase.  k-tiles are fetched in pairs by the even phases (8 DMA
+// instructions per wave, none in odd phases) so that both 64-byte halves of a 128-byte line are requested together; every
+// wave issues the same number (past the end of the k range the last pair is fetched again into slots nobody reads; the two
+// left-over W pieces are fetched twice), so the two vmcnt immediates (even / odd phase) are right for every wave.
 // =====================================================================================
 template <int AMODE, bool FAST>
 __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params p) {
@@ -1347,17 +1348,17 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
             return ok ? Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + c : zero;
         }
     };
-    auto a_src = [&](int kt, int g) -> const half_t* {
-        if constexpr (fast) return a_base[g] + a_koff;
+    auto a_src = [&](int kt, int g, int odd) -> const half_t* {     // odd = 1: the second k-tile of the pair begin_tile() was called for
+        if constexpr (fast) return a_base[g] + a_koff + odd * KS;
         else return slow_src(kt, g);
     };
-    // DMA instruction j (0..3) of this wave for absolute k-tile kt into ring slot `slot`
-    auto dma_piece = [&](int kt, int slot, int j) {
+    // DMA instruction j (0..3) of this wave for absolute k-tile kt (= pair base + odd) into ring slot `slot`
+    auto dma_piece = [&](int kt, int slot, int j, int odd) {
         const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
         if (j < 2) {
-            __builtin_amdgcn_global_load_lds((glb_ptr)a_src(kt, j), sa + (j * 8 + wave) * 1024, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)a_src(kt, j, odd), sa + (j * 8 + wave) * 1024, 16, 0, 0);
         } else if (j == 2) {
-            const half_t* sA = a_src(kt, 2);
+            const half_t* sA = a_src(kt, 2, odd);
             const half_t* sw = w_row[0] + kt * KS;
             const half_t* src = flex_is_a ? sA : sw;
             const lds_ptr dst = flex_is_a ? sa + (16 + (wave & 3)) * 1024 : sa + A_BYTES + w_piece0 * 1024;
@@ -1366,10 +1367,17 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
             __builtin_amdgcn_global_load_lds((glb_ptr)(w_row[1] + kt * KS), sa + A_BYTES + w_piece1 * 1024, 16, 0, 0);
         }
     };
-    auto issue = [&](int kt, int slot) {
-        begin_tile(kt);
+    // k-tiles are fetched in PAIRS (2m, 2m+1): the two 64-byte halves of every 128-byte line of A and W are requested back
+    // to back, so the second one merges with / hits behind the first in the vector L1.  (Fetched one k-tile per phase, the
+    // second half came ~1 us later, after 30 KiB of other lines had gone through the 32 KiB L1: every line crossed the
+    // L2 -> L1 path twice.)
+    auto issue_pair = [&](int kt_even, int slot_even, int slot_odd) {
+        begin_tile(kt_even);
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) dma_piece(kt, slot, j);
+        for (int j = 0; j < PPW; ++j) {
+            dma_piece(kt_even, slot_even, j, 0);
+            dma_piece(kt_even + 1, slot_odd, j, 1);
+        }
     };
 
     const int fr = lane & 15, fg = lane >> 4;
@@ -1401,14 +1409,16 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n * PPW) : "memory");
         __builtin_amdgcn_s_barrier();
     };
-    const int kt_last = kt_begin + nk - 1;
-    int s_cur = 0, s_nxt = 1;          // ring slots of tiles i and i+1 (tile i's slot is where tile i+NS goes)
+    const int kt_last_pair = kt_begin + nk - 2;          // nk is even: the last (even, odd) pair of this block's k range
+    int s_cur = 0, s_nxt = 1;          // ring slots of tiles i and i+1
     constexpr int NMMA = MT * NT, NRD = MT + NT;
-    // phase i: MFMAs of tile i from fragment set S; reads of tile i+1 into the other set; DMA of tile i+NS into tile i's slot
+    // phase i: MFMAs of tile i from fragment set S = i & 1; reads of tile i+1 into the other set; EVEN phases also issue the
+    // pair (i+4, i+5): tile i+4 goes to the slot of tile i-1, tile i+5 to the slot of tile i (both fully read by now).
     auto phase = [&](auto set_tag, int i) {
         constexpr int S = decltype(set_tag)::value;
-        const int ktn = min(kt_begin + i + NS, kt_last);
-        begin_tile(ktn);
+        const int ktn = min(kt_begin + i + 4, kt_last_pair);
+        const int s_prev = s_cur == 0 ? NS - 1 : s_cur - 1;
+        if constexpr (S == 0) begin_tile(ktn);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < NMMA; ++j) {
@@ -1423,12 +1433,17 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (j % 6 == 3 && j / 6 < PPW) {
-                __builtin_amdgcn_sched_barrier(0);
+            if constexpr (S == 0) {
+                if (j % 3 == 1 && j / 3 < 2 * PPW) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int q = j / 3;                       // 0..7: piece q>>1 of the even tile, then of its odd partner
+                    __builtin_amdgcn_sched_barrier(0);
 #ifndef W80_NO_DMA
-                dma_piece(ktn, s_cur, j / 6);
+                    if (q & 1) dma_piece(ktn + 1, s_cur, q >> 1, 1);
+                    else dma_piece(ktn, s_prev, q >> 1, 0);
 #endif
-                __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1436,24 +1451,25 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
         s_nxt = (s_nxt + 1 == NS) ? 0 : s_nxt + 1;
     };
 
-    // ---- prologue: NS tiles in flight, fragments of tile 0 in set 0, tile 1 landed ----
-#pragma unroll
-    for (int t = 0; t < NS; ++t) issue(min(kt_begin + t, kt_last), t);
+    // ---- prologue: tiles 0..3 (two pairs) in flight, fragments of tile 0 in set 0 ----
+    // The DMA instructions of a pair are issued interleaved (even piece j, odd piece j, ...), so a pair lands as a unit:
+    // the waits count whole pairs (8 instructions per wave).
+    issue_pair(kt_begin, 0, 1);
+    issue_pair(min(kt_begin + 2, kt_last_pair), 2, 3);
     MOCA_STAMP(1);
-    sync_tiles(int_c<NS - 1>{});                     // tile 0 landed
+    sync_tiles(int_c<2>{});                          // pair (0, 1) landed; pair (2, 3) may fly
     MOCA_STAMP(2);
 #pragma unroll
     for (int r = 0; r < NRD; ++r) read_frag(int_c<0>{}, 0, r);
-    sync_tiles(int_c<NS - 2>{});                     // tile 1 landed, everyone has read tile 0
-    // after phase i (which issued tile i+NS) tile i+2 must have landed: tiles i+3 .. i+NS stay in flight
-    int i = 0;
-    for (; i + 1 < nk; i += 2) {
+    sync_tiles(int_c<2>{});                          // everyone has read tile 0 (its slot is reused by phase 0's DMA)
+    // even phase i issues pair (i+4, i+5) and then needs tile i+2: pair (i+2, i+3) complete, the new pair may fly;
+    // the odd phase i+1 issues nothing and needs tile i+3, which landed with its partner
+    for (int i = 0; i < nk; i += 2) {
         phase(int_c<0>{}, i);
-        sync_tiles(int_c<NS - 2>{});
+        sync_tiles(int_c<2>{});
         phase(int_c<1>{}, i + 1);
-        sync_tiles(int_c<NS - 2>{});
+        sync_tiles(int_c<2>{});
     }
-    if (i < nk) phase(int_c<0>{}, i);
     sync_tiles(int_c<0>{});            // every DMA (incl. the repeats) and fragment read is done: the ring is free for the epilogue
     MOCA_STAMP(3);
 
