@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     const int m0 = tile_m * TM, n0 = tile_n * BN;
 
     const int nk_total = 2 * ((p.K + 63) / 64);        // 64-deep units -> even
-    const int kts = (nk_total + p.splits - 1) / p.splits;
+    const int kts = 2 * (((p.K + 63) / 64 + p.splits - 1) / p.splits);   // 64-deep units, as the host sizes the splits -> even
     const int kt_begin = split * kts;
     const int nk = min(kt_begin + kts, nk_total) - kt_begin;
 
@@ -1004,12 +1004,12 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
             return ok ? Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + c : zero;
         }
     };
-    // DMA piece j (0..3: A, 4..5: W) of tile kt into ring slot `slot`
-    auto dma_piece = [&](int kt, int slot, int j) {
+    // DMA piece j (0..3: A, 4..5: W) of tile kt (= the tile begin_tile() was called for, + odd) into ring slot `slot`
+    auto dma_piece = [&](int kt, int slot, int j, int odd) {
         const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
         if (j < 4) {
             const half_t* src;
-            if constexpr (fast) src = a_base[j] + a_koff;
+            if constexpr (fast) src = a_base[j] + a_koff + odd * KS;
             else src = slow_src(kt, j);
             __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (j * 4 + wave) * 1024, 16, 0, 0);
         } else {
@@ -1017,10 +1017,15 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
             __builtin_amdgcn_global_load_lds((glb_ptr)(w_row[g] + kt * KS), sa + A_BYTES + (g * 4 + wave) * 1024, 16, 0, 0);
         }
     };
-    auto issue = [&](int kt, int slot) {
-        begin_tile(kt);
+    // k-tiles travel in (even, odd) pairs: the two 64-byte halves of every 128-byte line are requested back to back
+    // (see gemm_w80_kernel); the pair's 12 DMA instructions are interleaved, so a pair lands as a unit
+    auto issue_pair = [&](int kt_even, int slot_even, int slot_odd) {
+        begin_tile(kt_even);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) dma_piece(kt, slot, j);
+        for (int j = 0; j < 6; ++j) {
+            dma_piece(kt_even, slot_even, j, 0);
+            dma_piece(kt_even + 1, slot_odd, j, 1);
+        }
     };
 
     f32x4 acc[MT][NT];
@@ -1047,32 +1052,33 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     // wave on the same SIMD (the two blocks of a CU run out of phase), not by a second register set --
     // 128 accumulator + 48 fragment registers leave room for two blocks per CU.
     half8v af[MT], bf[NT];
-    // n_after = DMA groups allowed to stay in flight (each 6 instructions of this wave)
-    auto sync = [&](int n_after) {
-        if (n_after >= 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
     int s0 = 0, s1 = 1, s2 = 2;                 // ring slots of tiles i, i+1, i+2 (rotating registers, no modulo)
-    // phase i: read tile i's fragments, 32 MFMAs with the 6 DMA pieces of tile i+2 in the gaps (its slot held
-    // tile i-1, whose reads every wave finished before the barrier that ended phase i-1)
-    auto phase = [&](auto issue_tag, int i) {
-        constexpr bool do_issue = decltype(issue_tag)::value;
+    const int kt_last_pair = kt_begin + nk - 2;  // nk is even
+    // phase i: read tile i's fragments, 32 MFMAs.  EVEN phases also issue the pair (i+2, i+3): tile i+2 into the slot of
+    // tile i-1, tile i+3 into tile i's own slot -- hence the barrier after the fragment reads (every wave has tile i in
+    // registers before any wave's DMA overwrites it).  The pair must be complete at the end of the following odd phase.
+    auto phase = [&](auto even_tag, int i) {
+        constexpr bool even = decltype(even_tag)::value;
         const char* cur = smem + s0 * STAGE;
-        const int kt2 = kt_begin + i + 2;
-        if constexpr (do_issue) begin_tile(kt2);
+        const int kt2 = min(kt_begin + i + 2, kt_last_pair);
+        if constexpr (even) begin_tile(kt2);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const half8v*>(cur + a_off[mt]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const half8v*>(cur + b_off[nt]);
+        if constexpr (even) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < NMMA; ++j) {
             const int mt = j / NT, nt = j % NT;
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);   // D^T: lane = row m
-            if constexpr (do_issue) {
-                if ((j & 3) == 3 && (j >> 2) < 6) {
-                    dma_piece(kt2, s2, j >> 2);
+            if constexpr (even) {
+                if (j % 5 == 2 && j / 5 < 6) {              // after MFMA 2, 7, ..., 27: piece j/5 of both tiles of the pair
+                    dma_piece(kt2, s2, j / 5, 0);
+                    dma_piece(kt2 + 1, s0, j / 5, 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1081,21 +1087,19 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
         { const int t = s0; s0 = s1; s1 = s2; s2 = t; }
     };
 
-    // ---- prologue: two tiles in flight ----
-    if (nk > 0) issue(kt_begin, 0);
-    if (nk > 1) issue(kt_begin + 1, 1);
-    if (nk > 0) sync(nk > 1 ? 1 : 0);             // tile 0 landed
-    int i = 0;
-    for (; i + 2 < nk; ++i) {
+    // ---- prologue: pair (0, 1) ----
+    issue_pair(kt_begin, 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int i = 0; i < nk; i += 2) {
         phase(yes_t{}, i);
-        sync(1);                                   // tile i+1 landed (tile i+2 may fly); everyone has read tile i
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile i+1 landed with its partner; everyone is past tile i's MFMAs
+        __builtin_amdgcn_s_barrier();
+        phase(no_t{}, i + 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // pair (i+2, i+3) complete
+        __builtin_amdgcn_s_barrier();
     }
-    for (; i < nk; ++i) {
-        phase(no_t{}, i);
-        if (i + 1 < nk) sync(0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // all fragment reads done before the ring is reused by the epilogue
+    // (the last barrier also ends every fragment read: the ring is free for the epilogue)
 
     // ---- epilogue (same scheme as the 8-wave kernel): lane owns 4 consecutive columns of row
     //      m = wave_m*128 + mt*16 + fr: column n = wave_n*64 + nt*16 + 4*fg + r ----
