@@ -1439,7 +1439,6 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
             }
             if constexpr (S == 0) {
                 if (j % 3 == 1 && j / 3 < 2 * PPW) {
-                    constexpr int dummy = 0; (void)dummy;
                     const int q = j / 3;                       // 0..7: piece q>>1 of the even tile, then of its odd partner
                     __builtin_amdgcn_sched_barrier(0);
 #ifndef W80_NO_DMA
