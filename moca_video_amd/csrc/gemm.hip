@@ -1673,11 +1673,13 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     // g4 (4 waves, two blocks per CU) wins where the epilogue is VALU-heavy and K is short (GEGLU at C = 320 / 640:
     // one block's erf-GELU epilogue runs under the other block's MFMAs, -5 % on the same device); the 8-wave kernel's
     // deeper pipeline wins everywhere else (K >= 1280: 1137 vs 880 TFLOP/s).  MOCA_GEMM_G4=0/2 forces never/always.
-    static const int g4_mode = [] { const char* e = getenv("MOCA_GEMM_G4"); return e ? atoi(e) : 1; }();
+    const char* e_g4 = getenv("MOCA_GEMM_G4");      // read per call (tests / A-B runs flip it inside one process)
+    const int g4_mode = e_g4 ? atoi(e_g4) : 1;
     const bool use_g4 = !(p.flags & MOCA_EP_OUT_F32) && (g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640));
     // w80 (320 x 160 tiles, 80 x 80 wave tiles): every non-GEGLU contraction whose N is a multiple of 160 and whose
     // 320-row tiles fill the chip.  MOCA_GEMM_W80=0 disables it (A/B against the 256-row kernel), 2 drops the tile-count rule.
-    static const int w80_mode = [] { const char* e = getenv("MOCA_GEMM_W80"); return e ? atoi(e) : 1; }();
+    const char* e_w80 = getenv("MOCA_GEMM_W80");
+    const int w80_mode = e_w80 ? atoi(e_w80) : 1;
     const int tiles320 = ((p.M + 319) / 320) * (p.N / 160);
     const bool use_w80 = w80_mode && p.N % 160 == 0 && !geglu && !(p.flags & (MOCA_EP_OUT_F32 | MOCA_FORCE_SMALL_TILE)) &&
                          p.M > 160 && (tiles320 * p.splits >= 200 || w80_mode == 2);

@@ -243,3 +243,64 @@ def test_timestep_embedding_and_silu_rows():
     o = torch.empty(6, 128, dtype=torch.float16, device=DEV)
     ops.silu_add_rows(a, 1, b, 3, o, rows=6, Cn=128, silu=True)
     check(o, F.silu(a.float() + b.float().repeat_interleave(3, 0)), TOL16, "silu_add_rows")
+
+
+# ---------------------------------------------------------------- GEMM: randomized sweep over every big kernel
+def _sweep_cases(n, seed):
+    import random
+    r = random.Random(seed)
+    out = []
+    for _ in range(n):
+        mode = r.choice(["linear", "linear", "conv", "tconv"])
+        N = r.choice([160, 320, 480, 640, 128, 256])
+        splits = r.choice([1, 1, 1, 2, 3])
+        if mode == "linear":
+            M, K = r.randint(161, 1500), r.choice([64, 72, 128, 320, 328, 640, 1000, 1280, 2048])
+            out.append((mode, M, N, K, splits, r.random() < 0.5, (0, 0, 0, 0)))
+        elif mode == "conv":
+            Fr, H, W, C = r.randint(1, 4), r.randint(5, 14), r.randint(5, 16), r.choice([8, 64, 128, 192, 320])
+            out.append((mode, Fr * H * W, N, 9 * C, splits, r.random() < 0.5, (Fr, H, W, C)))
+        else:
+            B, T, HW, C = r.randint(1, 2), r.choice([4, 8, 16]), r.randint(6, 60), r.choice([64, 128, 320])
+            out.append((mode, B * T * HW, N, 3 * C, splits, r.random() < 0.5, (B, T, HW, C)))
+    return out
+
+
+@pytest.mark.parametrize("kernel,env", [("w80", {"MOCA_GEMM_W80": "2"}), ("glds", {"MOCA_GEMM_W80": "0", "MOCA_GEMM_G4": "0"}),
+                                        ("g4", {"MOCA_GEMM_W80": "0", "MOCA_GEMM_G4": "2"})])
+def test_gemm_random_sweep_forced_kernels(kernel, env, monkeypatch):
+    """30 seeded random shapes per kernel family (forced through the env switches): linear / conv3x3 / temporal conv,
+    M tails, K % 64 != 0 (slow gather path), split-k, residual.  The kernels hand data over through counted vmcnt waits;
+    this sweep is there to trip a mis-counted wait, which a handful of fixed shapes can miss."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for ci, (mode, M, N, K, splits, with_res, geo) in enumerate(_sweep_cases(30, {"w80": 1, "glds": 2, "g4": 3}[kernel])):
+        res = rnd(M, N) if with_res else None
+        b = rnd(N, dtype=torch.float32)
+        if mode == "linear":
+            a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+            pw = ops.pack_linear(w, b)
+            kw = {}
+            ref = a.float() @ w.float().t() + b
+        elif mode == "conv":
+            Fr, H, W, C = geo
+            x = rnd(Fr, C, H, W)
+            w = rnd(N, C, 3, 3, scale=(9 * C) ** -0.5)
+            pw = ops.pack_conv3x3(w, b)
+            a = nhwc(x).reshape(M, C)
+            kw = dict(mode=L.MOCA_A_CONV3X3, conv=(C, H, W, H, W, 1, 0))
+            ref = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(M, N)
+        else:
+            B, T, HW, C = geo
+            x = rnd(B, C, T, HW, 1)
+            w = rnd(N, C, 3, 1, 1, scale=(3 * C) ** -0.5)
+            pw = ops.pack_tconv3(w, b)
+            a = x.permute(0, 2, 3, 4, 1).reshape(M, C).contiguous()
+            kw = dict(mode=L.MOCA_A_TCONV3, tconv=(C, T, HW))
+            ref = F.conv3d(x.float(), w.float(), b, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(M, N)
+        if res is not None:
+            ref = ref + res.float()
+        out = torch.empty(M, pw.N, dtype=torch.float16, device=DEV)
+        ws = torch.empty(splits * M * pw.N, dtype=torch.float32, device=DEV) if splits > 1 else None
+        ops.gemm(a, pw, out, M=M, residual=res, splits=splits, splitk_ws=ws, **kw)
+        check(out[:, :N], ref, TOL16, f"{kernel} case {ci}: {mode} M={M} N={N} K={K} splits={splits} res={with_res}")
