@@ -77,6 +77,33 @@ def load_cond_image(path, height, width, device="cuda"):
     return t.unsqueeze(1).unsqueeze(0).to(device)
 
 
+def load_masks(mask_dir, num_frames, height, width, device="cuda", ext=("png", "npy")):
+    """Mask-producer interface: precomputed Grounded-SAM-2 / DAVIS masks from disk instead of the
+    segmentation models.  `mask_dir/{i}.png` (8-bit, > 127 = object) or `{i}.npy` ([n,H,W] or [H,W]) per frame i; a
+    missing file = no detection for that frame.  Masks are resized (nearest) to the latent grid.  Returns the list the
+    `sam_masks=` argument of `DDIMSampler.ddim_step` takes; `torch.stack` of single-mask frames gives `davis_masks`."""
+    import numpy as np
+    from PIL import Image
+    h, w = height // 8, width // 8
+    out = []
+    for i in range(num_frames):
+        m = None
+        for e in ext:
+            path = os.path.join(mask_dir, f"{i}.{e}")
+            if os.path.exists(path):
+                if e == "npy":
+                    a = np.load(path).astype(np.float32)
+                    a = a[None] if a.ndim == 2 else a
+                    m = torch.stack([torch.from_numpy(np.asarray(Image.fromarray((x > 0.5).astype(np.uint8) * 255)
+                                                                .resize((w, h), Image.NEAREST), dtype=np.float32) / 255.0) for x in a])
+                else:
+                    im = Image.open(path).convert("L").resize((w, h), Image.NEAREST)
+                    m = (torch.from_numpy(np.asarray(im, dtype=np.float32)) > 127).float()[None]
+                break
+        out.append(None if m is None else m.to(device))
+    return out
+
+
 def frames_to_uint8(batch_tensors):
     """funcs.py:614-622: [1,3,f,H,W] in [-1,1] -> uint8 [f,H,W,3]"""
     video = torch.squeeze(batch_tensors, 0) if batch_tensors.dim() == 5 else batch_tensors

@@ -237,17 +237,67 @@ class DDIMSampler(object):
         return self.ddim_step(latents, noise_pred, indices, cond_image, target, ts, use_self_attention=use_self_attention,
                               davis_masks=davis_masks, noise=noise)
 
+    @staticmethod
+    def calculate_iou(masks1, masks2):
+        """ddim.py:905-943: mean IoU over zip(masks1, masks2) of the masks binarised at 0.5 (both empty -> 1.0)"""
+        m1, m2 = torch.as_tensor(masks1) > 0.5, torch.as_tensor(masks2) > 0.5
+        ious = []
+        for a, b in zip(m1, m2):
+            b = b.to(a.device)
+            inter, union = torch.logical_and(a, b).sum().float(), torch.logical_or(a, b).sum().float()
+            ious.append(torch.tensor(1.0) if union == 0 else (inter / union).cpu())
+        return torch.stack(ious).mean().item() if ious else 0.0
+
+    def select_sam_masks(self, sam_masks, ts, H, W, device):
+        """The mask bookkeeping of `_apply_segmentation` (ddim.py:739-903) for PRECOMPUTED candidate masks (the
+        Grounded-SAM-2 producer itself is out of scope).  `sam_masks[i]` = the masks SAM would return for frame i, shape
+        [n_i, H, W] (None / empty = no box detected).  Per frame, in order, with `pre_masks` starting at None (:391):
+          * only frames with timestep <= 300 are touched (:592);
+          * no detection -> previous masks, or nothing if there are none yet (:788-793);
+          * IoU(new, previous) < 0.5 -> previous masks (:804-807);
+          * masks are applied in order; one covering > 80 % of the frame RESETS what the earlier ones injected (:820-822).
+        Returns (effective [f, H*W] float mask, frame mask index [f] with -1 = no injection)."""
+        f = len(ts)
+        eff = torch.zeros(f, H * W, dtype=torch.float32, device=device)
+        midx = np.full((f,), -1, dtype=np.int32)
+        pre = None
+        for i in range(f):
+            if float(ts[i]) > 300:
+                continue
+            cand = sam_masks[i] if i < len(sam_masks) else None
+            if cand is not None:
+                cand = torch.as_tensor(cand, device=device).float().reshape(-1, H, W)
+            if cand is None or cand.shape[0] == 0:
+                if pre is None:
+                    continue                                   # returns (pred_x0, None): pre_masks stays None
+                masks = pre
+            else:
+                masks = cand
+                if pre is not None and self.calculate_iou(masks, pre) < 0.5:
+                    masks = pre
+            pre = masks
+            cur = torch.zeros(H, W, dtype=torch.bool, device=device)
+            for m in masks:
+                if m.sum() > 0.8 * m.numel():
+                    cur.zero_()                                # modified_pred_x0 = pred_x0 (:821)
+                    continue
+                cur |= m > 0.5
+            eff[i] = cur.reshape(-1).float()
+            midx[i] = i
+        return eff, midx
+
     @torch.no_grad()
     def ddim_step(self, sample, noise_pred, indices, cond_image, target, ts, gamma=0.5, use_self_attention=False,
-                  davis_masks=None, noise=None):
+                  davis_masks=None, noise=None, sam_masks=None):
         """ddim.py:377-649.  Returns (x_prev, pred_x0); `self.momentum` persists across calls (:395-397).
 
         Mask semantics follow the reference bit for bit, quirk included: its plotting loops
         reuse the loop variable `i` (ddim.py:477,502,533), so for every frame i >= 1 the mask
         frame consulted at :565-567 is ceil(H/4)-1, not i (frame 0 uses mask frame 0).  Set
         `self.reference_index_quirk = False` for the per-frame mask the code evidently meant.
-        Without `davis_masks` the reference would call Grounded-SAM-2 (out of scope): no
-        injection happens here."""
+        Without `davis_masks` the reference calls Grounded-SAM-2 per frame (out of scope); pass what it would
+        return as `sam_masks` (list over frames of [n,H,W] candidate masks) to get that branch's behaviour
+        (`select_sam_masks`: t <= 300 only, IoU fallback, > 80 % reset, factor 2); with neither, no injection."""
         b, Cc, f, H, W = sample.shape
         device = sample.device
         sample, noise_pred = _f32c(sample), _f32c(noise_pred)
@@ -280,6 +330,13 @@ class DDIMSampler(object):
         x_prev, pred_x0 = torch.empty_like(sample), torch.empty_like(sample)
         coef_d = torch.from_numpy(coef).to(device)
         mask_d = cond_d = midx_d = enh_d = ws = None
+        if davis_masks is None and sam_masks is not None and not use_self_attention:
+            if b != 1:
+                raise ValueError("the segmentation branch squeezes the batch axis (ddim.py:746-747): batch must be 1")
+            eff, midx = self.select_sam_masks(sam_masks, ts_np, H, W, device)
+            davis_masks = eff.reshape(1, 1, f, H, W)            # same injection kernel, other factor / frame selection
+            Fm = f
+            enh[:] = 2.0                                        # enhancement_factor = 2 (:847)
         if davis_masks is not None:
             mask_d = _f32c(davis_masks.to(device)).reshape(b, 1, Fm, H * W)
             if cond_image is None:

@@ -52,13 +52,58 @@ def p_sample_ddim(sch, x, e_c, e_u, cfg, index, noise, use_scale=True):
 
 
 # ---- ddim.py:377-649 (arithmetic only) ---------------------------------------------------------
+def _calculate_iou(masks1, masks2):
+    """ddim.py:905-943"""
+    masks1, masks2 = torch.as_tensor(masks1) > 0.5, torch.as_tensor(masks2) > 0.5
+    ious = []
+    for m1, m2 in zip(masks1, masks2):
+        inter = torch.logical_and(m1, m2).sum().float()
+        union = torch.logical_or(m1, m2).sum().float()
+        ious.append(1.0 if union == 0 else (inter / union).item())
+    return torch.tensor(ious).mean().item()
+
+
+def _apply_segmentation(pred_x0, cond_image, candidate_masks, pre_masks):
+    """`_apply_segmentation` (ddim.py:739-903) with the Grounded-SAM-2 output replaced by `candidate_masks` ([n,H,W], or
+    None / empty for "no box detected").  PARITY UNPINNED for this branch: the reference cannot run it offline (external
+    models), so no golden exists; the restatement follows the source line by line."""
+    if candidate_masks is None or len(candidate_masks) == 0:            # :788-793
+        if pre_masks is None:
+            return pred_x0, None
+        masks = pre_masks
+    else:
+        masks = torch.as_tensor(candidate_masks).float()
+        if pre_masks is not None and _calculate_iou(masks, pre_masks) < 0.5:   # :804-807
+            masks = pre_masks
+    modified = pred_x0.clone()
+    for mask in masks:
+        if mask.sum() > 0.8 * mask.numel():                              # :820-822
+            modified = pred_x0
+            continue
+        # The reference expands the mask to [1,C,H,W] and lets torch.where broadcast it against the 5-D pred_x0
+        # [1,C,1,H,W]: the result is the injected frame REPLICATED C times along the frame axis ([1,C,C,H,W]) -- harmless
+        # there because every caller discards pred_x0 (funcs.py:320,336).  Restated here without the replication: one frame.
+        m = mask.reshape(1, 1, 1, *mask.shape[-2:]).expand(-1, pred_x0.shape[1], -1, -1, -1)
+        ci = cond_image
+        if ci is None:
+            ci = torch.zeros_like(pred_x0)
+        else:
+            ci = ci.reshape(ci.shape[0], ci.shape[1], 1, *ci.shape[-2:])
+            if ci.shape[1] != pred_x0.shape[1]:
+                ci = torch.cat([ci, torch.ones_like(ci[:, :1])], dim=1)
+        modified = torch.where(m > 0.5, ci * 2, modified)                 # enhancement_factor = 2 (:847,897-901)
+    return modified, masks
+
+
 def ddim_step(sch, sample, noise_pred, indices, cond_image, ts, noises, momentum, davis_masks=None, gamma=0.5, beta=0.9,
-              reference_index_quirk=True):
-    """noises: list of per-frame [b,c,1,h,w]; momentum: [b,c,f,h,w] state, updated in place. Returns (x_prev, pred_x0)."""
+              reference_index_quirk=True, sam_masks=None):
+    """noises: list of per-frame [b,c,1,h,w]; momentum: [b,c,f,h,w] state, updated in place. Returns (x_prev, pred_x0).
+    sam_masks: optional list over frames of candidate masks [n,H,W] standing in for Grounded-SAM-2 (:592-606)."""
     b, _, f, H, W = sample.shape
     size = (b, 1, 1, 1, 1)
     x_prevs, pred_x0s = [], []
     prev_frame = None
+    pre_masks = None                                                     # :391
     for i, index in enumerate(indices):
         x = sample[:, :, [i]]
         e_t = noise_pred[:, :, [i]]
@@ -87,6 +132,8 @@ def ddim_step(sch, sample, noise_pred, indices, cond_image, ts, noises, momentum
             enhancement_factor = 1.5 if timestep <= 300 else 1.0        # :582
             if mask.sum() != 0:                                         # :585
                 pred_x0 = torch.where(mask > 0.5, cond_image * enhancement_factor, pred_x0)
+        elif sam_masks is not None and timestep <= 300:                 # :592-606
+            pred_x0, pre_masks = _apply_segmentation(pred_x0, cond_image, sam_masks[i] if i < len(sam_masks) else None, pre_masks)
         pred_x0 = (1 - gamma) * pred_x0 + gamma * noise                 # :609
         x_prevs.append(x_prev)
         pred_x0s.append(pred_x0)

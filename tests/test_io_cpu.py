@@ -80,3 +80,16 @@ def test_load_cond_image_is_rgba_resized_to_latent_grid(tmp_path):
     assert torch.all(t[0, 3] == 1.0)                         # opaque alpha from convert("RGBA")
     ref = np.asarray(Image.fromarray(rgb).convert("RGBA").resize((64, 40), Image.BILINEAR), dtype=np.float32) / 255.0
     assert np.allclose(t[0, :, 0].permute(1, 2, 0).numpy(), ref)
+
+
+def test_load_masks_from_disk(tmp_path):
+    from PIL import Image
+    from moca_video_amd.io import load_masks
+    m = np.zeros((64, 128), np.uint8)
+    m[16:48, 32:96] = 255
+    Image.fromarray(m).save(str(tmp_path / "0.png"))
+    np.save(str(tmp_path / "2.npy"), np.stack([m > 0, np.zeros_like(m) > 0]).astype(np.float32))
+    out = load_masks(str(tmp_path), 4, 64, 128, device="cpu")
+    assert out[1] is None and out[3] is None
+    assert out[0].shape == (1, 8, 16) and out[2].shape == (2, 8, 16)
+    assert out[0].sum() == 4 * 8 and torch.equal(out[0][0], out[2][0]) and out[2][1].sum() == 0

@@ -127,3 +127,61 @@ def test_freeinit_linearity_and_identity():
     lpf = torch.rand(16, 40, 64, device="cuda").expand(shp)
     a = freq_mix_3d(x, n, lpf); b = freq_mix_3d(2 * x, 2 * n, lpf)
     assert relerr(b, 2 * a) < 2e-5
+
+
+def _sam_candidates(F, H, W, seq):
+    """per-frame candidate masks exercising every rule of `_apply_segmentation` (with the expected "pred_x0 changed" flags).
+    seq 0: no detection before any mask; a detection; a close one (taken); a deviating one (IoU < 0.5 -> previous reused);
+           no detection (-> previous); an oversized mask first (skipped) then a small one; a re-ordered pair (IoU over the
+           zipped pairs < 0.5 -> previous pair reused).
+    seq 1: a small mask followed by an oversized one (wipes it: no injection, but it becomes the previous set); no detection
+           (-> that set again: still nothing); a close single mask (IoU with the first of the previous pair high -> taken)."""
+    def rect(y0, y1, x0, x1):
+        m = torch.zeros(H, W)
+        m[y0:y1, x0:x1] = 1.0
+        return m
+    big = torch.ones(H, W)
+    if seq == 0:
+        cands = [None, rect(2, 10, 3, 12)[None], rect(2, 10, 4, 12)[None], rect(11, 15, 0, 5)[None], None,
+                 torch.stack([big, rect(1, 5, 1, 6)]), torch.stack([rect(1, 5, 1, 6), big])]
+        changed = [False, True, True, True, True, True, True]
+    else:
+        cands = [torch.stack([rect(2, 10, 3, 12), big]), None, rect(2, 10, 4, 12)[None]]
+        changed = [False, False, True]
+    # frames past the list have no detection -> the previous masks are reused (:790-793): they keep being injected
+    return (cands + [None] * F)[:F], (changed + [True] * F)[:F]
+
+
+@pytest.mark.parametrize("seq", [0, 1])
+def test_ddim_step_sam_mask_branch_vs_oracle(seq):
+    """The segmentation branch of ddim_step (ddim.py:592-606, 739-903) on precomputed candidate masks: HIP path vs the
+    oracle's line-by-line restatement (no reference golden can exist for this branch: it needs Grounded-SAM-2)."""
+    from oracle import sampler_oracle as SO
+    from test_oracle_sampler import BUF
+    s, _ = _sampler(64)
+    sch = SO.make_schedule(BUF, 64, 1.0)
+    C, F, H, W = 4, 8, 16, 16
+    x, e, noises, cond, _ = ddim_step_inputs("small", C, F, H, W, 0)
+    cands, expect_changed = _sam_candidates(F, H, W, seq)
+    indices = np.arange(3, 3 + F)                                      # low timesteps: every frame has t <= 300
+    ts = torch.as_tensor(np.asarray(s.ddim_timesteps)[indices]).long()
+    assert int(ts.max()) <= 300
+    mom = torch.zeros(1, C, F, H, W)
+    xp_ref, p0_ref = SO.ddim_step(sch, x, e, indices, cond[:, :, 0], ts, noises, mom, sam_masks=cands)
+    xp, p0 = s.ddim_step(x.cuda(), e.cuda(), indices, cond.cuda(), "object.", ts.cuda(), noise=torch.cat(noises, 2).cuda(),
+                         sam_masks=[None if c is None else c.cuda() for c in cands])
+    assert relerr(xp.cpu(), xp_ref) < TOL
+    assert relerr(p0.cpu(), p0_ref) < TOL
+    s2, _ = _sampler(64)
+    _, p0_plain = s2.ddim_step(x.cuda(), e.cuda(), indices, cond.cuda(), "object.", ts.cuda(), noise=torch.cat(noises, 2).cuda())
+    changed = [(p0[:, :, i] - p0_plain[:, :, i]).abs().max().item() > 1e-6 for i in range(F)]
+    assert changed == expect_changed, changed
+    # frames above t = 300 are never touched by this branch (:592)
+    hi = np.arange(40, 40 + F)
+    ts_hi = torch.as_tensor(np.asarray(s.ddim_timesteps)[hi]).long()
+    assert int(ts_hi.min()) > 300
+    s3, s4 = _sampler(64)[0], _sampler(64)[0]
+    _, a = s3.ddim_step(x.cuda(), e.cuda(), hi, cond.cuda(), "object.", ts_hi.cuda(), noise=torch.cat(noises, 2).cuda(),
+                        sam_masks=[None if c is None else c.cuda() for c in cands])
+    _, b = s4.ddim_step(x.cuda(), e.cuda(), hi, cond.cuda(), "object.", ts_hi.cuda(), noise=torch.cat(noises, 2).cuda())
+    assert torch.equal(a, b)
