@@ -62,6 +62,10 @@ typedef struct moca_gemm_params {
     int32_t HW;            /* pixels per frame (A_TCONV3)                                   */
     int32_t flags;         /* MOCA_EP_*                                                     */
     int32_t splits;        /* split-K factor (>=1)                                          */
+    int32_t nopad_lo;      /* A_CONV3X3, stride 2: 1 = no padding at the top/left, one row/column at the
+                              bottom/right (F.pad(x,(0,1,0,1)) + conv pad 0: ae_modules.py Downsample.forward);
+                              0 = the symmetric padding 1 of every other 3x3 conv                              */
+    int32_t reserved_;
 } moca_gemm_params;
 
 /* Replaces F.conv2d 3x3 (openaimodel3d.py:152,177,66-70,96-106,376,531),
@@ -138,6 +142,11 @@ int moca_silu_add_rows_f16(const void* a, int32_t div_a, const void* b, int32_t 
 int moca_channel_mix_f16(const void* z, int32_t z_is_f32, const float* w, const float* bias, void* out,
                          int32_t B, int32_t Cin, int32_t T, int32_t HW, int32_t Cout, int32_t Cpad,
                          float inv_scale, void* stream);
+/* out[n][z][hw] = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise), moments [n][2z][hw] = (mean | logvar) fp32;
+ * noise NULL = the mode.  Replaces DiagonalGaussianDistribution.sample/.mode (lvdm/distributions.py:24-40,66-67) and the
+ * `scale_factor *` of get_first_stage_encoding (ddpm3d.py:458-465). */
+int moca_gaussian_sample_f32(const float* moments, const float* noise, float* out, int32_t n, int32_t z, int32_t hw,
+                             float scale, void* stream);
 /* p[r][0:N] = softmax(scale * s[r][0:N]) for R rows, fp32 logits in, fp16 probabilities out; N, lds, ldp % 4 == 0.
  * Replaces `w_ = w_ * c**-0.5; softmax(w_, dim=2)` of AttnBlock.forward (ae_modules.py:66-68). */
 int moca_softmax_rows_f16(const float* s, void* p, int64_t R, int32_t N, int64_t lds, int64_t ldp, float scale,

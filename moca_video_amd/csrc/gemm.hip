@@ -97,8 +97,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const moca_gemm_params
             const int f = mm / ohw, rem = mm - f * ohw;
             const int oy = rem / p.outW, ox = rem - oy * p.outW;
             row_off[i] = (int64_t)f * p.inH * p.inW;
-            row_y[i] = oy * p.stride - 1;
-            row_x[i] = ox * p.stride - 1;
+            row_y[i] = oy * p.stride - 1 + p.nopad_lo;
+            row_x[i] = ox * p.stride - 1 + p.nopad_lo;
         } else {  // TCONV3
             const int frame = mm / p.HW;
             row_off[i] = mm;
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
                 oy = rem / p.outW; ox = rem - oy * p.outW;
             }
             row_off[g] = (int64_t)f * p.inH * p.inW;
-            row_y[g] = oy * p.stride - 1;
-            row_x[g] = ox * p.stride - 1;
+            row_y[g] = oy * p.stride - 1 + p.nopad_lo;
+            row_x[g] = ox * p.stride - 1 + p.nopad_lo;
         } else {
             int frame, pix, vid, t;
             if (p.M < (1 << 24)) {
@@ -925,8 +925,8 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
                 oy = rem / p.outW; ox = rem - oy * p.outW;
             }
             row_off[g] = (int64_t)f * p.inH * p.inW;
-            row_y[g] = oy * p.stride - 1;
-            row_x[g] = ox * p.stride - 1;
+            row_y[g] = oy * p.stride - 1 + p.nopad_lo;
+            row_x[g] = ox * p.stride - 1 + p.nopad_lo;
         } else {
             int frame, pix, vid, t;
             if (p.M < (1 << 24)) {
@@ -1274,8 +1274,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
                 oy = rem / p.outW; ox = rem - oy * p.outW;
             }
             row_off[g] = (int64_t)f * p.inH * p.inW;
-            row_y[g] = oy * p.stride - 1;
-            row_x[g] = ox * p.stride - 1;
+            row_y[g] = oy * p.stride - 1 + p.nopad_lo;
+            row_x[g] = ox * p.stride - 1 + p.nopad_lo;
         } else {
             int frame, pix, vid, t;
             if (p.M < (1 << 24)) {
@@ -1652,6 +1652,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
         case MOCA_A_CONV3X3:
             if (p.C % 8 || p.K != 9 * p.C || p.inH <= 0 || p.inW <= 0 || p.outH <= 0 || p.outW <= 0) return MOCA_E_BADARG;
             if (p.stride != 1 && p.stride != 2) return MOCA_E_BADARG;
+            if (p.nopad_lo != 0 && (p.nopad_lo != 1 || p.stride != 2 || p.up || (p.inH | p.inW) & 1)) return MOCA_E_BADARG;
             if (p.up && (p.stride != 1 || p.outH != 2 * p.inH || p.outW != 2 * p.inW)) return MOCA_E_BADARG;
             if (!p.up && p.stride == 1 && (p.outH != p.inH || p.outW != p.inW)) return MOCA_E_BADARG;
             if (p.stride == 2 && (p.outH != (p.inH - 1) / 2 + 1 || p.outW != (p.inW - 1) / 2 + 1)) return MOCA_E_BADARG;

@@ -103,6 +103,25 @@ inline int grid_for(int64_t total) {
     return (int)g;
 }
 
+// ---- DiagonalGaussianDistribution.sample / .mode (lvdm/distributions.py:24-40) + get_first_stage_encoding's scale_factor
+//      (ddpm3d.py:458-465): moments [n][2z][hw] = (mean | logvar) -> out [n][z][hw]
+__global__ void gaussian_sample_kernel(const float* __restrict__ mom, const float* __restrict__ noise, float* __restrict__ out,
+                                       int n, int z, int hw, float scale) {
+    const int64_t total = (int64_t)n * z * hw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / ((int64_t)z * hw), r = i - b * z * hw;
+        const float mean = mom[b * 2 * z * hw + r];
+        float v = mean;
+        if (noise) {
+            float lv = mom[b * 2 * z * hw + (int64_t)z * hw + r];
+            lv = fminf(fmaxf(lv, -30.0f), 20.0f);
+            const float sd = expf(0.5f * lv);
+            v = mean + sd * noise[i];
+        }
+        out[i] = scale * v;
+    }
+}
+
 }  // namespace
 
 extern "C" int moca_cfg_combine_f32(const float* e_c, const float* e_u, float* out, float scale,
@@ -145,6 +164,17 @@ extern "C" int moca_fifo_ddim_step_f32(const float* sample, const float* eps, co
     hipLaunchKernelGGL(fifo_step_kernel, dim3(grid_for((int64_t)B * C * HW)), dim3(256), 0, st, sample, eps, noise, momentum,
                        x_prev, pred_x0, coef, mask, ws, cond, mask_index, enh, B, C, F, Fm, HW, beta, one_minus_beta,
                        gamma, one_minus_gamma);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_gaussian_sample_f32(const float* moments, const float* noise, float* out, int32_t n, int32_t z, int32_t hw,
+                                        float scale, void* stream) {
+    if (!moments || !out || n <= 0 || z <= 0 || hw <= 0) return MOCA_E_BADARG;
+    const int64_t total = (int64_t)n * z * hw;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gaussian_sample_kernel, dim3(blocks), dim3(256), 0, moca_stream(stream), moments, noise, out, n, z, hw, scale);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

@@ -13,11 +13,16 @@ from .sampler import DDIMSampler
 
 
 def prepare_latents(args, input_path, sampler, model=None, data=None, initial_latents=None, noises=None):
-    """funcs.py:21-82 (non-DAVIS branch): frame j of the queue = sqrt(a_j) z[frame_idx] + sqrt(1-a_j) eps,
-    frame_idx = max(0, j - (N - z.shape[2])); with lookahead the first f/2 frames all use a_0."""
-    if data is not None:
-        raise NotImplementedError("DAVIS frame encoding needs the VAE (out of scope); pass initial_latents")
-    if initial_latents is None:
+    """funcs.py:21-82: frame j of the queue = sqrt(a_j) z[frame_idx] + sqrt(1-a_j) eps, frame_idx = max(0, j - (N - z.shape[2]));
+    with lookahead the first f/2 frames all use a_0.  z = the cached base-sampling latents (`{N}.pt`), `initial_latents`, or --
+    DAVIS mode, `data=(frames [b,3|4,t,H,W], masks)` -- the VAE encoding of the frames (`model.encode_first_stage_2DAE`)."""
+    if data is not None:                                      # DAVIS branch, funcs.py:38-48
+        frames, _masks = data
+        frames = frames.to("cuda")
+        if frames.shape[1] == 4:                              # RGBA -> RGB (:44-45)
+            frames = frames[:, :3]
+        initial_latents = model.encode_first_stage_2DAE(frames)
+    elif initial_latents is None:
         initial_latents = torch.load(input_path + f"/{args.num_inference_steps}.pt")
     initial_latents = initial_latents.to("cuda")
     latents_list = []

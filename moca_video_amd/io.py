@@ -104,6 +104,45 @@ def load_masks(mask_dir, num_frames, height, width, device="cuda", ext=("png", "
     return out
 
 
+def load_davis_data(video_name, davis_root, frame_stride=1, video_size=(40, 64), video_frames=16, sampling_strategy="first",
+                    seed=None):
+    """funcs.py:643-735: frames `JPEGImages/480p/<video>/*.jpg` and masks `Annotations/480p/<video>/*.png` of a DAVIS
+    sequence -> (frames [1,4,T,8h,8w] RGBA in [-1,1], masks [1,1,T,h,w] in {0,1}); `video_size` = the LATENT grid (h, w).
+    Frames are resized with Pillow's LANCZOS (the reference uses cv2.INTER_LANCZOS4; cv2 is not in this image), masks with
+    nearest neighbour; "first" / "random" / "uniform" pick the frame indices as upstream."""
+    import numpy as np
+    from PIL import Image
+    frames_dir = os.path.join(davis_root, "JPEGImages", "480p", video_name)
+    masks_dir = os.path.join(davis_root, "Annotations", "480p", video_name)
+    frame_files = sorted(f for f in os.listdir(frames_dir) if f.endswith(".jpg"))
+    mask_files = sorted(f for f in os.listdir(masks_dir) if f.endswith(".png"))
+    total = len(frame_files)
+    if sampling_strategy == "first":
+        idxs = list(range(min(video_frames, total)))
+    elif sampling_strategy == "random":
+        rng = np.random.default_rng(seed)
+        idxs = sorted(rng.choice(total, size=min(video_frames, total), replace=False).tolist())
+    elif sampling_strategy == "uniform":
+        idxs = list(range(total)) if total <= video_frames else list(range(0, total, max(1, total // video_frames)))[:video_frames]
+    else:
+        raise ValueError(f"Unknown sampling strategy: {sampling_strategy}")
+    H, W = video_size[0] * 8, video_size[1] * 8
+    frames, masks = [], []
+    for i in idxs:
+        fr = Image.open(os.path.join(frames_dir, frame_files[i])).convert("RGBA")
+        if fr.size != (W, H):
+            fr = fr.resize((W, H), Image.LANCZOS)
+        t = torch.from_numpy(np.asarray(fr, dtype=np.uint8).copy()).permute(2, 0, 1).float()
+        frames.append((t / 255. - 0.5) * 2)
+        mk = Image.open(os.path.join(masks_dir, mask_files[i])).convert("L")
+        if mk.size != (video_size[1], video_size[0]):
+            mk = mk.resize((video_size[1], video_size[0]), Image.NEAREST)
+        masks.append(np.asarray(mk, dtype=np.uint8))
+    frames = torch.stack(frames).unsqueeze(0).permute(0, 2, 1, 3, 4).contiguous()
+    masks = torch.tensor(np.stack(masks)).unsqueeze(1).float().unsqueeze(0).permute(0, 2, 1, 3, 4)
+    return frames, (masks > 0).float().contiguous()
+
+
 def frames_to_uint8(batch_tensors):
     """funcs.py:614-622: [1,3,f,H,W] in [-1,1] -> uint8 [f,H,W,3]"""
     video = torch.squeeze(batch_tensors, 0) if batch_tensors.dim() == 5 else batch_tensors

@@ -35,7 +35,7 @@ class GemmParams(C.Structure):
         ("rowadd_div", C.c_int32), ("a_mode", C.c_int32), ("C", C.c_int32),
         ("inH", C.c_int32), ("inW", C.c_int32), ("outH", C.c_int32), ("outW", C.c_int32),
         ("stride", C.c_int32), ("up", C.c_int32), ("T", C.c_int32), ("HW", C.c_int32),
-        ("flags", C.c_int32), ("splits", C.c_int32),
+        ("flags", C.c_int32), ("splits", C.c_int32), ("nopad_lo", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -56,6 +56,7 @@ SIGNATURES = {
     "moca_silu_add_rows_f16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "moca_channel_mix_f16": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "moca_softmax_rows_f16": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _i64, _f32, _vp]),
+    "moca_gaussian_sample_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "moca_cfg_combine_f32": (C.c_int, [_vp, _vp, _vp, _f32, _i64, _vp]),
     "moca_ddim_update_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i64, _vp]),
     "moca_fifo_ddim_step_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

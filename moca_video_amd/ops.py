@@ -130,7 +130,8 @@ def gemm(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd
     p.rowadd_div = rowadd_div
     p.a_mode = mode
     if conv is not None:
-        p.C, p.inH, p.inW, p.outH, p.outW, p.stride, p.up = conv
+        p.C, p.inH, p.inW, p.outH, p.outW, p.stride, p.up = conv[:7]
+        p.nopad_lo = conv[7] if len(conv) > 7 else 0
     if tconv is not None:
         p.C, p.T, p.HW = tconv
     p.flags = (_l.MOCA_EP_GEGLU if pw.geglu else 0) | (_l.MOCA_EP_OUT_F32 if out_f32 else 0)
@@ -208,3 +209,10 @@ def softmax_rows(s, p, *, R, N, scale):
     _l.check(_l.load().moca_softmax_rows_f16(_l.ptr(s), _l.ptr(p), R, N, s.stride(-2), p.stride(-2), scale, _st()),
              "moca_softmax_rows_f16")
     return p
+
+
+def gaussian_sample(moments, noise, out, *, n, z, hw, scale):
+    """out = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise); noise None -> the mode"""
+    _l.check(_l.load().moca_gaussian_sample_f32(_l.ptr(moments), _l.ptr(noise), _l.ptr(out), n, z, hw, scale, _st()),
+             "moca_gaussian_sample_f32")
+    return out

@@ -3,8 +3,7 @@ FIFO frame `[1,4,40,64]` into pixels `[1,3,320,512]` (`scripts/evaluation/funcs.
 `lvdm/models/ddpm3d.py:556-562`, `lvdm/models/autoencoder.py:104-107`, `lvdm/modules/networks/ae_modules.py:466-579`).
 
 Same constructor arguments and `state_dict()` names/shapes as the reference `AutoencoderKL` (encoder parameters are
-declared so that `load_state_dict(strict=True)` of a VideoCrafter2 `first_stage_model.*` checkpoint works; `encode`
-is not on the MoCA hot path and raises).  Nothing of the reference's execution survives: activations are channels-last
+used by `encode`, the DAVIS-video mode's entry, `scripts/evaluation/funcs.py:47-48`; prompt mode only decodes).  Nothing of the reference's execution survives: activations are channels-last
 fp16 `[frame·H·W][C]`, every conv is the implicit-GEMM kernel (the nearest-x2 upsample is folded into the following
 conv's gather), GroupNorm+swish is the HBM-bound norm kernel, and the single-head 512-channel mid attention is three
 GEMMs around a row-softmax kernel:
@@ -26,7 +25,7 @@ from . import ops
 from .plan import _PlanBase
 from .unet import _FMap, _Param
 
-__all__ = ["AutoencoderKL"]
+__all__ = ["AutoencoderKL", "DiagonalGaussianDistribution"]
 
 
 class _ResnetBlock(nn.Module):
@@ -73,6 +72,7 @@ class _Encoder(nn.Module):
 
     def __init__(self, *, ch, ch_mult, num_res_blocks, in_channels, z_channels, double_z=True, **_):
         super().__init__()
+        self.in_channels = in_channels
         self.conv_in = _Param((ch, in_channels, 3, 3), kind="conv")
         in_mult = (1,) + tuple(ch_mult)
         self.down = nn.ModuleList()
@@ -229,6 +229,120 @@ class _VaePlan(_PlanBase):
         return out
 
 
+class _EncPlan(_PlanBase):
+    """recorded encode of `n` RGB frames [n, 3, H, W] -> moments [n, 2*embed_dim, H/8, W/8] (fp32)"""
+
+    def __init__(self, model, n, H, W, in_dtype, device):
+        super().__init__(model, device)
+        self.n, self.H, self.W = n, H, W
+        e = model.encoder
+        down = 2 ** (len(e.down) - 1)
+        self.x_in = torch.empty(n, e.in_channels, H, W, dtype=in_dtype, device=device)
+        self.out = torch.empty(n, 2 * model.embed_dim, H // down, W // down, dtype=torch.float32, device=device)
+        self._build()
+
+    resnet = _VaePlan.resnet
+    attn = _VaePlan.attn
+
+    def _build(self):
+        m, e, P = self.model, self.model.encoder, self.P
+        n, H, W = self.n, self.H, self.W
+        x8 = self.pool.get(n * H * W, 8)
+        self._emit(ops.ncthw_to_nhwc, self.x_in, x8, B=n, Cin=e.in_channels, T=1, HW=H * W, Cpad=8)
+        x = self.conv(_FMap(x8, n, H, W, 8), P[id(e.conv_in)])
+        self._release(x8)
+
+        def step(fn, *a):
+            nonlocal x
+            nx = fn(*a)
+            self._release(x.buf)
+            x = nx
+
+        for i, lvl in enumerate(e.down):                                   # Encoder.forward, ae_modules.py:429-464
+            for blk in lvl.block:
+                step(self.resnet, blk, x)
+            if i != len(e.down) - 1:
+                step(self.down, lvl.downsample, x)
+        step(self.resnet, e.mid.block_1, x)
+        step(self.attn, e.mid.attn_1, x)
+        step(self.resnet, e.mid.block_2, x)
+        g = self.gn(x, P[id(e.norm_out)], fps=1, eps=1e-6, silu=True)
+        self._release(x.buf)
+        o = self.conv(_FMap(g, x.F, x.H, x.W, x.C), P[id(e.conv_out)])   # [M][64]: 2*z_channels real columns
+        self._release(g)
+        q = self.linear(o.buf, o.M, P["quant"])                           # quant_conv 1x1 (autoencoder.py:100)
+        self._release(o.buf)
+        self._emit(ops.nhwc_to_ncthw, q, q.shape[1], self.out, B=n, Cout=2 * m.embed_dim, T=1, HW=o.H * o.W)
+        self._release(q)
+
+    def down(self, mod, x):
+        """Downsample.forward with_conv (ae_modules.py:98-103): F.pad(x, (0,1,0,1)) then a stride-2 3x3 conv without padding"""
+        if x.H % 2 or x.W % 2:
+            raise NotImplementedError("AutoencoderKL.encode needs H and W divisible by 8")
+        M = x.F * (x.H // 2) * (x.W // 2)
+        pw = self.P[id(mod.conv)]
+        out = self._gemm(x.buf, pw, M, mode=_l.MOCA_A_CONV3X3, conv=(x.C, x.H, x.W, x.H // 2, x.W // 2, 2, 0, 1))
+        return _FMap(out, x.F, x.H // 2, x.W // 2, pw.N)
+
+    def run(self, x):
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.x_in.copy_(x, non_blocking=True)
+            handle = self.stream.cuda_stream
+            ops.set_stream(handle)
+            try:
+                self._launch(handle)
+            finally:
+                ops.set_stream(None)
+            out = self.out.clone()
+        self.n_runs += 1
+        out.record_stream(cur)
+        cur.wait_stream(self.stream)
+        return out
+
+
+class DiagonalGaussianDistribution:
+    """lvdm/distributions.py:24-67 over device moments [n, 2z, h, w] (fp32): `.sample(noise=None)`, `.mode()`, `.mean`,
+    `.logvar`, `.std`, `.var`; the arithmetic of sample/mode is one HIP kernel (`moca_gaussian_sample_f32`)."""
+
+    def __init__(self, parameters, deterministic=False):
+        self.parameters = parameters
+        self.deterministic = deterministic
+        self.mean, self._logvar_raw = torch.chunk(parameters, 2, dim=1)
+
+    @property
+    def logvar(self):
+        return torch.clamp(self._logvar_raw, -30.0, 20.0)
+
+    @property
+    def std(self):
+        return torch.zeros_like(self.mean) if self.deterministic else torch.exp(0.5 * self.logvar)
+
+    @property
+    def var(self):
+        return torch.zeros_like(self.mean) if self.deterministic else torch.exp(self.logvar)
+
+    def _draw(self, noise, scale=1.0):
+        n, z2, h, w = self.parameters.shape
+        out = torch.empty(n, z2 // 2, h, w, dtype=torch.float32, device=self.parameters.device)
+        if noise is not None:
+            noise = noise.to(device=out.device, dtype=torch.float32).contiguous()
+        ops.set_stream(None)
+        ops.gaussian_sample(self.parameters.contiguous(), noise, out, n=n, z=z2 // 2, hw=h * w, scale=scale)
+        return out
+
+    def sample(self, noise=None):
+        if self.deterministic:
+            return self._draw(None)
+        if noise is None:
+            noise = torch.randn(self.mean.shape, device=self.parameters.device)
+        return self._draw(noise)
+
+    def mode(self):
+        return self._draw(None)
+
+
 class AutoencoderKL(nn.Module):
     """drop-in for `lvdm.models.autoencoder.AutoencoderKL` (autoencoder.py:13-50) on the decode path"""
 
@@ -262,11 +376,11 @@ class AutoencoderKL(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("moca_video_amd.AutoencoderKL runs on an MI355X only; call .cuda() first (no CPU path)")
         P, d = {}, self.decoder
-        if any(m.cout % 64 or m.cin % 64 for m in d.modules() if isinstance(m, _ResnetBlock)):
+        if any(m.cout % 64 or m.cin % 64 for m in self.modules() if isinstance(m, _ResnetBlock)):
             raise NotImplementedError("decoder channel counts must be multiples of 64 (ch=128 in inference_t2v_512_v2.0.yaml)")
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         conv = lambda m, **kw: ops.pack_conv3x3(m.weight.detach(), m.bias.detach(), device=dev, **kw)
-        for mod in d.modules():
+        for mod in list(d.modules()) + list(self.encoder.modules()):
             if isinstance(mod, _ResnetBlock):
                 P[id(mod.norm1)] = (f32(mod.norm1.weight), f32(mod.norm1.bias))
                 P[id(mod.norm2)] = (f32(mod.norm2.weight), f32(mod.norm2.bias))
@@ -289,11 +403,36 @@ class AutoencoderKL(nn.Module):
         P[id(d.conv_out)] = conv(d.conv_out)
         pq = self.post_quant_conv
         P["post_quant"] = (f32(pq.weight).reshape(pq.weight.shape[0], -1).contiguous(), f32(pq.bias))
+        e = self.encoder
+        P[id(e.conv_in)] = conv(e.conv_in, cpad=8)
+        P[id(e.norm_out)] = (f32(e.norm_out.weight), f32(e.norm_out.bias))
+        P[id(e.conv_out)] = conv(e.conv_out)
+        P["quant"] = ops.pack_conv1x1(self.quant_conv.weight.detach(), self.quant_conv.bias.detach(), device=dev)
         self._packed = P
 
     # ---- reference API -------------------------------------------------------------------
+    @torch.no_grad()
     def encode(self, x, **kwargs):
-        raise NotImplementedError("AutoencoderKL.encode is off the MoCA denoising hot path (SURVEY §8f N1 covers decode)")
+        """autoencoder.py:98-102: x [n, 3, H, W] in [-1, 1] -> DiagonalGaussianDistribution over [n, 2*embed_dim, H/8, W/8]
+        (used by the DAVIS-video mode, funcs.py:47-48; prompt mode never encodes)"""
+        if x.dim() != 4 or x.shape[1] != self.encoder.in_channels:
+            raise ValueError(f"encode expects [n,{self.encoder.in_channels},H,W], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise ValueError("moca_video_amd.AutoencoderKL.encode needs a CUDA (HIP) tensor; there is no CPU path")
+        down = 2 ** (len(self.encoder.down) - 1)
+        if x.shape[2] % down or x.shape[3] % down or ((x.shape[2] // down) * (x.shape[3] // down)) % 64:
+            raise NotImplementedError("H, W must be multiples of 8 and (H/8)*(W/8) a multiple of 64")
+        if self._packed is None:
+            self._pack()
+        outs = []
+        for i in range(0, x.shape[0], self.max_frames_per_launch):
+            xi = x[i:i + self.max_frames_per_launch].contiguous()
+            key = ("enc", xi.shape[0], xi.shape[2], xi.shape[3], xi.dtype)
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = self._plans[key] = _EncPlan(self, xi.shape[0], xi.shape[2], xi.shape[3], xi.dtype, xi.device)
+            outs.append(plan.run(xi))
+        return DiagonalGaussianDistribution(outs[0] if len(outs) == 1 else torch.cat(outs, 0))
 
     @torch.no_grad()
     def decode(self, z, **kwargs):

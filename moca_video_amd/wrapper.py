@@ -125,6 +125,30 @@ class DenoiseModel(nn.Module):
         out = self.first_stage_model.decode(zf, **kwargs)
         return out.reshape(b, t, *out.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()
 
+    def get_first_stage_encoding(self, encoder_posterior, noise=None):
+        """ddpm3d.py:458-465"""
+        from .vae import DiagonalGaussianDistribution
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
+            z = encoder_posterior.sample(noise=noise)
+        elif isinstance(encoder_posterior, torch.Tensor):
+            z = encoder_posterior
+        else:
+            raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
+        return self.scale_factor * z
+
+    @torch.no_grad()
+    def encode_first_stage_2DAE(self, x, noise=None):
+        """ddpm3d.py:496-502: x [b,3,t,H,W] -> latents [b,4,t,H/8,W/8]; the reference encodes (and samples) frame by
+        frame, here all frames go through the recorded encoder together (`noise` [b,4,t,h,w] optionally fixes the draw)."""
+        if self.first_stage_model is None:
+            raise RuntimeError("DenoiseModel was built without first_stage_config")
+        b, c, t, H, W = x.shape
+        post = self.first_stage_model.encode(x.permute(0, 2, 1, 3, 4).reshape(b * t, c, H, W))
+        if noise is not None:
+            noise = noise.permute(0, 2, 1, 3, 4).reshape(b * t, *noise.shape[1:2], *noise.shape[3:])
+        z = self.get_first_stage_encoding(post, noise=noise)
+        return z.reshape(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()
+
     @property
     def device(self):
         return self.betas.device

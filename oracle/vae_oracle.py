@@ -68,3 +68,41 @@ def decode_first_stage_2DAE(sd, z, scale_factor, **kw):
     """ddpm3d.py:556-562: z [b,c,t,h,w] -> [b,3,t,H,W], one frame at a time"""
     z = 1.0 / scale_factor * z
     return torch.cat([decode(sd, z[:, :, i], **kw).unsqueeze(2) for i in range(z.shape[2])], dim=2)
+
+
+def encoder_forward(sd, x, pre="encoder", num_resolutions=4, num_res_blocks=2):
+    """Encoder.forward, ae_modules.py:429-464 (attn_resolutions = [], temb None)"""
+    h = _conv(sd, pre + ".conv_in", x, 1)
+    for lvl in range(num_resolutions):
+        for i in range(num_res_blocks):
+            h = resnet_block(sd, f"{pre}.down.{lvl}.block.{i}", h)
+        if lvl != num_resolutions - 1:                                   # Downsample.forward, :98-103
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = F.conv2d(h, sd[f"{pre}.down.{lvl}.downsample.conv.weight"], sd[f"{pre}.down.{lvl}.downsample.conv.bias"], stride=2)
+    h = resnet_block(sd, pre + ".mid.block_1", h)
+    h = attn_block(sd, pre + ".mid.attn_1", h)
+    h = resnet_block(sd, pre + ".mid.block_2", h)
+    h = _swish(_norm(sd, pre + ".norm_out", h))
+    return _conv(sd, pre + ".conv_out", h, 1)
+
+
+def encode_moments(sd, x, **kw):
+    """AutoencoderKL.encode up to the distribution parameters (autoencoder.py:98-101)"""
+    return _conv(sd, "quant_conv", encoder_forward(sd, x, **kw), 0)
+
+
+def sample_posterior(moments, noise=None):
+    """DiagonalGaussianDistribution.sample / .mode (lvdm/distributions.py:24-40,66-67)"""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    if noise is None:
+        return mean
+    return mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise
+
+
+def encode_first_stage_2DAE(sd, x, scale_factor, noises=None, **kw):
+    """ddpm3d.py:496-502: per frame encode -> sample -> * scale_factor"""
+    out = []
+    for i in range(x.shape[2]):
+        z = sample_posterior(encode_moments(sd, x[:, :, i], **kw), None if noises is None else noises[:, :, i])
+        out.append((scale_factor * z).unsqueeze(2))
+    return torch.cat(out, dim=2)

@@ -93,3 +93,24 @@ def test_load_masks_from_disk(tmp_path):
     assert out[1] is None and out[3] is None
     assert out[0].shape == (1, 8, 16) and out[2].shape == (2, 8, 16)
     assert out[0].sum() == 4 * 8 and torch.equal(out[0][0], out[2][0]) and out[2][1].sum() == 0
+
+
+def test_load_davis_data_layout(tmp_path):
+    from PIL import Image
+    from moca_video_amd.io import load_davis_data
+    fd = tmp_path / "JPEGImages" / "480p" / "bear"
+    md = tmp_path / "Annotations" / "480p" / "bear"
+    fd.mkdir(parents=True); md.mkdir(parents=True)
+    for i in range(20):
+        Image.fromarray(np.full((48, 80, 3), 10 * i, np.uint8)).save(str(fd / f"{i:05d}.jpg"))
+        m = np.zeros((48, 80), np.uint8)
+        m[10:30, 20:50] = i % 3          # palette index: frames with i % 3 == 0 have an empty mask
+        Image.fromarray(m).save(str(md / f"{i:05d}.png"))
+    frames, masks = load_davis_data("bear", str(tmp_path), video_size=(4, 8), video_frames=16)
+    assert frames.shape == (1, 4, 16, 32, 64) and masks.shape == (1, 1, 16, 4, 8)
+    assert float(frames.min()) >= -1.0 and float(frames.max()) <= 1.0 and torch.all(frames[0, 3] == 1.0)
+    assert set(masks.unique().tolist()) <= {0.0, 1.0} and masks[0, 0, 0].sum() == 0 and masks[0, 0, 1].sum() > 0
+    f2, _ = load_davis_data("bear", str(tmp_path), video_size=(4, 8), video_frames=8, sampling_strategy="uniform")
+    assert f2.shape[2] == 8 and abs(float(f2[0, 0, 1].mean()) - ((20 / 255 - 0.5) * 2)) < 0.05    # stride 2 -> frame 2
+    with pytest.raises(ValueError):
+        load_davis_data("bear", str(tmp_path), sampling_strategy="nope")

@@ -47,6 +47,52 @@ def test_oracle_vs_reference_golden(name, ch):
     assert relerr(out, g["out"]) < 2e-5
 
 
+@pytest.mark.parametrize("name,ch", CASES)
+def test_oracle_encode_vs_reference_golden(name, ch):
+    """AutoencoderKL.encode of the real reference: distribution parameters, mode, and scale_factor * sample(fixed noise)"""
+    g = golden(name)
+    sd = state_dict_for(_model(ch), 5)
+    shape = tuple(int(v) for v in g["z_shape"])
+    img, nz = _enc_inputs(name, shape)
+    mom = torch.cat([VO.encode_moments(sd, img[:, :, i]).unsqueeze(2) for i in range(img.shape[2])], 2)
+    assert relerr(mom, g["enc_moments"]) < 2e-5
+    assert relerr(torch.chunk(mom, 2, dim=1)[0], g["enc_mode"]) < 2e-5
+    assert relerr(VO.encode_first_stage_2DAE(sd, img, float(g["scale_factor"]), nz), g["enc_sample"]) < 2e-5
+
+
+def _enc_inputs(name, shape):
+    xs = (1, 3, shape[2], 8 * shape[3], 8 * shape[4])
+    return (inp(name + ":img", xs, seed=5) * 0.5).clamp(-1, 1), inp(name + ":enc_noise", shape, seed=5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,ch", CASES)
+def test_hip_encode_vs_reference_golden(name, ch):
+    """HIP encoder (incl. the asymmetric-padding stride-2 Downsample convs) through AutoencoderKL.encode and
+    DenoiseModel.encode_first_stage_2DAE against the real reference's moments / mode / scaled sample"""
+    from moca_video_amd import DenoiseModel
+    from helpers import REDUCED
+    g = golden(name)
+    shape = tuple(int(v) for v in g["z_shape"])
+    img, nz = _enc_inputs(name, shape)
+    dm = DenoiseModel({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": REDUCED},
+                      first_stage_config={"target": "lvdm.models.autoencoder.AutoencoderKL",
+                                          "params": {"embed_dim": 4, "ddconfig": dict(VAE_DD, ch=ch), "lossconfig": {"target": "torch.nn.Identity"}}},
+                      scale_factor=float(g["scale_factor"]))
+    dm.first_stage_model.load_state_dict(state_dict_for(dm.first_stage_model, 5), strict=True)
+    dm = dm.cuda()
+    frames = img[0].permute(1, 0, 2, 3).contiguous().cuda()                      # [t, 3, H, W]
+    for it in range(3):                                                          # eager, capture, replay
+        post = dm.first_stage_model.encode(frames)
+        mom = post.parameters.cpu().permute(1, 0, 2, 3).unsqueeze(0)             # -> [1, 8, t, h, w]
+        e = relerr(mom, g["enc_moments"])
+        assert e < TOL_HIP, f"{name} pass {it}: moments rel err {e:.3e}"
+    assert relerr(post.mode().cpu().permute(1, 0, 2, 3).unsqueeze(0), g["enc_mode"]) < TOL_HIP
+    z = dm.encode_first_stage_2DAE(img.cuda(), noise=nz.cuda())
+    assert z.shape == shape and relerr(z.cpu(), g["enc_sample"]) < TOL_HIP
+    assert relerr(post.std.cpu(), torch.exp(0.5 * torch.clamp(torch.chunk(post.parameters.cpu(), 2, 1)[1], -30, 20))) < 1e-6
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,ch", CASES)
 def test_hip_decode_vs_reference_golden(name, ch):
@@ -95,8 +141,10 @@ def test_decode_rejects_bad_inputs():
         m.decode(torch.zeros(1, 4, 8, 8))
     with pytest.raises(NotImplementedError):
         m.decode(torch.zeros(1, 4, 5, 8, device="cuda"))
+    with pytest.raises(ValueError):
+        m.encode(torch.zeros(1, 4, 64, 64, device="cuda"))
     with pytest.raises(NotImplementedError):
-        m.encode(torch.zeros(1, 3, 64, 64, device="cuda"))
+        m.encode(torch.zeros(1, 3, 60, 64, device="cuda"))
 
 
 @pytest.mark.gpu
@@ -139,3 +187,34 @@ def test_prompt_mode_driver_end_to_end(tmp_path):
     os.remove(os.path.dirname(done[1]) + "/origin.gif")
     done2 = run_prompts(args, dm, embed, cimg, mask, root=str(tmp_path), uc_emb=embed(""), n_iterations=2)
     assert not os.path.exists(os.path.dirname(done2[1]) + "/origin.gif")      # latent cache hit: no base sampling
+
+
+@pytest.mark.gpu
+def test_prepare_latents_davis_branch_encodes_frames():
+    """funcs.py:38-48: DAVIS mode builds the FIFO queue from the VAE encoding of the video frames (RGBA -> RGB)."""
+    import types
+    from moca_video_amd import DenoiseModel
+    from moca_video_amd.fifo import prepare_latents
+    from moca_video_amd.sampler import DDIMSampler
+    from helpers import REDUCED
+    dm = DenoiseModel({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": REDUCED},
+                      first_stage_config={"target": "lvdm.models.autoencoder.AutoencoderKL",
+                                          "params": {"embed_dim": 4, "ddconfig": dict(VAE_DD, ch=64), "lossconfig": {"target": "torch.nn.Identity"}}},
+                      scale_factor=0.18215)
+    sd = state_dict_for(dm.first_stage_model, 5)
+    dm.first_stage_model.load_state_dict(sd, strict=True)
+    dm = dm.cuda()
+    s = DDIMSampler(dm)
+    s.make_schedule(ddim_num_steps=16, ddim_eta=1.0, verbose=False)
+    args = types.SimpleNamespace(num_inference_steps=16, video_length=8, lookahead_denoising=True)
+    frames = (inp("davis.frames", (1, 4, 8, 64, 64)) * 0.5).clamp(-1, 1)
+    noises = [torch.zeros(1, 4, 1, 8, 8) for _ in range(20)]                 # zero queue noise: queue = sqrt(a_j) * z
+    torch.manual_seed(0)
+    lat = prepare_latents(args, None, s, model=dm, data=(frames, None), noises=noises)
+    assert lat.shape == (1, 4, 20, 8, 8)
+    # posterior mean * scale (the sample noise is random): compare the direction of the first queue frame with the oracle's mode
+    z_mode = VO.encode_first_stage_2DAE(sd, frames[:, :3], 0.18215)
+    a0 = float(s.ddim_alphas[0])
+    got = lat[:, :, 0].cpu() / a0 ** 0.5
+    std = torch.exp(0.5 * torch.clamp(torch.chunk(VO.encode_moments(sd, frames[:, :3, 0]), 2, 1)[1], -30, 20)) * 0.18215
+    assert ((got - z_mode[:, :, 0]).abs() <= 6 * std + 2e-2 * z_mode.abs().max()).all()

@@ -322,7 +322,17 @@ def vae_cases():
             zz = 1.0 / scale * z
             out = torch.cat([ae.decode(zz[:, :, i]).unsqueeze(2) for i in range(zz.shape[2])], dim=2)   # ddpm3d.py:559-560
             print(f"{tag}: {time.time() - t0:.1f}s out {tuple(out.shape)} std {out.std():.3f}")
-            save(tag, ch=np.asarray(ch), z_shape=np.asarray(shape), scale_factor=np.asarray(scale), out=out)
+            # encode side (DAVIS mode, funcs.py:47-48): distribution parameters, the mode and a sample with fixed noise
+            xs = (1, 3, shape[2], 8 * shape[3], 8 * shape[4])
+            img = (inp(tag + ":img", xs, seed=5) * 0.5).clamp(-1, 1)
+            nz = inp(tag + ":enc_noise", shape, seed=5)
+            moms, modes, samples = [], [], []
+            for i in range(xs[2]):
+                post = ae.encode(img[:, :, i])
+                moms.append(post.parameters.unsqueeze(2)); modes.append(post.mode().unsqueeze(2))
+                samples.append((scale * post.sample(noise=nz[:, :, i])).unsqueeze(2))               # ddpm3d.py:465
+            save(tag, ch=np.asarray(ch), z_shape=np.asarray(shape), scale_factor=np.asarray(scale), out=out,
+                 enc_moments=torch.cat(moms, 2), enc_mode=torch.cat(modes, 2), enc_sample=torch.cat(samples, 2))
 
 
 def main():
