@@ -34,7 +34,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X dense fp16 MFMA (MI355X_MICROARCH.m
 # L2<->fabric bytes of one batched (B=2) UNet forward launch, from separate rocprofv3 --pmc FETCH_SIZE and
 # --pmc WRITE_SIZE passes over this same command (profiles/r01_pmc_traffic_per_forward_final.txt; FETCH_SIZE doubled
 # per the gfx950 correction in MI355X_MICROARCH.md; Infinity-Cache hits are included in these counters)
-TRAFFIC_BYTES_PER_LAUNCH = 113.6e9
+TRAFFIC_BYTES_PER_LAUNCH = 112.9e9
 
 FULL = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
             channel_mult=[1, 2, 4, 4], num_head_channels=64, transformer_depth=1, context_dim=1024, use_linear=True,
