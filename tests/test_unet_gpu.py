@@ -152,3 +152,19 @@ def test_unet_full_width_vs_reference_golden():
             y = m(x, t, context=ctx, fps=fps, clean_cond=True, gamma=0.5)
             e = relerr(y.cpu(), torch.from_numpy(g[name]))
             assert e < TOL_UNET, f"{tag}.{name}: rel err {e:.3e}"
+    # size-independent properties at the headline shape [.,4,16,40,64] (no oracle needed):
+    xs = [inp(f"prop.x{i}", (1, 4, 16, 40, 64)).cuda() for i in range(2)]
+    cs = [inp(f"prop.c{i}", (1, 77, 1024)).cuda() for i in range(2)]
+    ts = torch.tensor([981, 20]).cuda()
+    fps = torch.tensor([10, 10]).cuda()
+    single = [m(xs[i], ts[i:i + 1], context=cs[i], fps=fps[i:i + 1]) for i in range(2)]
+    both = m(torch.cat(xs), ts, context=torch.cat(cs), fps=fps)
+    for i in range(2):      # every op is per sample: a batch of two equals two single launches (other tile counts / split-k: tolerance)
+        assert relerr(both[i:i + 1].cpu(), single[i].cpu()) < 1e-2, f"batch consistency sample {i}"      # fp16 noise level: 2-3e-3
+    runs = [m(torch.cat(xs), ts, context=torch.cat(cs), fps=fps) for _ in range(3)]      # eager / capture / replay
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[1], runs[2]) and torch.equal(runs[0], both), "replays must be bit-identical"
+    # FIFO semantics: a per-frame timestep vector that happens to be constant equals the uniform-timestep call
+    t16 = torch.full((16,), 500).cuda()
+    a = m(xs[0], t16, context=cs[0], fps=fps[:1])
+    b = m(xs[0], torch.tensor([500]).cuda(), context=cs[0], fps=fps[:1])
+    assert relerr(a.cpu(), b.cpu()) < 1e-6
