@@ -1,0 +1,114 @@
+"""End-to-end parity of the whole pipelines on the reduced-width UNet: the HIP path driven through the drop-in classes
+(DenoiseModel / DDIMSampler / fifo_ddim_sampling) against the SAME pipelines composed from the oracle's pieces (UNet +
+p_sample_ddim + ddim_step + prepare/shift_latents), with every random draw fixed.  The denoising loop feeds its own output
+back in, so the fp16-storage error of the UNet accumulates: tolerance 6e-2 * max|ref| after 10 CFG steps / 2 FIFO iterations
+(observed ~1e-2), still far below what a wrong coefficient, index or mask would produce (O(1))."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import REDUCED, inp, relerr, state_dict_for  # noqa: E402
+
+TOL = 6e-2
+
+
+@pytest.fixture(scope="module")
+def models():
+    from moca_video_amd import DenoiseModel
+    from oracle import sampler_oracle as SO
+    dm = DenoiseModel({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": REDUCED})
+    sd = state_dict_for(dm.model.diffusion_model, 11)
+    dm.model.diffusion_model.load_state_dict(sd, strict=True)
+    return dm.cuda(), sd, SO.ddpm_buffers()
+
+
+def _oracle_eps(sd, x, t, ctx, uctx, fps, cfg):
+    from oracle import unet_oracle as UO
+    e_c = UO.unet_forward(sd, x, t, ctx, fps=fps)
+    e_u = UO.unet_forward(sd, x, t, uctx, fps=fps)
+    return e_c, e_u
+
+
+def test_base_ddim_sampling_10_steps_vs_oracle(models):
+    """funcs.py:177-241 / ddim.py:109-252: S=10, eta=1, CFG 12, use_scale -- config[0]'s loop at reduced width"""
+    from moca_video_amd.fifo import base_ddim_sampling
+    from oracle import sampler_oracle as SO
+    dm, sd, buf = models
+    S, cfg = 10, 12.0
+    shape = (1, 4, 8, 16, 16)
+    x_T = inp("e2e.xT", shape)
+    ctx, uctx = inp("e2e.ctx", (1, 77, 128)), inp("e2e.uctx", (1, 77, 128))
+    noises = [inp(f"e2e.n{i}", shape) for i in range(S)]
+    fps = torch.tensor([10])
+    # oracle pipeline
+    sch = SO.make_schedule(buf, S, 1.0)
+    img = x_T.clone()
+    for i, step in enumerate(np.flip(sch["ddim_timesteps"])):
+        index = S - i - 1
+        t = torch.full((1,), int(step), dtype=torch.long)
+        e_c, e_u = _oracle_eps(sd, img, t, ctx, uctx, fps, cfg)
+        img, _ = SO.p_sample_ddim(sch, img, e_c, e_u, cfg, index, noises[i])
+    # HIP pipeline through the reference-shaped entry point
+    cond = {"c_crossattn": [ctx.cuda()], "fps": fps.cuda()}
+    _, sampler, samples = base_ddim_sampling(dm, cond, list(shape), S, 1.0, cfg, uc_emb=uctx.cuda(), x_T=x_T.cuda(),
+                                             noises=[n.cuda() for n in noises])
+    assert samples.shape == shape
+    e = relerr(samples.cpu(), img)
+    assert e < TOL, f"base sampling: rel err {e:.3e}"
+
+
+def test_fifo_two_iterations_vs_oracle(models):
+    """funcs.py:243-373: queue of 20 frames (f=8, n=2, lookahead), 2 outer iterations, CFG 12 with two prompts on the cond
+    branch, MoCA ddim_step with DAVIS-style masks, FreeInit shift; every noise draw fixed"""
+    from moca_video_amd.fifo import fifo_ddim_sampling, fifo_windows
+    from moca_video_amd.sampler import DDIMSampler
+    from oracle import freeinit_oracle as FO
+    from oracle import sampler_oracle as SO
+    dm, sd, buf = models
+    args = types.SimpleNamespace(num_inference_steps=16, video_length=8, lookahead_denoising=True, num_partitions=2,
+                                 new_video_length=100)
+    h = w = 8
+    Q, f, n_it, cfg = 20, 8, 2, 12.0
+    nwin = 2 * args.num_partitions
+    lat0 = inp("e2e.queue", (1, 4, Q, h, w))
+    ctx2 = inp("e2e.ctx2", (1, 154, 128))
+    uctx = inp("e2e.uctx", (1, 77, 128))
+    cimg = (inp("e2e.cimg", (1, 4, 1, h, w)) * 0.25 + 0.5).clamp(0, 1)
+    mask = (inp("e2e.mask", (1, 1, Q, h, w)) > 0.3).float()
+    noises = [[inp(f"e2e.fn{i}.{wi}", (1, 4, f, h, w)) for wi in range(nwin)] for i in range(n_it)]
+    shifts = [inp(f"e2e.sh{i}", (1, 4, h, w)) for i in range(n_it)]
+    fps = torch.tensor([10])
+    # ---- oracle pipeline
+    sch = SO.make_schedule(buf, 16, 1.0)
+    ts_all = np.concatenate([np.full((f // 2,), sch["ddim_timesteps"][0]), sch["ddim_timesteps"]])
+    idx_all = np.concatenate([np.full((f // 2,), 0), np.arange(16)])
+    lat, msk = lat0.clone(), mask.clone()
+    mom = torch.zeros(1, 4, f, h, w)
+    frames_ref = []
+    for i in range(n_it):
+        for wi, (s0, mid, e0) in enumerate(fifo_windows(args)):
+            x = lat[:, :, s0:e0].clone()
+            t = torch.as_tensor(ts_all[s0:e0].copy()).long()
+            e_c, e_u = _oracle_eps(sd, x, t, ctx2, uctx, fps, cfg)
+            eps = e_u + cfg * (e_c - e_u)
+            out, _ = SO.ddim_step(sch, x, eps, idx_all[s0:e0], cimg[:, :, 0], t, [noises[i][wi][:, :, [k]] for k in range(f)], mom,
+                                  davis_masks=msk[:, :, s0:e0].clone())
+            lat[:, :, mid:e0] = out[:, :, -(f // 2):]
+        frames_ref.append(lat[:, :, [f // 2]].clone())
+        lat = FO.shift_latents(lat, shifts[i])
+        msk[:, :, :-1] = msk[:, :, 1:].clone()
+    # ---- HIP pipeline
+    s = DDIMSampler(dm)
+    s.make_schedule(16, ddim_eta=1.0, verbose=False)
+    cond = {"c_crossattn": [ctx2[:, :77].cuda(), ctx2[:, 77:].cuda()], "fps": fps.cuda()}
+    frames = fifo_ddim_sampling(args, dm, cond, (1, 4, f, h, w), s, cfg_scale=cfg, uc_emb=uctx.cuda(), latents=lat0.clone().cuda(),
+                                conditioned_image=cimg.cuda(), masks=mask.clone().cuda(), n_iterations=n_it, batch_windows=True,
+                                noises=[[n.cuda() for n in row] for row in noises], shift_noises=[x.cuda() for x in shifts])
+    assert len(frames) == n_it
+    for i in range(n_it):
+        e = relerr(frames[i].cpu(), frames_ref[i])
+        assert e < TOL, f"fifo iteration {i}: rel err {e:.3e}"
