@@ -417,6 +417,126 @@ __device__ __forceinline__ void divmod24(int n, int d, float rd, int& q, int& r)
     else if (r >= d) { r -= d; ++q; }
 }
 
+// ---- A-operand gather addressing shared by the direct-to-LDS kernels (glds, g4, w80) -----------------------------------
+// A lane owns NAP rows of the block tile (one per DMA instruction it issues) and a 16-byte chunk `lch` of the KS-wide k-tile.
+// Fast path (every layer of the UNet except the 4-channel input conv): a k-tile lies inside ONE tap (C % 64 == 0) resp. inside
+// K (K % 64 == 0), so per tile every lane just adds a block-uniform element offset to a per-row base pointer.  Rows that must
+// read zeros (conv halo, t-1/t+1 outside the clip, M tail) have the zero page as base; the zero page is longer than any
+// per-tile offset, so no per-tile select is needed.  Bases are recomputed only when the tap changes (every C/KS tiles).
+// Slow path (input conv with C = 8, odd K): the source of every (row, tile) is computed from scratch.
+template <int AMODE, bool FAST, int NAP, int KS>
+struct AGather {
+    const moca_gemm_params& p;
+    const half_t* Aptr;
+    const half_t* zero;
+    int lch;
+    int64_t row_off[NAP];
+    int row_y[NAP], row_x[NAP];
+    bool row_ok[NAP];
+    const half_t* a_base[NAP];
+    int tap_cur = -1, a_koff = 0, tiles_per_tap;
+
+    __device__ __forceinline__ AGather(const moca_gemm_params& p_, int lch_)
+        : p(p_), Aptr(reinterpret_cast<const half_t*>(p_.a)), zero(g_zero_page), lch(lch_),
+          tiles_per_tap((AMODE == MOCA_A_LINEAR || !FAST) ? (1 << 30) : p_.C / KS) {}
+
+    // row slot g of this lane is output row m (pixel m of the [frame][y][x] raster for the conv modes)
+    __device__ __forceinline__ void init_row(int g, int m) {
+        row_ok[g] = m < p.M;
+        const int mm = row_ok[g] ? m : 0;
+        if (AMODE == MOCA_A_LINEAR) {
+            row_off[g] = (int64_t)mm * p.lda;
+            row_y[g] = row_x[g] = 0;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int ohw = p.outH * p.outW;
+            int f, rem, oy, ox;
+            if (p.M < (1 << 24)) {
+                divmod24(mm, ohw, 1.0f / (float)ohw, f, rem);
+                divmod24(rem, p.outW, 1.0f / (float)p.outW, oy, ox);
+            } else {
+                f = mm / ohw; rem = mm - f * ohw;
+                oy = rem / p.outW; ox = rem - oy * p.outW;
+            }
+            row_off[g] = (int64_t)f * p.inH * p.inW;
+            row_y[g] = oy * p.stride - 1 + p.nopad_lo;
+            row_x[g] = ox * p.stride - 1 + p.nopad_lo;
+        } else {
+            int frame, pix, vid, t;
+            if (p.M < (1 << 24)) {
+                divmod24(mm, p.HW, 1.0f / (float)p.HW, frame, pix);
+                divmod24(frame, p.T, 1.0f / (float)p.T, vid, t);
+            } else {
+                frame = mm / p.HW; t = frame % p.T;
+            }
+            row_off[g] = mm;
+            row_y[g] = t;
+            row_x[g] = 0;
+        }
+    }
+
+    __device__ __forceinline__ void set_tap(int tap) {
+        tap_cur = tap;
+        if (AMODE == MOCA_A_LINEAR) {
+#pragma unroll
+            for (int g = 0; g < NAP; ++g) a_base[g] = row_ok[g] ? Aptr + row_off[g] + lch * 8 : zero;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
+#pragma unroll
+            for (int g = 0; g < NAP; ++g) {
+                int iy = row_y[g] + ky, ix = row_x[g] + kx;
+                const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+                if (p.up) { iy >>= 1; ix >>= 1; }
+                const half_t* src = Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + lch * 8;
+                a_base[g] = ok ? src : zero;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < NAP; ++g) {
+                const int tt = row_y[g] + tap - 1;
+                const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
+                const half_t* src = Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + lch * 8;
+                a_base[g] = ok ? src : zero;
+            }
+        }
+    }
+
+    // block-uniform per-tile state of the DMA stream (fast path): element offset added to every a_base
+    __device__ __forceinline__ void begin_tile(int kt) {
+        if constexpr (FAST) {
+            const int tap = kt / tiles_per_tap;
+            if (tap != tap_cur) set_tap(tap);
+            a_koff = (kt - tap * tiles_per_tap) * KS;
+        }
+    }
+
+    __device__ __forceinline__ const half_t* slow_src(int kt, int g) const {
+        const int k = kt * KS + lch * 8;
+        if (AMODE == MOCA_A_LINEAR) {
+            return (k < p.K && row_ok[g]) ? Aptr + row_off[g] + k : zero;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int tap = k / p.C, c = k - tap * p.C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
+            int iy = row_y[g] + ky, ix = row_x[g] + kx;
+            const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+            if (p.up) { iy >>= 1; ix >>= 1; }
+            return ok ? Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + c : zero;
+        } else {
+            const int tap = k / p.C, c = k - tap * p.C;
+            const int tt = row_y[g] + tap - 1;
+            const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
+            return ok ? Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + c : zero;
+        }
+    }
+
+    // source of row slot g for k-tile kt; `odd` = kt is the second tile of the pair begin_tile() was called for
+    __device__ __forceinline__ const half_t* src(int kt, int g, int odd = 0) const {
+        if constexpr (FAST) return a_base[g] + a_koff + odd * KS;
+        else return slow_src(kt, g);
+    }
+};
+
 typedef __attribute__((address_space(3))) char* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
 
@@ -452,9 +572,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     const int kt_end = min(kt_begin + kts, nk_total);
     const int nk = kt_end - kt_begin;
 
-    const half_t* __restrict__ Aptr = reinterpret_cast<const half_t*>(p.a);
     const half_t* __restrict__ Wptr = reinterpret_cast<const half_t*>(p.w);
-    const half_t* zero = g_zero_page;
 
     // ---- DMA coordinates: instruction g of this wave fills row group q = g*8 + wave,
     //      i.e. rows q*8 + (lane>>3), physical chunk lane&7
@@ -462,43 +580,9 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     const int swz = (((wave * 8 + lrow) >> 1) & 7);   // same for every g (64 g rows apart)
     const int lch = pch ^ swz;                        // logical 16-byte chunk of the k-tile this lane fetches
 
-    int64_t row_off[4];
-    int row_y[4], row_x[4];
-    bool row_ok[4];
+    AGather<AMODE, FAST, 4, BK> ga(p, lch);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int m = m0 + (g * 8 + wave) * 8 + lrow;
-        row_ok[g] = m < p.M;
-        const int mm = row_ok[g] ? m : 0;
-        if (AMODE == MOCA_A_LINEAR) {
-            row_off[g] = (int64_t)mm * p.lda;
-            row_y[g] = row_x[g] = 0;
-        } else if (AMODE == MOCA_A_CONV3X3) {
-            const int ohw = p.outH * p.outW;
-            int f, rem, oy, ox;
-            if (p.M < (1 << 24)) {
-                divmod24(mm, ohw, 1.0f / (float)ohw, f, rem);
-                divmod24(rem, p.outW, 1.0f / (float)p.outW, oy, ox);
-            } else {
-                f = mm / ohw; rem = mm - f * ohw;
-                oy = rem / p.outW; ox = rem - oy * p.outW;
-            }
-            row_off[g] = (int64_t)f * p.inH * p.inW;
-            row_y[g] = oy * p.stride - 1 + p.nopad_lo;
-            row_x[g] = ox * p.stride - 1 + p.nopad_lo;
-        } else {
-            int frame, pix, vid, t;
-            if (p.M < (1 << 24)) {
-                divmod24(mm, p.HW, 1.0f / (float)p.HW, frame, pix);
-                divmod24(frame, p.T, 1.0f / (float)p.T, vid, t);
-            } else {
-                frame = mm / p.HW; t = frame % p.T;
-            }
-            row_off[g] = mm;
-            row_y[g] = t;
-            row_x[g] = 0;
-        }
-    }
+    for (int g = 0; g < 4; ++g) ga.init_row(g, m0 + (g * 8 + wave) * 8 + lrow);
     // W rows of this lane: group q = g*8 + wave (valid while q < B_GROUPS)
     const half_t* w_row[3];
 #pragma unroll
@@ -508,80 +592,12 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
         w_row[g] = Wptr + (int64_t)n * p.ldw + lch * 8;
     }
 
-    // ---- gather addressing ------------------------------------------------------------------
-    // Fast path (every layer of the UNet except the 4-channel input conv): a 64-wide k-tile lies inside
-    // ONE tap (C % 64 == 0) resp. inside K (K % 64 == 0), so per tile every lane just adds a block-uniform
-    // element offset to a per-row base pointer.  Rows that must read zeros (conv halo, t-1/t+1 outside the
-    // clip, M tail) have the zero page as base; the zero page is longer than any per-tile offset, so no
-    // per-tile select is needed.  Bases are recomputed only when the tap changes (every C/64 tiles).
-    constexpr bool fast = FAST;   // host checks: LINEAR K % 64 == 0, CONV/TCONV C % 64 == 0 (both <= 8192)
-    const int tiles_per_tap = (AMODE == MOCA_A_LINEAR || !fast) ? (1 << 30) : p.C / BK;
-    const half_t* a_base[4];
-    int tap_cur = -1;
-
-    auto set_tap = [&](int tap) {
-        tap_cur = tap;
-        if (AMODE == MOCA_A_LINEAR) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) a_base[g] = row_ok[g] ? Aptr + row_off[g] + lch * 8 : zero;
-        } else if (AMODE == MOCA_A_CONV3X3) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int iy = row_y[g] + ky, ix = row_x[g] + kx;
-                const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
-                if (p.up) { iy >>= 1; ix >>= 1; }
-                const half_t* src = Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + lch * 8;
-                a_base[g] = ok ? src : zero;
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int tt = row_y[g] + tap - 1;
-                const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
-                const half_t* src = Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + lch * 8;
-                a_base[g] = ok ? src : zero;
-            }
-        }
-    };
-
-    // per-tile state of the DMA stream (block-uniform): element offset added to every a_base
-    int a_koff = 0;
-    auto begin_tile = [&](int kt) {
-        if constexpr (fast) {
-            const int tap = kt / tiles_per_tap;
-            if (tap != tap_cur) set_tap(tap);
-            a_koff = (kt - tap * tiles_per_tap) * BK;
-        }
-    };
-    // generic (slow) source of row group g for tile kt: input conv (C = 8) and odd K only
-    auto slow_src = [&](int kt, int g) -> const half_t* {
-        const int k = kt * BK + lch * 8;
-        if (AMODE == MOCA_A_LINEAR) {
-            return (k < p.K && row_ok[g]) ? Aptr + row_off[g] + k : zero;
-        } else if (AMODE == MOCA_A_CONV3X3) {
-            const int tap = k / p.C, c = k - tap * p.C;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
-            int iy = row_y[g] + ky, ix = row_x[g] + kx;
-            const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
-            if (p.up) { iy >>= 1; ix >>= 1; }
-            return ok ? Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + c : zero;
-        } else {
-            const int tap = k / p.C, c = k - tap * p.C;
-            const int tt = row_y[g] + tap - 1;
-            const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
-            return ok ? Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + c : zero;
-        }
-    };
     // DMA piece j (0..3: A row groups, 4..6: W row groups) of tile kt into ring slot `slot`
     auto dma_piece = [&](int kt, int slot, int j) {
         const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
         if (j < 4) {
             const half_t* src;
-            if constexpr (fast) src = a_base[j] + a_koff;
-            else src = slow_src(kt, j);
+            src = ga.src(kt, j);
             __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (j * 8 + wave) * 1024, 16, 0, 0);
         } else {
             const int g = j - 4;
@@ -590,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
         }
     };
     auto issue = [&](int kt, int slot) {
-        begin_tile(kt);
+        ga.begin_tile(kt);
 #pragma unroll
         for (int j = 0; j < 7; ++j) dma_piece(kt, slot, j);
     };
@@ -661,7 +677,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
         constexpr bool do_issue = decltype(issue_tag)::value;
         const char* cur = smem + s_cur * STAGE;
         const int kt2 = kt_begin + i + 2, slot2 = s_far;     // ring slot (i-1)%3: every wave passed sync(i-1) after its last read of it
-        if constexpr (do_issue) begin_tile(kt2);
+        if constexpr (do_issue) ga.begin_tile(kt2);
         // ---- P0 ----
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -872,7 +888,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     constexpr int A_BYTES = TM * RB;                   // 16 KiB
     constexpr int B_BYTES = BN * RB;                   // 8 KiB
     constexpr int STAGE = A_BYTES + B_BYTES;           // 24 KiB
-    constexpr int NMMA = MT * NT, NRD = MT + NT;
+    constexpr int NMMA = MT * NT;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -895,51 +911,15 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     const int kt_begin = split * kts;
     const int nk = min(kt_begin + kts, nk_total) - kt_begin;
 
-    const half_t* __restrict__ Aptr = reinterpret_cast<const half_t*>(p.a);
     const half_t* __restrict__ Wptr = reinterpret_cast<const half_t*>(p.w);
-    const half_t* zero = g_zero_page;
 
     // DMA piece = 1 KiB = 16 rows x 64 B: lane -> row (lane>>2), physical chunk lane&3; A piece g of this
     // wave covers rows (g*4 + wave)*16 .. +15 (g = 0..3), W piece g rows (g*4 + wave)*16 .. (g = 0..1)
     const int lrow = lane >> 2, pch = lane & 3;
     const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);     // logical chunk fetched into this lane's slot
-    int64_t row_off[4];
-    int row_y[4], row_x[4];
-    bool row_ok[4];
+    AGather<AMODE, FAST, 4, KS> ga(p, lch);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int m = m0 + (g * 4 + wave) * 16 + lrow;
-        row_ok[g] = m < p.M;
-        const int mm = row_ok[g] ? m : 0;
-        if (AMODE == MOCA_A_LINEAR) {
-            row_off[g] = (int64_t)mm * p.lda;
-            row_y[g] = row_x[g] = 0;
-        } else if (AMODE == MOCA_A_CONV3X3) {
-            const int ohw = p.outH * p.outW;
-            int f, rem, oy, ox;
-            if (p.M < (1 << 24)) {
-                divmod24(mm, ohw, 1.0f / (float)ohw, f, rem);
-                divmod24(rem, p.outW, 1.0f / (float)p.outW, oy, ox);
-            } else {
-                f = mm / ohw; rem = mm - f * ohw;
-                oy = rem / p.outW; ox = rem - oy * p.outW;
-            }
-            row_off[g] = (int64_t)f * p.inH * p.inW;
-            row_y[g] = oy * p.stride - 1 + p.nopad_lo;
-            row_x[g] = ox * p.stride - 1 + p.nopad_lo;
-        } else {
-            int frame, pix, vid, t;
-            if (p.M < (1 << 24)) {
-                divmod24(mm, p.HW, 1.0f / (float)p.HW, frame, pix);
-                divmod24(frame, p.T, 1.0f / (float)p.T, vid, t);
-            } else {
-                frame = mm / p.HW; t = frame % p.T;
-            }
-            row_off[g] = mm;
-            row_y[g] = t;
-            row_x[g] = 0;
-        }
-    }
+    for (int g = 0; g < 4; ++g) ga.init_row(g, m0 + (g * 4 + wave) * 16 + lrow);
     const half_t* w_row[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -947,71 +927,11 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
         w_row[g] = Wptr + (int64_t)n * p.ldw + lch * 8;
     }
 
-    constexpr bool fast = FAST;      // host checks: LINEAR K % 64 == 0, CONV/TCONV C % 64 == 0 (both <= 8192)
-    const int tiles_per_tap = (AMODE == MOCA_A_LINEAR || !fast) ? (1 << 30) : p.C / KS;
-    const half_t* a_base[4];
-    int tap_cur = -1;
-    auto set_tap = [&](int tap) {
-        tap_cur = tap;
-        if (AMODE == MOCA_A_LINEAR) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) a_base[g] = row_ok[g] ? Aptr + row_off[g] + lch * 8 : zero;
-        } else if (AMODE == MOCA_A_CONV3X3) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int iy = row_y[g] + ky, ix = row_x[g] + kx;
-                const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
-                if (p.up) { iy >>= 1; ix >>= 1; }
-                const half_t* src = Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + lch * 8;
-                a_base[g] = ok ? src : zero;
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int tt = row_y[g] + tap - 1;
-                const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
-                const half_t* src = Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + lch * 8;
-                a_base[g] = ok ? src : zero;
-            }
-        }
-    };
-    int a_koff = 0;
-    auto begin_tile = [&](int kt) {
-        if constexpr (fast) {
-            const int tap = kt / tiles_per_tap;
-            if (tap != tap_cur) set_tap(tap);
-            a_koff = (kt - tap * tiles_per_tap) * KS;
-        }
-    };
-    auto slow_src = [&](int kt, int g) -> const half_t* {
-        const int k = kt * KS + lch * 8;
-        if (AMODE == MOCA_A_LINEAR) {
-            return (k < p.K && row_ok[g]) ? Aptr + row_off[g] + k : zero;
-        } else if (AMODE == MOCA_A_CONV3X3) {
-            const int tap = k / p.C, c = k - tap * p.C;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
-            int iy = row_y[g] + ky, ix = row_x[g] + kx;
-            const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
-            if (p.up) { iy >>= 1; ix >>= 1; }
-            return ok ? Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + c : zero;
-        } else {
-            const int tap = k / p.C, c = k - tap * p.C;
-            const int tt = row_y[g] + tap - 1;
-            const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
-            return ok ? Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + c : zero;
-        }
-    };
     // DMA piece j (0..3: A, 4..5: W) of tile kt (= the tile begin_tile() was called for, + odd) into ring slot `slot`
     auto dma_piece = [&](int kt, int slot, int j, int odd) {
         const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
         if (j < 4) {
-            const half_t* src;
-            if constexpr (fast) src = a_base[j] + a_koff + odd * KS;
-            else src = slow_src(kt, j);
-            __builtin_amdgcn_global_load_lds((glb_ptr)src, sa + (j * 4 + wave) * 1024, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)ga.src(kt, j, odd), sa + (j * 4 + wave) * 1024, 16, 0, 0);
         } else {
             const int g = j - 4;
             __builtin_amdgcn_global_load_lds((glb_ptr)(w_row[g] + kt * KS), sa + A_BYTES + (g * 4 + wave) * 1024, 16, 0, 0);
@@ -1020,7 +940,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     // k-tiles travel in (even, odd) pairs: the two 64-byte halves of every 128-byte line are requested back to back
     // (see gemm_w80_kernel); the pair's 12 DMA instructions are interleaved, so a pair lands as a unit
     auto issue_pair = [&](int kt_even, int slot_even, int slot_odd) {
-        begin_tile(kt_even);
+        ga.begin_tile(kt_even);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             dma_piece(kt_even, slot_even, j, 0);
@@ -1061,7 +981,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
         constexpr bool even = decltype(even_tag)::value;
         const char* cur = smem + s0 * STAGE;
         const int kt2 = min(kt_begin + i + 2, kt_last_pair);
-        if constexpr (even) begin_tile(kt2);
+        if constexpr (even) ga.begin_tile(kt2);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const half8v*>(cur + a_off[mt]);
 #pragma unroll
@@ -1240,9 +1160,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
     const int kt_begin = split * kts;
     const int nk = min(kt_begin + kts, nk_total) - kt_begin;
 
-    const half_t* __restrict__ Aptr = reinterpret_cast<const half_t*>(p.a);
     const half_t* __restrict__ Wptr = reinterpret_cast<const half_t*>(p.w);
-    const half_t* zero = g_zero_page;
 
     // DMA piece = 16 rows x 64 B: lane -> row (lane >> 2), physical chunk lane & 3.  Wave w moves
     //   j = 0: A piece w        j = 1: A piece 8 + w
@@ -1251,118 +1169,22 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
     const int lrow = lane >> 2, pch = lane & 3;
     const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
     const bool flex_is_a = wave < 4;
-    int64_t row_off[NAP];
-    int row_y[NAP], row_x[NAP];
-    bool row_ok[NAP];
+    AGather<AMODE, FAST, NAP, KS> ga(p, lch);
 #pragma unroll
-    for (int g = 0; g < NAP; ++g) {
-        const int piece = g < 2 ? g * 8 + wave : 16 + (wave & 3);
-        const int m = m0 + piece * 16 + lrow;
-        row_ok[g] = m < p.M;
-        const int mm = row_ok[g] ? m : 0;
-        if (AMODE == MOCA_A_LINEAR) {
-            row_off[g] = (int64_t)mm * p.lda;
-            row_y[g] = row_x[g] = 0;
-        } else if (AMODE == MOCA_A_CONV3X3) {
-            const int ohw = p.outH * p.outW;
-            int f, rem, oy, ox;
-            if (p.M < (1 << 24)) {
-                divmod24(mm, ohw, 1.0f / (float)ohw, f, rem);
-                divmod24(rem, p.outW, 1.0f / (float)p.outW, oy, ox);
-            } else {
-                f = mm / ohw; rem = mm - f * ohw;
-                oy = rem / p.outW; ox = rem - oy * p.outW;
-            }
-            row_off[g] = (int64_t)f * p.inH * p.inW;
-            row_y[g] = oy * p.stride - 1 + p.nopad_lo;
-            row_x[g] = ox * p.stride - 1 + p.nopad_lo;
-        } else {
-            int frame, pix, vid, t;
-            if (p.M < (1 << 24)) {
-                divmod24(mm, p.HW, 1.0f / (float)p.HW, frame, pix);
-                divmod24(frame, p.T, 1.0f / (float)p.T, vid, t);
-            } else {
-                frame = mm / p.HW; t = frame % p.T;
-            }
-            row_off[g] = mm;
-            row_y[g] = t;
-            row_x[g] = 0;
-        }
-    }
+    for (int g = 0; g < NAP; ++g) ga.init_row(g, m0 + (g < 2 ? g * 8 + wave : 16 + (wave & 3)) * 16 + lrow);
     const int w_piece0 = wave & 3;                        // j = 2 (waves 4..7)
     const int w_piece1 = wave < 6 ? 4 + wave : 2 + wave;  // j = 3
     const half_t* w_row[2];
     w_row[0] = Wptr + (int64_t)(n0 + w_piece0 * 16 + lrow) * p.ldw + lch * 8;
     w_row[1] = Wptr + (int64_t)(n0 + w_piece1 * 16 + lrow) * p.ldw + lch * 8;
 
-    constexpr bool fast = FAST;
-    const int tiles_per_tap = (AMODE == MOCA_A_LINEAR || !fast) ? (1 << 30) : p.C / KS;
-    const half_t* a_base[NAP];
-    int tap_cur = -1;
-    auto set_tap = [&](int tap) {
-        tap_cur = tap;
-        if (AMODE == MOCA_A_LINEAR) {
-#pragma unroll
-            for (int g = 0; g < NAP; ++g) a_base[g] = row_ok[g] ? Aptr + row_off[g] + lch * 8 : zero;
-        } else if (AMODE == MOCA_A_CONV3X3) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
-#pragma unroll
-            for (int g = 0; g < NAP; ++g) {
-                int iy = row_y[g] + ky, ix = row_x[g] + kx;
-                const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
-                if (p.up) { iy >>= 1; ix >>= 1; }
-                const half_t* src = Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + lch * 8;
-                a_base[g] = ok ? src : zero;
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < NAP; ++g) {
-                const int tt = row_y[g] + tap - 1;
-                const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
-                const half_t* src = Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + lch * 8;
-                a_base[g] = ok ? src : zero;
-            }
-        }
-    };
-    int a_koff = 0;
-    auto begin_tile = [&](int kt) {
-        if constexpr (fast) {
-            const int tap = kt / tiles_per_tap;
-            if (tap != tap_cur) set_tap(tap);
-            a_koff = (kt - tap * tiles_per_tap) * KS;
-        }
-    };
-    auto slow_src = [&](int kt, int g) -> const half_t* {
-        const int k = kt * KS + lch * 8;
-        if (AMODE == MOCA_A_LINEAR) {
-            return (k < p.K && row_ok[g]) ? Aptr + row_off[g] + k : zero;
-        } else if (AMODE == MOCA_A_CONV3X3) {
-            const int tap = k / p.C, c = k - tap * p.C;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
-            int iy = row_y[g] + ky, ix = row_x[g] + kx;
-            const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
-            if (p.up) { iy >>= 1; ix >>= 1; }
-            return ok ? Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + c : zero;
-        } else {
-            const int tap = k / p.C, c = k - tap * p.C;
-            const int tt = row_y[g] + tap - 1;
-            const bool ok = tap < 3 && row_ok[g] && tt >= 0 && tt < p.T;
-            return ok ? Aptr + (row_off[g] + (int64_t)(tap - 1) * p.HW) * p.C + c : zero;
-        }
-    };
-    auto a_src = [&](int kt, int g, int odd) -> const half_t* {     // odd = 1: the second k-tile of the pair begin_tile() was called for
-        if constexpr (fast) return a_base[g] + a_koff + odd * KS;
-        else return slow_src(kt, g);
-    };
     // DMA instruction j (0..3) of this wave for absolute k-tile kt (= pair base + odd) into ring slot `slot`
     auto dma_piece = [&](int kt, int slot, int j, int odd) {
         const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
         if (j < 2) {
-            __builtin_amdgcn_global_load_lds((glb_ptr)a_src(kt, j, odd), sa + (j * 8 + wave) * 1024, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)ga.src(kt, j, odd), sa + (j * 8 + wave) * 1024, 16, 0, 0);
         } else if (j == 2) {
-            const half_t* sA = a_src(kt, 2, odd);
+            const half_t* sA = ga.src(kt, 2, odd);
             const half_t* sw = w_row[0] + kt * KS;
             const half_t* src = flex_is_a ? sA : sw;
             const lds_ptr dst = flex_is_a ? sa + (16 + (wave & 3)) * 1024 : sa + A_BYTES + w_piece0 * 1024;
@@ -1376,7 +1198,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
     // second half came ~1 us later, after 30 KiB of other lines had gone through the 32 KiB L1: every line crossed the
     // L2 -> L1 path twice.)
     auto issue_pair = [&](int kt_even, int slot_even, int slot_odd) {
-        begin_tile(kt_even);
+        ga.begin_tile(kt_even);
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             dma_piece(kt_even, slot_even, j, 0);
@@ -1422,7 +1244,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
         constexpr int S = decltype(set_tag)::value;
         const int ktn = min(kt_begin + i + 4, kt_last_pair);
         const int s_prev = s_cur == 0 ? NS - 1 : s_cur - 1;
-        if constexpr (S == 0) begin_tile(ktn);
+        if constexpr (S == 0) ga.begin_tile(ktn);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < NMMA; ++j) {
