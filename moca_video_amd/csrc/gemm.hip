@@ -537,6 +537,42 @@ struct AGather {
     }
 };
 
+// ---- epilogue stage 2 of the direct-to-LDS kernels: the fp16 tile staged in LDS (`rows` x `out_bn`, row pitch `pitch` bytes)
+//      leaves as 16-byte coalesced stores; the time-embedding row add and the residual are added in fp32 on the way ----
+template <int NTHREADS>
+__device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const char* stage, int pitch, int rows, int out_bn,
+                                                int m0, int on0, int tid) {
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    const int chunks_per_row = out_bn / 8;
+    const int total_chunks = rows * chunks_per_row;
+    for (int idx = tid; idx < total_chunks; idx += NTHREADS) {
+        const int row = idx / chunks_per_row, ch = idx - row * chunks_per_row;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        const int col = on0 + ch * 8;
+        half8v h = *reinterpret_cast<const half8v*>(stage + row * pitch + ch * 16);
+        if (rowadd || resid) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+            if (rowadd) {
+                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            }
+            if (resid) {
+                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+        }
+        *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
+    }
+}
+
 typedef __attribute__((address_space(3))) char* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
 
@@ -819,33 +855,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     __syncthreads();
     MOCA_STAMP(4);
 
-    const int chunks_per_row = out_bn / 8;
-    const int total_chunks = TM * chunks_per_row;
-    for (int idx = tid; idx < total_chunks; idx += 512) {
-        const int row = idx / chunks_per_row, ch = idx - row * chunks_per_row;
-        const int m = m0 + row;
-        if (m >= p.M) continue;
-        const int col = on0 + ch * 8;
-        half8v h = *reinterpret_cast<const half8v*>(smem + row * pitch + ch * 16);
-        if (rowadd || resid) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
-            if (rowadd) {
-                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-            }
-            if (resid) {
-                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
-        }
-        *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
-    }
+    store_fp16_tile<512>(p, smem, pitch, TM, out_bn, m0, on0, tid);
     MOCA_STAMP(5);
 #ifdef MOCA_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {
@@ -1042,8 +1052,6 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     const int out_bn = geglu ? BN / 2 : BN;
     const int on0 = geglu ? n0 / 2 : n0;
     const int pitch = out_bn * 2 + 16;
-    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
-    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
     if (geglu) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -1078,33 +1086,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
         }
     }
     __syncthreads();
-    const int chunks_per_row = out_bn / 8;
-    const int total_chunks = TM * chunks_per_row;
-    for (int idx = tid; idx < total_chunks; idx += 256) {
-        const int row = idx / chunks_per_row, ch = idx - row * chunks_per_row;
-        const int m = m0 + row;
-        if (m >= p.M) continue;
-        const int col = on0 + ch * 8;
-        half8v h = *reinterpret_cast<const half8v*>(smem + row * pitch + ch * 16);
-        if (rowadd || resid) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
-            if (rowadd) {
-                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-            }
-            if (resid) {
-                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
-        }
-        *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
-    }
+    store_fp16_tile<256>(p, smem, pitch, TM, out_bn, m0, on0, tid);
 }
 
 
@@ -1315,8 +1297,6 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
         return;
     }
     constexpr int pitch = BN * 2 + 16;
-    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
-    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = wave_n * 80 + nt * 16 + 4 * fg;
@@ -1328,33 +1308,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
     }
     __syncthreads();
     MOCA_STAMP(4);
-    constexpr int chunks_per_row = BN / 8;
-    constexpr int total_chunks = TM * chunks_per_row;
-    for (int idx = tid; idx < total_chunks; idx += 512) {
-        const int row = idx / chunks_per_row, ch = idx - row * chunks_per_row;
-        const int m = m0 + row;
-        if (m >= p.M) continue;
-        const int col = n0 + ch * 8;
-        half8v h = *reinterpret_cast<const half8v*>(smem + row * pitch + ch * 16);
-        if (rowadd || resid) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
-            if (rowadd) {
-                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-            }
-            if (resid) {
-                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
-        }
-        *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
-    }
+    store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
     MOCA_STAMP(5);
 #ifdef MOCA_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {
