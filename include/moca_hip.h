@@ -40,6 +40,8 @@ extern "C" {
                            /* 64-row groups: 32 value rows then their 32 gate rows           */
 #define MOCA_EP_OUT_F32 2  /* out is float32 instead of fp16                                 */
 #define MOCA_FORCE_SMALL_TILE 4  /* tuning/testing: use the 128-row register-staged kernel   */
+#define MOCA_EP_GELU    8  /* out = gelu(acc + bias) (exact erf GELU; 128-row kernel only:   */
+                           /* M <= 128 or MOCA_FORCE_SMALL_TILE, splits = 1)                  */
 
 typedef struct moca_gemm_params {
     const void* a;         /* fp16 activations (gather source)                              */
@@ -106,6 +108,12 @@ int moca_attention_f16(const void* q, const void* k, const void* v, void* out,
                        int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
                        int32_t kv_div, float scale, void* stream);
 
+/* Causal self-attention, head dim 64: query i attends to keys 0..i (the text tower of the OpenCLIP encoder,
+ * condition.py:205-212: `text_transformer_forward(x, attn_mask=self.model.attn_mask)`); q/k/v/out as above, N = Nq = Nk. */
+int moca_attention_causal_f16(const void* q, const void* k, const void* v, void* out,
+                              int32_t B, int32_t heads, int32_t N, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                              float scale, void* stream);
+
 /* Temporal self-attention over the frame axis: for every (video b, pixel p, head h)
  * attend over the T (<=16) frames.  qkv rows are channels-last tokens
  * [(b*T+t)*HW + p][ld]; q/k/v point at their first column.  Replaces
@@ -134,6 +142,11 @@ int moca_timestep_embedding_f16(const int64_t* t, void* out, int32_t n, int32_t 
 /* y = silu(x) (+ broadcasting helper for the embedding MLPs): out[i][:] = silu(a[i/div_a] + b[i/div_b]) */
 int moca_silu_add_rows_f16(const void* a, int32_t div_a, const void* b, int32_t div_b, void* out,
                            int32_t rows, int32_t C, int32_t apply_silu, void* stream);
+
+/* out[i][:] = table[tokens[i]][:] + pos[i % L][:]  (fp32 tables, fp16 out; condition.py:206-207:
+ * `token_embedding(text) + positional_embedding`) */
+int moca_embed_tokens_f16(const int64_t* tokens, const float* table, const float* pos, void* out,
+                          int32_t n_tokens, int32_t L, int32_t C, int32_t vocab, void* stream);
 
 /* ---- VAE decoder helpers (next row N1: AutoencoderKL.decode, lvdm/models/autoencoder.py:104-107) ---- */
 /* out[(b*T+t)*HW+p][co] = bias[co] + sum_ci w[co][ci] * z[b][ci][t][p] * inv_scale  (co < Cout; zero up to Cpad).

@@ -8,7 +8,8 @@ Public surface mirrors the reference interfaces for this path only:
   freq_mix_3d, get_freq_filter   utils/freeinit_utils.py
   prepare_latents, shift_latents, fifo_ddim_sampling, base_ddim_sampling   scripts/evaluation/funcs.py
   instantiate_from_config       utils/utils.py:27-42
-  AutoencoderKL (decode)        lvdm/models/autoencoder.py:13-107 + lvdm/modules/networks/ae_modules.py:466-579
+  AutoencoderKL                 lvdm/models/autoencoder.py:13-107 + lvdm/modules/networks/ae_modules.py:364-579
+  FrozenOpenCLIPEmbedder        lvdm/modules/encoders/condition.py:174-235 (text tower on token ids)
 Importing the package loads libmoca_hip.so and fails loudly if it has not been built.
 """
 from . import lib as _lib
@@ -18,5 +19,6 @@ _lib.load()
 from .unet import UNetModel  # noqa: E402
 from .wrapper import DiffusionWrapper, DenoiseModel, instantiate_from_config, load_unet_config  # noqa: E402
 from .vae import AutoencoderKL  # noqa: E402
+from .clip_text import FrozenOpenCLIPEmbedder  # noqa: E402
 
-__all__ = ["UNetModel", "DiffusionWrapper", "DenoiseModel", "AutoencoderKL", "instantiate_from_config", "load_unet_config"]
+__all__ = ["UNetModel", "DiffusionWrapper", "DenoiseModel", "AutoencoderKL", "FrozenOpenCLIPEmbedder", "instantiate_from_config", "load_unet_config"]

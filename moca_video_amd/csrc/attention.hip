@@ -38,6 +38,7 @@ __device__ __forceinline__ half4v tr_read(const char* addr) {
     return __builtin_bit_cast(half4v, v);
 }
 
+template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attention_kernel(
     const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, half_t* __restrict__ out,
     int heads, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, int kv_div, float scale_log2e) {
@@ -132,14 +133,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
                 s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sub], 0, 0, 0);
             }
         }
-        // mask keys beyond Nk (last tile only)
-        if ((kt + 1) * KT > Nk) {
+        // mask keys beyond Nk (last tile only); CAUSAL: also keys after this lane's query (text tower of the CLIP encoder)
+        if (CAUSAL || (kt + 1) * KT > Nk) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * KT + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    if (key >= Nk) s[sub][r] = -INFINITY;
+                    if (key >= Nk || (CAUSAL && key > qrow)) s[sub][r] = -INFINITY;
                 }
         }
         // ---- online softmax (this lane = one query column; partner lane^32 has the other keys) ----
@@ -310,10 +311,26 @@ extern "C" int moca_attention_f16(const void* q, const void* k, const void* v, v
     if (ldq < heads * D || ldk < heads * D || ldv < heads * D || ldo < heads * D) return MOCA_E_BADARG;
     if ((int64_t)Bq * heads > 65535) return MOCA_E_BADARG;
     const dim3 grid((Nq + QB - 1) / QB, Bq * heads), block(256);
-    hipLaunchKernelGGL(attention_kernel, grid, block, 0, moca_stream(stream),
+    hipLaunchKernelGGL(attention_kernel<false>, grid, block, 0, moca_stream(stream),
                        reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
                        reinterpret_cast<const half_t*>(v), reinterpret_cast<half_t*>(out),
                        heads, Nq, Nk, ldq, ldk, ldv, ldo, kv_div, scale * 1.4426950408889634f);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_attention_causal_f16(const void* q, const void* k, const void* v, void* out,
+                                         int32_t B, int32_t heads, int32_t N, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                                         float scale, void* stream) {
+    if (!q || !k || !v || !out || B <= 0 || heads <= 0 || N <= 0) return MOCA_E_BADARG;
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return MOCA_E_BADARG;
+    if (ldq < heads * D || ldk < heads * D || ldv < heads * D || ldo < heads * D) return MOCA_E_BADARG;
+    if ((int64_t)B * heads > 65535) return MOCA_E_BADARG;
+    const dim3 grid((N + QB - 1) / QB, B * heads), block(256);
+    hipLaunchKernelGGL(attention_kernel<true>, grid, block, 0, moca_stream(stream),
+                       reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
+                       reinterpret_cast<const half_t*>(v), reinterpret_cast<half_t*>(out),
+                       heads, N, N, ldq, ldk, ldv, ldo, 1, scale * 1.4426950408889634f);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

@@ -141,6 +141,18 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     }
 }
 
+// ---- token + positional embedding of the CLIP text tower ----
+__global__ void embed_tokens_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ table, const float* __restrict__ pos,
+                                    half_t* __restrict__ out, int n_tokens, int L, int C, int vocab) {
+    const int64_t total = (int64_t)n_tokens * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / C), c = (int)(i - (int64_t)t * C);
+        int64_t tok = tokens[t];
+        tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+        out[i] = (half_t)(table[tok * C + c] + pos[(int64_t)(t % L) * C + c]);
+    }
+}
+
 }  // namespace
 
 extern "C" int moca_ncthw_to_nhwc_f16(const void* x, int32_t x_is_f32, void* y, int32_t B, int32_t Cin,
@@ -224,6 +236,16 @@ extern "C" int moca_softmax_rows_f16(const float* s, void* p, int64_t R, int32_t
     if (blocks > 0x7fffffff) return MOCA_E_BADARG;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, moca_stream(stream), s,
                        reinterpret_cast<half_t*>(p), R, N, lds, ldp, scale * 1.4426950408889634f);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_embed_tokens_f16(const int64_t* tokens, const float* table, const float* pos, void* out,
+                                     int32_t n_tokens, int32_t L, int32_t C, int32_t vocab, void* stream) {
+    if (!tokens || !table || !pos || !out || n_tokens <= 0 || L <= 0 || C <= 0 || vocab <= 0) return MOCA_E_BADARG;
+    const int g = grid_for((int64_t)n_tokens * C);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(g), dim3(256), 0, moca_stream(stream), tokens, table, pos,
+                       reinterpret_cast<half_t*>(out), n_tokens, L, C, vocab);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

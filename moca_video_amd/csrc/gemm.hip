@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const moca_gemm_params
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = wave_m * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    sC[row * out_bn + col] = acc[mt][nt][r] + bv;
+                    const float v = acc[mt][nt][r] + bv;
+                    sC[row * out_bn + col] = (p.flags & MOCA_EP_GELU) ? moca_gelu(v) : v;
                 }
         }
     }
@@ -1416,6 +1417,8 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     if (geglu && p.N % 128) return MOCA_E_BADARG;
     if (p.ldo % 8 || (p.residual && p.ldr % 8) || (p.rowadd && (p.ld_rowadd % 8 || p.rowadd_div <= 0))) return MOCA_E_BADARG;
     if (p.splits > 1 && !p.splitk_ws) return MOCA_E_BADARG;
+    // the plain-GELU epilogue (CLIP text MLP) exists in the 128-row kernel only
+    if ((p.flags & MOCA_EP_GELU) && (geglu || p.splits != 1 || !((p.flags & MOCA_FORCE_SMALL_TILE) || p.M <= 128))) return MOCA_E_BADARG;
     if (p.splits > (p.K + BK - 1) / BK) p.splits = (p.K + BK - 1) / BK;
     if (p.splits > 1) {   // no empty k range: every split writes its slab
         const int nkt = (p.K + BK - 1) / BK, kts = (nkt + p.splits - 1) / p.splits;

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOCA_HIP_LIB") or os.path.join(_HERE, "libmoca_hip.so")
 
 MOCA_A_LINEAR, MOCA_A_CONV3X3, MOCA_A_TCONV3 = 0, 1, 2
-MOCA_EP_GEGLU, MOCA_EP_OUT_F32 = 1, 2
+MOCA_EP_GEGLU, MOCA_EP_OUT_F32, MOCA_FORCE_SMALL_TILE, MOCA_EP_GELU = 1, 2, 4, 8
 
 _ERR = {0: "ok", -1: "bad argument (shape/alignment contract)", -2: "HIP launch/runtime error",
         -3: "no gfx950 device", -4: "graph capture/replay failed"}
@@ -48,6 +48,8 @@ SIGNATURES = {
     "moca_groupnorm_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "moca_layernorm_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "moca_attention_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "moca_attention_causal_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "moca_embed_tokens_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "moca_temporal_attention_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "moca_ncthw_to_nhwc_f16": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "moca_nhwc_to_ncthw": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

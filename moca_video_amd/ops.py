@@ -111,7 +111,7 @@ def pack_geglu(weight, bias, device="cuda"):
 # kernel wrappers
 # --------------------------------------------------------------------------------------
 def gemm(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
-         residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None):
+         residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False):
     """out[M][:] = epilogue(gather(a) @ pw.w^T).  conv = (C, inH, inW, outH, outW, stride, up);
     tconv = (C, T, HW)."""
     lib = _l.load()
@@ -134,7 +134,8 @@ def gemm(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd
         p.nopad_lo = conv[7] if len(conv) > 7 else 0
     if tconv is not None:
         p.C, p.T, p.HW = tconv
-    p.flags = (_l.MOCA_EP_GEGLU if pw.geglu else 0) | (_l.MOCA_EP_OUT_F32 if out_f32 else 0)
+    p.flags = (_l.MOCA_EP_GEGLU if pw.geglu else 0) | (_l.MOCA_EP_OUT_F32 if out_f32 else 0) | \
+              ((_l.MOCA_EP_GELU | _l.MOCA_FORCE_SMALL_TILE) if gelu else 0)
     p.splits = splits
     _l.check(lib.moca_gemm_f16(C.byref(p), _st()), "moca_gemm_f16")
     return out
@@ -215,4 +216,16 @@ def gaussian_sample(moments, noise, out, *, n, z, hw, scale):
     """out = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise); noise None -> the mode"""
     _l.check(_l.load().moca_gaussian_sample_f32(_l.ptr(moments), _l.ptr(noise), _l.ptr(out), n, z, hw, scale, _st()),
              "moca_gaussian_sample_f32")
+    return out
+
+
+def attention_causal(q, k, v, out, *, B, heads, N, ldq, ldk, ldv, ldo, scale):
+    _l.check(_l.load().moca_attention_causal_f16(_l.ptr(q), _l.ptr(k), _l.ptr(v), _l.ptr(out), B, heads, N, ldq, ldk, ldv, ldo,
+                                                 scale, _st()), "moca_attention_causal_f16")
+    return out
+
+
+def embed_tokens(tokens, table, pos, out, *, n_tokens, L, Cn, vocab):
+    _l.check(_l.load().moca_embed_tokens_f16(_l.ptr(tokens), _l.ptr(table), _l.ptr(pos), _l.ptr(out), n_tokens, L, Cn, vocab, _st()),
+             "moca_embed_tokens_f16")
     return out

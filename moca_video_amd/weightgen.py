@@ -24,7 +24,7 @@ def _rng(key: str, seed: int):
 def gen_tensor(key: str, shape, seed: int = 0) -> torch.Tensor:
     shape = tuple(int(s) for s in shape)
     z = _rng(key, seed).standard_normal(shape, dtype=np.float32)
-    if len(shape) == 1:
+    if len(shape) <= 1:
         if key.endswith("weight"):          # GroupNorm / LayerNorm scale
             z = 1.0 + 0.1 * z
         else:                               # any bias
@@ -32,7 +32,7 @@ def gen_tensor(key: str, shape, seed: int = 0) -> torch.Tensor:
     else:
         fan_in = int(np.prod(shape[1:]))
         z = z * np.float32(fan_in ** -0.5)
-    return torch.from_numpy(z)
+    return torch.from_numpy(np.asarray(z, dtype=np.float32))
 
 
 def gen_state_dict(shapes, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":

@@ -23,7 +23,13 @@ def _vae_cls(**kw):
 _TARGET_ALIASES = {
     "lvdm.modules.networks.openaimodel3d.UNetModel": UNetModel,
     "lvdm.models.autoencoder.AutoencoderKL": _vae_cls,
+    "lvdm.modules.encoders.condition.FrozenOpenCLIPEmbedder": lambda **kw: _clip_cls(**kw),
 }
+
+
+def _clip_cls(**kw):
+    from .clip_text import FrozenOpenCLIPEmbedder
+    return FrozenOpenCLIPEmbedder(**kw)
 
 
 def get_obj_from_str(string):
@@ -87,7 +93,7 @@ class DenoiseModel(nn.Module):
 
     def __init__(self, unet_config, timesteps=1000, linear_start=0.00085, linear_end=0.012, conditioning_key="crossattn",
                  use_scale=True, scale_a=1, scale_b=0.7, mid_step=400, fix_scale_bug=False, parameterization="eps",
-                 uncond_type="empty_seq", first_stage_config=None, scale_factor=1.0, **ignored):
+                 uncond_type="empty_seq", first_stage_config=None, scale_factor=1.0, cond_stage_config=None, **ignored):
         super().__init__()
         self.parameterization = parameterization
         self.uncond_type = uncond_type
@@ -113,6 +119,14 @@ class DenoiseModel(nn.Module):
         # first stage (ddpm3d.py:383,386,431-437): only the decode side is on the MoCA path (funcs.py:360)
         self.scale_factor = scale_factor
         self.first_stage_model = instantiate_from_config(first_stage_config) if first_stage_config is not None else None
+        self.cond_stage_model = instantiate_from_config(cond_stage_config) if cond_stage_config is not None else None
+
+    def get_learned_conditioning(self, c):
+        """ddpm3d.py:440-455 (cond_stage_forward is None: `self.cond_stage_model.encode(c)`); `c` = token ids [B, 77] -- the BPE
+        tokenizer of open_clip is the caller's (not available offline)"""
+        if self.cond_stage_model is None:
+            raise RuntimeError("DenoiseModel was built without cond_stage_config")
+        return self.cond_stage_model.encode(c)
 
     @torch.no_grad()
     def decode_first_stage_2DAE(self, z, **kwargs):

@@ -304,3 +304,36 @@ def test_gemm_random_sweep_forced_kernels(kernel, env, monkeypatch):
         ws = torch.empty(splits * M * pw.N, dtype=torch.float32, device=DEV) if splits > 1 else None
         ops.gemm(a, pw, out, M=M, residual=res, splits=splits, splitk_ws=ws, **kw)
         check(out[:, :N], ref, TOL16, f"{kernel} case {ci}: {mode} M={M} N={N} K={K} splits={splits} res={with_res}")
+
+
+# ---------------------------------------------------------------- CLIP text tower kernels
+@pytest.mark.parametrize("B,heads,N", [(1, 16, 77), (2, 2, 77), (1, 4, 200)])
+def test_attention_causal(B, heads, N):
+    C = heads * 64
+    qkv = rnd(B, N, 3 * C)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    out = torch.empty(B, N, C, dtype=torch.float16, device=DEV)
+    ops.attention_causal(q, k, v, out, B=B, heads=heads, N=N, ldq=3 * C, ldk=3 * C, ldv=3 * C, ldo=C, scale=0.125)
+    sp = lambda t: t.float().view(B, N, heads, 64).permute(0, 2, 1, 3)
+    mask = torch.full((N, N), float("-inf"), device=DEV).triu_(1)
+    s = torch.einsum("bhid,bhjd->bhij", sp(q), sp(k)) * 0.125 + mask
+    ref = torch.einsum("bhij,bhjd->bhid", s.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(B, N, C)
+    check(out, ref, TOL16, "causal attention")
+
+
+def test_gemm_gelu_epilogue_and_token_embedding():
+    M, K, N = 77, 256, 512
+    a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N, dtype=torch.float32, scale=0.5)
+    pw = ops.pack_linear(w, b)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(a, pw, out, M=M, gelu=True)
+    check(out, F.gelu(a.float() @ w.float().t() + b), TOL16, "gelu epilogue")
+    big = rnd(300, K)                      # M > 128 is forced onto the 128-row kernel by the flag
+    out2 = torch.empty(300, N, dtype=torch.float16, device=DEV)
+    ops.gemm(big, pw, out2, M=300, gelu=True)
+    check(out2, F.gelu(big.float() @ w.float().t() + b), TOL16, "gelu epilogue M=300")
+    table, pos = rnd(50, 64, dtype=torch.float32), rnd(7, 64, dtype=torch.float32)
+    tok = torch.tensor([3, 49, 0, 7, 7, 12, 1, 5, 48, 2, 9, 9, 30, 31], device=DEV)
+    emb = torch.empty(14, 64, dtype=torch.float16, device=DEV)
+    ops.embed_tokens(tok, table, pos, emb, n_tokens=14, L=7, Cn=64, vocab=50)
+    check(emb, table[tok] + pos.repeat(2, 1), 1e-3, "token embedding")
