@@ -31,8 +31,20 @@ __global__ void gn_partial_kernel(const half_t* __restrict__ x, float* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
     const half_t* base = x + ((int64_t)f * HW) * C + cx * 8;
-    for (int p = p_begin + py; p < p_end; p += ppb) {
-        const half8v v = *reinterpret_cast<const half8v*>(base + (int64_t)p * C);
+    // four pixels per trip: the four 16-byte loads of a thread are in flight together (a one-load-per-trip loop leaves the
+    // memory pipe of this streaming pass mostly empty)
+    int pp = p_begin + py;
+    for (; pp + 3 * ppb < p_end; pp += 4 * ppb) {
+        half8v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8v*>(base + (int64_t)(pp + u * ppb) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float a = (float)v[u][j]; s[j] += a; q[j] += a * a; }
+    }
+    for (; pp < p_end; pp += ppb) {
+        const half8v v = *reinterpret_cast<const half8v*>(base + (int64_t)pp * C);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float a = (float)v[j]; s[j] += a; q[j] += a * a; }
     }
@@ -96,8 +108,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
         sh[j] = beta[c] - mean * sc[j];
     }
     const int64_t off = ((int64_t)f * HW) * C + cx * 8;
-    for (int p = p_begin + py; p < p_end; p += ppb) {
-        const half8v v = *reinterpret_cast<const half8v*>(x + off + (int64_t)p * C);
+    auto norm8 = [&](const half8v& v) {
         half8v o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -105,8 +116,18 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
             if (silu) a = moca_silu(a);
             o[j] = (half_t)a;
         }
-        *reinterpret_cast<half8v*>(y + off + (int64_t)p * C) = o;
+        return o;
+    };
+    int pp = p_begin + py;
+    for (; pp + 3 * ppb < p_end; pp += 4 * ppb) {         // four loads in flight per thread, as in the statistics pass
+        half8v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8v*>(x + off + (int64_t)(pp + u * ppb) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<half8v*>(y + off + (int64_t)(pp + u * ppb) * C) = norm8(v[u]);
     }
+    for (; pp < p_end; pp += ppb)
+        *reinterpret_cast<half8v*>(y + off + (int64_t)pp * C) = norm8(*reinterpret_cast<const half8v*>(x + off + (int64_t)pp * C));
 }
 
 // ---- single-launch GroupNorm for small tensors ------------------------------------
