@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from .fifo import base_ddim_sampling, fifo_ddim_sampling, tensor2image
+from .fifo import base_ddim_sampling, fifo_ddim_sampling, prepare_latents, tensor2image
 from .sampler import DDIMSampler
 
 _FIELDS = ("prompt", "conditioned_object", "conditioned_image_path", "conditioned_prompt", "gamma")
@@ -212,3 +212,34 @@ def run_prompts(args, model, embed_text, cond_image_fn=None, mask_fn=None, root=
             torch.save(torch.cat(keep, dim=2).cpu(), path)
         done[idx] = path
     return done
+
+
+def run_davis(args, model, embed_text, prompt, cond_image=None, root=".", uc_emb=None, decode=True, n_iterations=None):
+    """The DAVIS-video mode of videocrafter_main.py:102-175 on the drop-in classes: frames + annotation masks of
+    `args.video_name` -> VAE-encoded 72-frame queue (`prepare_latents(data=...)`, funcs.py:38-48) -> MoCA FIFO sampling with the
+    DAVIS masks as injection masks -> the FIRST `new_video_length // 2` emitted frames as a GIF (:170-175).  `prompt` replaces
+    `get_davis_prompt(video_name) + " cat."` (annotation file absent offline); `embed_text` as in run_prompts."""
+    h, w = args.height // 8, args.width // 8
+    f = args.video_length
+    Q = args.num_inference_steps + (f // 2 if args.lookahead_denoising else 0)
+    frames, masks = load_davis_data(args.video_name, args.davis_root, frame_stride=getattr(args, "frame_stride", 1),
+                                    video_size=(h, w), video_frames=Q, sampling_strategy=getattr(args, "sampling_strategy", "uniform"))
+    out_dir, lat_dir = set_directory(args, args.video_name, getattr(args, "conditioned_image_path", None), root=root)
+    fps = torch.tensor([args.fps], device=model.device).long()
+    cond = {"c_crossattn": [embed_text(prompt)], "fps": fps}
+    sampler = DDIMSampler(model)
+    sampler.make_schedule(ddim_num_steps=args.num_inference_steps, ddim_eta=args.eta, verbose=False)
+    latents = prepare_latents(args, lat_dir, sampler, model=model, data=(frames, masks))
+    masks = masks.to(model.device)
+    if masks.shape[2] < latents.shape[2]:                       # short clips: the remaining queue frames carry no mask
+        pad = torch.zeros(1, 1, latents.shape[2] - masks.shape[2], h, w, device=masks.device)
+        masks = torch.cat([masks, pad], dim=2)
+    out = fifo_ddim_sampling(args, model, cond, [1, 4, f, h, w], sampler, args.unconditional_guidance_scale, uc_emb=uc_emb,
+                             latents=latents, conditioned_image=cond_image, masks=masks, gamma=getattr(args, "gamma", 0.5),
+                             decode=decode, n_iterations=n_iterations)
+    keep = out[:args.new_video_length // 2]
+    if decode:
+        return save_gif(torch.cat(keep, dim=2), out_dir, args.video_name, duration_ms=int(1000 / args.output_fps))
+    path = os.path.join(out_dir, f"{args.video_name}_latents.pt")
+    torch.save(torch.cat(keep, dim=2).cpu(), path)
+    return path

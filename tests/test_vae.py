@@ -218,3 +218,39 @@ def test_prepare_latents_davis_branch_encodes_frames():
     got = lat[:, :, 0].cpu() / a0 ** 0.5
     std = torch.exp(0.5 * torch.clamp(torch.chunk(VO.encode_moments(sd, frames[:, :3, 0]), 2, 1)[1], -30, 20)) * 0.18215
     assert ((got - z_mode[:, :, 0]).abs() <= 6 * std + 2e-2 * z_mode.abs().max()).all()
+
+
+@pytest.mark.gpu
+def test_davis_mode_driver_end_to_end(tmp_path):
+    """moca_video_amd.io.run_davis = the DAVIS branch of videocrafter_main.py:102-175: frames + annotation masks from disk ->
+    VAE-encoded queue -> MoCA FIFO with the DAVIS masks -> decoded GIF of the first new_video_length//2 frames"""
+    import types
+    from PIL import Image
+    from moca_video_amd import DenoiseModel
+    from moca_video_amd.io import run_davis
+    from helpers import REDUCED
+    fd = tmp_path / "DAVIS" / "JPEGImages" / "480p" / "bear"
+    md = tmp_path / "DAVIS" / "Annotations" / "480p" / "bear"
+    fd.mkdir(parents=True); md.mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    for i in range(24):
+        Image.fromarray(rng.integers(0, 255, (48, 80, 3), dtype=np.uint8)).save(str(fd / f"{i:05d}.jpg"))
+        m = np.zeros((48, 80), np.uint8)
+        m[12:30, 20 + i:50 + i] = 1
+        Image.fromarray(m).save(str(md / f"{i:05d}.png"))
+    dm = DenoiseModel({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": REDUCED},
+                      first_stage_config={"target": "lvdm.models.autoencoder.AutoencoderKL",
+                                          "params": {"embed_dim": 4, "ddconfig": dict(VAE_DD, ch=64), "lossconfig": {"target": "torch.nn.Identity"}}},
+                      scale_factor=0.18215)
+    dm.model.diffusion_model.load_state_dict(state_dict_for(dm.model.diffusion_model, 11), strict=True)
+    dm.first_stage_model.load_state_dict(state_dict_for(dm.first_stage_model, 5), strict=True)
+    dm = dm.cuda()
+    args = types.SimpleNamespace(video_name="bear", davis_root=str(tmp_path / "DAVIS"), height=64, width=64, fps=10, video_length=8,
+                                 num_partitions=2, num_inference_steps=16, new_video_length=6, lookahead_denoising=True, eta=1.0,
+                                 unconditional_guidance_scale=12.0, output_dir=None, use_self_attention=False, output_fps=10,
+                                 sampling_strategy="first", gamma=0.5, use_davis=True)
+    embed = lambda text: inp("txt:" + text, (1, 77, 128)).cuda()
+    cimg = inp("davis.cimg", (1, 4, 1, 8, 8)).cuda()
+    path = run_davis(args, dm, embed, "a bear walking, cat.", cond_image=cimg, root=str(tmp_path), uc_emb=embed(""), n_iterations=4)
+    im = Image.open(path)
+    assert im.n_frames == 3 and im.size == (64, 64)           # first new_video_length // 2 of the 4 emitted frames
