@@ -31,10 +31,24 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_UNET_STEP = 12.581e12      # FlopCounterMode on the reference UNet, [1,4,16,40,64], L=77
 PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
-# L2<->fabric bytes of one batched (B=2) UNet forward launch, from separate rocprofv3 --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE passes over this same command (profiles/r01_pmc_traffic_per_forward_final.txt; FETCH_SIZE doubled
-# per the gfx950 correction in MI355X_MICROARCH.md; Infinity-Cache hits are included in these counters)
-TRAFFIC_BYTES_PER_LAUNCH = 112.9e9
+# L2<->fabric bytes of one batched (B=2) UNet forward launch come from separate rocprofv3 --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE passes over this same command (tools/profile_round.sh -> tools/pmc_traffic_summary.py; FETCH_SIZE
+# doubled per the gfx950 correction in MI355X_MICROARCH.md; Infinity-Cache hits are included in these counters).  The
+# figure is READ from the committed summary of the current kernels -- never a constant in this file -- and the JSON
+# names the file; it is null when no summary for this round exists.
+TRAFFIC_PROFILES = ("profiles/r02_pmc_traffic_per_forward.txt",)
+
+
+def traffic_from_profile():
+    import re
+    for rel in TRAFFIC_PROFILES:
+        path = os.path.join(ROOT, rel)
+        if os.path.exists(path):
+            m = re.search(r"=\s*([0-9.]+)\s*GB per UNet forward launch", open(path).read())
+            if m:
+                return float(m.group(1)) * 1e9, rel
+    return None, None
+
 
 FULL = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
             channel_mult=[1, 2, 4, 4], num_head_channels=64, transformer_depth=1, context_dim=1024, use_linear=True,
@@ -53,18 +67,21 @@ def build_model(device, seed=321):
     return dm
 
 
-def cpu_baseline(dm, x, ctx, ts, threads):
+def cpu_baseline(dm, x, ctx, ts, threads, runs=2):
     """The CPU oracle (fp32 restatement of the reference UNet, oracle/unet_oracle.py) on the host
-    cores: ONE UNet-step at the full [1,4,16,40,64] shape (bounded sample, ~10-40 s)."""
+    cores: ONE UNet-step at the full [1,4,16,40,64] shape per run (bounded sample, ~20 s each); `runs` timed runs,
+    the minimum is reported (the first run also pages the weights in)."""
     from oracle import unet_oracle as UO
     torch.set_num_threads(threads)
     sd = {k: v.detach().float().cpu() for k, v in dm.model.diffusion_model.state_dict().items()}
     xc, cc, tc = x.float().cpu(), ctx.float().cpu(), ts.cpu()
+    times = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        y = UO.unet_forward(sd, xc, tc, cc, fps=torch.tensor([10]))
-        dt = time.perf_counter() - t0
-    return dt, y
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            y = UO.unet_forward(sd, xc, tc, cc, fps=torch.tensor([10]))
+            times.append(time.perf_counter() - t0)
+    return min(times), y, times
 
 
 def fifo_leg(dm, device, T, H, W, iters=3):
@@ -100,6 +117,43 @@ def fifo_leg(dm, device, T, H, W, iters=3):
             "note": "8 windows batched (B=8, 154-token cond + B=8, 77-token uncond), MoCA ddim_step + FreeInit shift included, VAE decode excluded"}
 
 
+def video_leg(dm, ae, device, T, H, W):
+    """Extra: MEASURED wall-clock of one whole video (second half of BASELINE.json's metric), prompt mode of
+    videocrafter_main.py:176-232 at full size -- base sampling (64 CFG DDIM steps, funcs.py:177-241, + decode of its 16
+    frames), queue construction (prepare_latents), 148 outer MoCA-FIFO iterations (8 batched windows each, cond = 2 prompts,
+    mask injection, FreeInit shift) and the VAE decode of the 148 emitted frames.  Text encoding / Grounded-SAM-2 are
+    inputs (out of scope); file writing excluded."""
+    import types
+    from moca_video_amd.fifo import base_ddim_sampling, fifo_ddim_sampling, prepare_latents
+    args = types.SimpleNamespace(num_inference_steps=64, video_length=T, lookahead_denoising=True, num_partitions=4,
+                                 new_video_length=100)
+    dm.first_stage_model, dm.scale_factor = ae, 0.18215
+    g = torch.Generator(device=device).manual_seed(9)
+    c1, c2, uc_emb = (torch.randn(1, 77, 1024, device=device, generator=g) for _ in range(3))
+    fps = torch.tensor([10], device=device)
+    Q = 64 + T // 2
+    mask = torch.zeros(1, 1, Q, H, W, device=device)
+    mask[..., H // 4: 3 * H // 4, W // 4: 3 * W // 4] = 1.0
+    cimg = torch.rand(1, 4, 1, H, W, device=device, generator=g)
+    shape = [1, 4, T, H, W]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    base, sampler, samples = base_ddim_sampling(dm, {"c_crossattn": [c1], "fps": fps}, shape, 64, 1.0, 12.0, uc_emb=uc_emb)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    lat = prepare_latents(args, None, sampler, initial_latents=samples)
+    frames = fifo_ddim_sampling(args, dm, {"c_crossattn": [c1, c2], "fps": fps}, shape, sampler, cfg_scale=12.0, uc_emb=uc_emb,
+                                latents=lat, conditioned_image=cimg, masks=mask, decode=True, batch_windows=True)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    ok = len(frames) == 148 and all(bool(torch.isfinite(f).all()) for f in frames[-4:]) and tuple(frames[0].shape) == (1, 3, 1, 8 * H, 8 * W)
+    dm.first_stage_model = None
+    return {"video_s": round(t2 - t0, 2), "base_sampling_s": round(t1 - t0, 2), "fifo_148_iterations_incl_decode_s": round(t2 - t1, 2),
+            "unet_steps": 2 * 64 + 148 * 16, "frames_decoded": 16 + 148, "output_ok": ok,
+            "note": "measured, one prompt, 1 GPU: 64 CFG base steps + prepare_latents + 148 FIFO iterations (8 batched windows, 154-token "
+                    "cond / 77-token uncond, mask injection, FreeInit shift) + VAE decode of every emitted frame"}
+
+
 VAE_DD = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
               num_res_blocks=2, attn_resolutions=[], dropout=0.0)          # configs/inference_t2v_512_v2.0.yaml:56-70
 VAE_FLOP_PER_FRAME = 1.5635e12      # conv/linear/bmm MACs x 2 of AutoencoderKL.decode on [1,4,40,64] (FlopCounterMode on the oracle)
@@ -127,7 +181,71 @@ def vae_leg(device, H, W, frames=8, iters=5):
     assert out.shape == (frames, 3, 8 * H, 8 * W) and bool(torch.isfinite(out).all())
     return {"ms_per_frame": round(dt / frames * 1e3, 3), "frames_per_launch": frames,
             "tflops": round(VAE_FLOP_PER_FRAME * frames / dt / 1e12, 1),
-            "s_per_video_148_frames": round(148 * dt / frames, 3)}
+            "s_per_video_148_frames": round(148 * dt / frames, 3)}, ae
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes of this file, one per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, the reference idiom of hand-launched ranks,
+    videocrafter_main.py:179-181).  The parent never touches the GPU (no HIP call, no torch.cuda call): it only
+    forwards rank 0's stdout (the JSON line) and returns the worst exit code.  Children are new processes, not a re-exec."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.PIPE if r == 0 else sys.stderr        # only rank 0 owns stdout: ONE JSON line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
+    text, _ = procs[0].communicate()
+    for line in (text.decode() if text else "").splitlines():
+        # stdout carries the JSON line only; anything else rank 0 printed (gloo/RCCL banners) goes to stderr
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=300 if rc == 0 else 20)
+        except subprocess.TimeoutExpired:
+            p.kill()                                             # exact PID of a child we started
+            p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def launcher_selftest(args):
+    """`--selftest-cpu`: the multi-rank plumbing of this file WITHOUT the hot path (CPU, gloo): rendezvous from the
+    environment, C1 parameter broadcast, barrier, K no-op "steps", max-over-ranks timing, C2 gather, rank 0 prints one
+    JSON line.  Test infrastructure for tests/test_dist_cpu.py -- it measures nothing and says so in `metric`."""
+    from moca_video_amd import dist as mdist
+    rank, local, world = mdist.init_from_env(backend="gloo")
+    torch.manual_seed(100 + rank)
+    m = torch.nn.Linear(64, 64)
+    sent = mdist.broadcast_parameters(m, src=0)
+    w_sum = float(m.weight.detach().sum())
+    mdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    mdist.barrier()
+    dt = mdist.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
+    outs = mdist.gather_results(torch.tensor([float(rank), w_sum]), dst=0)
+    if rank == 0:
+        ranks = [int(o[0]) for o in outs]
+        same_w = all(abs(float(o[1]) - w_sum) < 1e-6 for o in outs)
+        print(json.dumps({"metric": "launcher-selftest (no compute)", "value": 0.0, "unit": "none", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ranks_gathered": ranks, "weights_equal_after_broadcast": same_w,
+                          "broadcast_bytes": sent, "elapsed_s": dt}))
 
 
 def main():
@@ -143,7 +261,15 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--height", type=int, default=40)
     ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--no-video", action="store_true", help="skip the measured whole-video leg (base sampling + 148 FIFO iterations + decode)")
+    ap.add_argument("--selftest-cpu", action="store_true", help="launcher/collective plumbing only (CPU, gloo): see launcher_selftest")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with no launcher around it: become the launcher (before anything touches the GPU)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.selftest_cpu:
+        return launcher_selftest(args)
 
     from moca_video_amd import dist as mdist
     from moca_video_amd import lib as mlib
@@ -245,6 +371,7 @@ def main():
         flop_per_launch = 2 * flop_unit            # one launch = batched cond+uncond forward
         achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
     name, cus = mlib.device_info()
+    traffic_bytes, traffic_src = traffic_from_profile()
     res = {
         "metric": "denoising UNet-steps/sec @16x320x512 fp16",
         "value": round(value, 3),
@@ -265,25 +392,27 @@ def main():
                    "hipgraph_replay": graph_on, "cfg_mode": args.cfg_mode, "device": name, "compute_units": cus, "output_finite": finite},
         "achieved_tflops": round(value / world * FLOP_PER_UNET_STEP / 1e12, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH if not concurrent else None,
+                     "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic_bytes if not concurrent else None, "traffic_source": traffic_src if not concurrent else None,
                      "kernel": "UNet forward launch sequence (hipGraph of ~0.9k launches; the implicit-GEMM conv/linear kernels "
                                "gemm_w80/gemm_glds/gemm_g4 are 75% of it)" + (", two B=1 graphs on two streams" if concurrent else ", batch 2"),
                      "flop_per_launch": flop_per_launch, "avg_launch_ms": round(avg_launch_ms, 3), "launches": len(unet_ms)},
     }
     if world == 1 and not args.no_fifo:
         res["fifo"] = fifo_leg(dm, device, T, H, W)
-        res["vae_decode"] = vae_leg(device, H, W)
+        res["vae_decode"], ae = vae_leg(device, H, W)
         res["fifo"]["projected_s_per_video_incl_vae_decode"] = round(
             res["fifo"]["projected_s_per_video_148_iterations"] + res["vae_decode"]["s_per_video_148_frames"], 1)
+    if world == 1 and not args.no_fifo and not args.no_video:
+        res["video"] = video_leg(dm, ae, device, T, H, W)
     if world == 1 and not args.no_cpu_baseline:
         threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share
         ts = torch.full((1,), int(sampler.ddim_timesteps[S - 1]), device=device, dtype=torch.long)
-        cdt, y_cpu = cpu_baseline(dm, x, ctx, ts, threads)
+        cdt, y_cpu, ctimes = cpu_baseline(dm, x, ctx, ts, threads)
         y_gpu = dm.apply_model(x, ts, cond).float().cpu()
         err = ((y_gpu - y_cpu).abs().max() / y_cpu.abs().max()).item()
         res["cpu_baseline"] = {"value": round(1.0 / cdt, 5), "unit": "UNet-steps/s", "cores": threads, "kind": "port",
                                "sample": "1 UNet-step (fp32 oracle of the reference UNet, [1,4,%d,%d,%d], same weights/inputs), "
-                                         "%.1f s; HIP-vs-oracle max rel err %.2e" % (T, H, W, cdt, err)}
+                                         "min of %d runs (%s s); HIP-vs-oracle max rel err %.2e" % (T, H, W, len(ctimes), "/".join("%.1f" % c for c in ctimes), err)}
     print(json.dumps(res))
 
 
@@ -291,5 +420,6 @@ if __name__ == "__main__":
     try:
         main()
     finally:
-        from moca_video_amd import dist as _mdist
-        _mdist.shutdown()
+        import torch.distributed as _dist          # (not moca_video_amd.dist: the launcher parent must not load the HIP library)
+        if _dist.is_available() and _dist.is_initialized():
+            _dist.destroy_process_group()

@@ -66,3 +66,40 @@ def test_shard_indices_cover():
         for w in (1, 2, 8):
             got = sorted(i for r in range(w) for i in shard_indices(n, r, w))
             assert got == list(range(n))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks itself (the driver's SCALE run uses that
+    form) and print ONE JSON line from rank 0 with n_gpus = 2.  `--selftest-cpu` keeps the hot path out (no GPU here):
+    rendezvous, C1 broadcast, barrier, max-over-ranks and C2 gather run on gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--selftest-cpu"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks_gathered"] == [0, 1] and res["weights_equal_after_broadcast"]
+    assert res["steps"] == 3
+
+
+def test_bench_under_torchrun_env_does_not_relaunch():
+    """under torch.distributed.run (WORLD_SIZE set) bench.py must NOT spawn again: each rank is already a process"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--selftest-cpu"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1000:] for o in outs]
+    assert json.loads(outs[0][0].strip().splitlines()[-1])["n_gpus"] == 2
+    assert not any(l.lstrip().startswith("{") for l in outs[1][0].splitlines())      # only rank 0 prints the JSON line
