@@ -65,8 +65,9 @@ def _calculate_iou(masks1, masks2):
 
 def _apply_segmentation(pred_x0, cond_image, candidate_masks, pre_masks):
     """`_apply_segmentation` (ddim.py:739-903) with the Grounded-SAM-2 output replaced by `candidate_masks` ([n,H,W], or
-    None / empty for "no box detected").  PARITY UNPINNED for this branch: the reference cannot run it offline (external
-    models), so no golden exists; the restatement follows the source line by line."""
+    None / empty for "no box detected").  Pinned: tools/make_golden.py::sampler_sam_cases runs the REAL `ddim_step` with fake
+    sam2_predictor / processor / grounding_model objects returning scripted candidates (tests/golden/sampler_ddim_step_sam.npz);
+    tests/test_oracle_sampler.py holds this restatement to it bit-exactly."""
     if candidate_masks is None or len(candidate_masks) == 0:            # :788-793
         if pre_masks is None:
             return pred_x0, None

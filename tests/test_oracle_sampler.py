@@ -54,6 +54,60 @@ def test_ddim_step(tag, dims):
         assert torch.equal(momentum, torch.from_numpy(g[f"c{call}_momentum"]))
 
 
+def sam_candidates(F, H, W, seq):
+    """The scripted Grounded-SAM-2 outputs tools/make_golden.py::sam_candidates fed to the REAL `_apply_segmentation`
+    (same lists, rebuilt here: a fixture holds outputs only).  One entry per frame, None = no box detected."""
+    def rect(y0, y1, x0, x1):
+        m = torch.zeros(H, W)
+        m[y0:y1, x0:x1] = 1.0
+        return m
+    big = torch.ones(H, W)
+    if seq == 0:
+        cands = [None, rect(2, 10, 3, 12)[None], rect(2, 10, 4, 12)[None], rect(11, 15, 0, 5)[None], None,
+                 torch.stack([big, rect(1, 5, 1, 6)]), torch.stack([rect(1, 5, 1, 6), big])]
+    else:
+        cands = [torch.stack([rect(2, 10, 3, 12), big]), None, rect(2, 10, 4, 12)[None]]
+    return (cands + [None] * F)[:F]
+
+
+def sam_golden(key, F):
+    """(x_prev, pred_x0 [1,C,F,H,W], indices, ts) of tests/golden/sampler_ddim_step_sam.npz.  The reference's `torch.where`
+    broadcasts a [1,C,H,W] mask against the 5-D pred_x0 (ddim.py:897-901), so a frame that went through an injection comes
+    back REPLICATED C times along the frame axis (`frames_out` records 1 or C per frame that entered the branch); the copies
+    are asserted identical and folded to one frame here."""
+    g = golden("sampler_ddim_step_sam")
+    p0 = torch.from_numpy(g[key + "_pred_x0"])
+    counts = [int(c) for c in g[key + "_frames_out"]]
+    if counts == [0]:                       # t > 300 everywhere: the branch was never entered
+        counts = []
+    counts = counts + [1] * (F - len(counts))
+    assert sum(counts) == p0.shape[2]
+    frames, k = [], 0
+    for c in counts:
+        blk = p0[:, :, k:k + c]
+        for j in range(1, c):
+            assert torch.equal(blk[:, :, j], blk[:, :, 0])
+        frames.append(blk[:, :, :1])
+        k += c
+    return torch.from_numpy(g[key + "_x_prev"]), torch.cat(frames, 2), g[key + "_indices"], g[key + "_ts"]
+
+
+@pytest.mark.parametrize("key,seq", [("seq0_low", 0), ("seq1_low", 1), ("seq0_high", 0)])
+def test_ddim_step_sam_branch_vs_reference(key, seq):
+    """segmentation branch (ddim.py:592-606,739-903): the oracle restatement against the REAL reference code driven by
+    fake Grounded-SAM-2 objects (tools/make_golden.py::sampler_sam_cases) -- bit-exact"""
+    C, F, H, W = 4, 8, 16, 16
+    xp_g, p0_g, idx, tsn = sam_golden(key, F)
+    sch = SO.make_schedule(BUF, 64, 1.0)
+    x, e, noises, cond, _ = ddim_step_inputs("small", C, F, H, W, 0)
+    noises = noises + [inp(f"ds.small.nz0.{i}", (1, C, 1, H, W)) for i in range(len(noises), F)]
+    x, e = inp("ds.small.x0", (1, C, F, H, W)), inp("ds.small.e0", (1, C, F, H, W))
+    mom = torch.zeros(1, C, F, H, W)
+    xp, p0 = SO.ddim_step(sch, x, e, idx, cond, torch.from_numpy(tsn).long(), noises, mom, sam_masks=sam_candidates(F, H, W, seq))
+    assert torch.equal(xp, xp_g)
+    assert torch.equal(p0, p0_g)
+
+
 FI_SHAPES = ((1, 4, 1, 40, 64), (1, 4, 16, 40, 64), (1, 2, 3, 5, 7), (1, 4, 8, 32, 32))
 FI_FILTERS = (("gaussian", 0.25, 0.25), ("butterworth", 0.25, 0.25), ("ideal", 0.25, 0.25), ("box", 0.25, 0.25),
               ("gaussian", 0.3, 0.6), ("box", 0.5, 0.5))

@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from helpers import golden, inp, relerr  # noqa: E402
-from test_oracle_sampler import FI_FILTERS, FI_SHAPES, ddim_step_inputs  # noqa: E402
+from test_oracle_sampler import FI_FILTERS, FI_SHAPES, ddim_step_inputs, sam_candidates, sam_golden  # noqa: E402
 
 TOL = 2e-6
 
@@ -152,10 +152,31 @@ def _sam_candidates(F, H, W, seq):
     return (cands + [None] * F)[:F], (changed + [True] * F)[:F]
 
 
+@pytest.mark.parametrize("key,seq", [("seq0_low", 0), ("seq1_low", 1), ("seq0_high", 0)])
+def test_ddim_step_sam_branch_vs_reference_golden(key, seq):
+    """HIP `ddim_step(sam_masks=...)` against the REAL reference's segmentation branch (ddim.py:592-606,739-903) run with fake
+    Grounded-SAM-2 objects returning the same scripted candidates (tests/golden/sampler_ddim_step_sam.npz): IoU fallback,
+    > 80 % reset, factor-2 injection, t <= 300 gate.  (The reference returns an injected frame replicated C times along the
+    frame axis; `sam_golden` checks the copies are identical and folds them.)"""
+    C, F, H, W = 4, 8, 16, 16
+    xp_g, p0_g, idx, tsn = sam_golden(key, F)
+    s, _ = _sampler(64)
+    x, e = inp("ds.small.x0", (1, C, F, H, W)), inp("ds.small.e0", (1, C, F, H, W))
+    noises = [inp(f"ds.small.nz0.{i}", (1, C, 1, H, W)) for i in range(F)]
+    cond = (inp("ds.small.cond", (1, C, 1, H, W)) * 0.25 + 0.5).clamp(0, 1)
+    ts = torch.from_numpy(tsn).long()
+    cands = sam_candidates(F, H, W, seq)
+    xp, p0 = s.ddim_step(x.cuda(), e.cuda(), idx, cond.cuda(), "object.", ts.cuda(), noise=torch.cat(noises, 2).cuda(),
+                         sam_masks=[None if c is None else c.cuda() for c in cands])
+    assert relerr(xp.cpu(), xp_g) < TOL
+    assert relerr(p0.cpu(), p0_g) < TOL
+
+
 @pytest.mark.parametrize("seq", [0, 1])
 def test_ddim_step_sam_mask_branch_vs_oracle(seq):
     """The segmentation branch of ddim_step (ddim.py:592-606, 739-903) on precomputed candidate masks: HIP path vs the
-    oracle's line-by-line restatement (no reference golden can exist for this branch: it needs Grounded-SAM-2)."""
+    oracle's restatement (itself pinned bit-exactly to the real reference by test_oracle_sampler.py::
+    test_ddim_step_sam_branch_vs_reference) plus the expected "which frames changed" pattern."""
     from oracle import sampler_oracle as SO
     from test_oracle_sampler import BUF
     s, _ = _sampler(64)

@@ -247,6 +247,109 @@ def sampler_cases():
         os.chdir(cwd)
 
 
+
+def sam_candidates(F, H, W, seq):
+    """Scripted Grounded-SAM-2 outputs, one entry per frame (None = no box detected), exercising every rule of
+    `_apply_segmentation` (ddim.py:739-903); tests/test_sampler_gpu.py::_sam_candidates builds the same lists."""
+    def rect(y0, y1, x0, x1):
+        m = torch.zeros(H, W)
+        m[y0:y1, x0:x1] = 1.0
+        return m
+    big = torch.ones(H, W)
+    if seq == 0:
+        cands = [None, rect(2, 10, 3, 12)[None], rect(2, 10, 4, 12)[None], rect(11, 15, 0, 5)[None], None,
+                 torch.stack([big, rect(1, 5, 1, 6)]), torch.stack([rect(1, 5, 1, 6), big])]
+    else:
+        cands = [torch.stack([rect(2, 10, 3, 12), big]), None, rect(2, 10, 4, 12)[None]]
+    return (cands + [None] * F)[:F]
+
+
+def sampler_sam_cases():
+    """The segmentation branch of the REAL `ddim_step` (use_self_attention=False, davis_masks=None; ddim.py:592-606 ->
+    apply_cond_img -> _apply_segmentation :739-903) with the three external-model attributes replaced by fakes that
+    return scripted boxes / masks: the IoU fallback, the > 80 % reset, the factor-2 injection, the t <= 300 gate and the
+    `torch.where` broadcast (an injected frame comes back replicated C times along the frame axis) are the reference's
+    own code.  The hard-coded `.to("cuda", ...)` of :769-773 is patched to a dtype-only conversion (CPU harness)."""
+    from lvdm.models.samplers import ddim as D
+    D.DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    fm = FakeModel()
+    real_to = torch.Tensor.to
+
+    def to_nocuda(self, *a, **k):
+        if a and isinstance(a[0], str) and a[0] == "cuda":
+            return real_to(self, **k) if k else self
+        return real_to(self, *a, **k)
+
+    class FakeProcessor:
+        def __init__(self, cands):
+            self.cands, self.k = cands, 0
+
+        def __call__(self, images=None, text=None, return_tensors="pt"):
+            return {"input_ids": torch.zeros(1, 4, dtype=torch.int64), "pixel_values": torch.zeros(1, 3, 2, 2)}
+
+        def post_process_grounded_object_detection(self, outputs, input_ids, box_threshold=0.4, text_threshold=0.3, target_sizes=None):
+            c = self.cands[self.k]
+            n = 0 if c is None else c.shape[0]
+            return [{"boxes": torch.zeros(n, 4)}]
+
+    class FakePredictor:
+        def __init__(self, proc):
+            self.proc = proc
+
+        def set_image(self, img):
+            assert img.ndim == 3 and img.shape[2] == 3 and img.dtype == np.uint8
+
+        def predict(self, point_coords=None, point_labels=None, box=None, multimask_output=False):
+            c = self.proc.cands[self.proc.k]
+            assert box.shape[0] == c.shape[0]
+            return c.numpy().copy(), None, None
+
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    torch.Tensor.to = to_nocuda
+    try:
+        C, F, H, W, S = 4, 8, 16, 16, 64
+        res = {}
+        for seq in (0, 1):
+            for rng_name, lo in (("low", 3), ("high", 40)):           # t <= 300 everywhere / t > 300 everywhere
+                if rng_name == "high" and seq == 1:
+                    continue
+                s = D.DDIMSampler(fm, use_self_attention=True)         # True: skips initialize_segmentation_models (:49-50)
+                s.make_schedule(S, ddim_eta=1.0, verbose=False)
+                cands = sam_candidates(F, H, W, seq)
+                proc = FakeProcessor(cands)
+                s.processor, s.sam2_predictor, s.grounding_model = proc, FakePredictor(proc), (lambda **kw: None)
+                idx = np.arange(lo, lo + F)
+                tsn = np.asarray(s.ddim_timesteps)[idx]
+                ts = torch.Tensor(tsn.copy()).to(dtype=torch.long)
+                shape = (1, C, F, H, W)
+                x = inp("ds.small.x0", shape); e = inp("ds.small.e0", shape)
+                noises = [inp(f"ds.small.nz0.{i}", (1, C, 1, H, W)) for i in range(F)]
+                q = list(noises)
+                D.noise_like = lambda shp, dev, repeat=False: q.pop(0).clone()
+                cond = (inp("ds.small.cond", (1, C, 1, H, W)) * 0.25 + 0.5).clamp(0, 1)
+                # frame counter for the fakes: _apply_segmentation is entered once per frame with t <= 300, in frame order
+                orig = s._apply_segmentation
+                frames_seen = []
+
+                def counted(pred_x0, cond_image, target, step, pre_masks, _o=orig, _p=proc, _fs=frames_seen):
+                    _p.k = len(_fs)
+                    out = _o(pred_x0, cond_image, target, step, pre_masks)
+                    _fs.append(int(out[0].shape[2]))
+                    return out
+                s._apply_segmentation = counted
+                xp, p0 = s.ddim_step(x, e, idx, cond, "object", ts, use_self_attention=False, davis_masks=None)
+                key = f"seq{seq}_{rng_name}"
+                res[key + "_x_prev"] = xp; res[key + "_pred_x0"] = p0; res[key + "_indices"] = idx; res[key + "_ts"] = tsn
+                res[key + "_frames_out"] = np.asarray(frames_seen if frames_seen else [0])
+                print(f"sam {key}: x_prev {tuple(xp.shape)} pred_x0 {tuple(p0.shape)} frames_out {frames_seen}")
+        save("sampler_ddim_step_sam", **res)
+    finally:
+        torch.Tensor.to = real_to
+        os.chdir(cwd)
+
+
 def freeinit_cases():
     from utils.freeinit_utils import freq_mix_3d, get_freq_filter
     out = {}
@@ -342,10 +445,11 @@ def main():
     a = ap.parse_args()
     torch.set_num_threads(8)
     om, att = import_reference()
-    todo = a.only.split(",") if a.only else ["blocks", "reduced", "sampler", "freeinit", "fifo", "vae"] + (["full"] if a.full else [])
+    todo = a.only.split(",") if a.only else ["blocks", "reduced", "sampler", "sam", "freeinit", "fifo", "vae"] + (["full"] if a.full else [])
     if "blocks" in todo: blocks(om, att)
     if "reduced" in todo: unet_reduced(om)
     if "sampler" in todo: sampler_cases()
+    if "sam" in todo: sampler_sam_cases()
     if "freeinit" in todo: freeinit_cases()
     if "fifo" in todo: fifo_cases()
     if "vae" in todo: vae_cases()
