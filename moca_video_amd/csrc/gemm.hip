@@ -538,6 +538,107 @@ struct AGather {
     }
 };
 
+// ---- A-operand gather for BUFFER-addressed LDS-DMA (buffer_load_dwordx4 ... offen lds) --------------------------------------
+// Same sources as AGather's fast path, expressed as  descriptor base (SGPRs) + per-lane 32-bit byte offset (one VGPR per
+// row slot, recomputed only when the tap changes) + a block-uniform scalar byte offset per k-tile.  The hot loop then has NO
+// 64-bit per-lane pointer arithmetic (the flat-address form costs v_lshl_add_u64 / v_mov_b64 pairs per DMA instruction, which
+// compete with the MFMAs for the SIMD's issue slots), and rows that must read zeros (conv halo, t-1/t+1 outside the clip, M
+// tail) carry an offset >= 2^31 = num_records of the descriptor: the hardware range check then writes ZEROS into LDS
+// (tools/micro/buflds.hip verifies both facts on gfx950: out-of-range lanes of an LDS-DMA store 0, soffset is range-checked).
+// Requires every in-range byte offset < 2^31 (host-checked) and C % 64 == 0 resp. K % 64 == 0 (the FAST conditions).
+constexpr unsigned OOB_OFF = 0x80000000u;
+template <int AMODE, int NAP, int KS>
+struct BGather {
+    const moca_gemm_params& p;
+    int lch;
+    int64_t row_off[NAP];
+    int row_y[NAP], row_x[NAP];
+    bool row_ok[NAP];
+    unsigned a_off[NAP];          // per-lane byte offset of row slot g for the current tap
+    int tap = -1, tin = 0, tiles_per_tap;
+    int kt_next, kt_last;         // even tile of the next pair to issue; last pair of this block's k range
+
+    __device__ __forceinline__ BGather(const moca_gemm_params& p_, int lch_, int kt_begin, int kt_last_pair)
+        : p(p_), lch(lch_), tiles_per_tap(AMODE == MOCA_A_LINEAR ? (1 << 30) : p_.C / KS), kt_next(kt_begin), kt_last(kt_last_pair) {}
+
+    __device__ __forceinline__ void init_row(int g, int m) {
+        row_ok[g] = m < p.M;
+        const int mm = row_ok[g] ? m : 0;
+        if (AMODE == MOCA_A_LINEAR) {
+            row_off[g] = (int64_t)mm * p.lda;
+            row_y[g] = row_x[g] = 0;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int ohw = p.outH * p.outW;
+            int f, rem, oy, ox;
+            if (p.M < (1 << 24)) {
+                divmod24(mm, ohw, 1.0f / (float)ohw, f, rem);
+                divmod24(rem, p.outW, 1.0f / (float)p.outW, oy, ox);
+            } else {
+                f = mm / ohw; rem = mm - f * ohw;
+                oy = rem / p.outW; ox = rem - oy * p.outW;
+            }
+            row_off[g] = (int64_t)f * p.inH * p.inW;
+            row_y[g] = oy * p.stride - 1 + p.nopad_lo;
+            row_x[g] = ox * p.stride - 1 + p.nopad_lo;
+        } else {
+            int frame, pix, vid, t;
+            if (p.M < (1 << 24)) {
+                divmod24(mm, p.HW, 1.0f / (float)p.HW, frame, pix);
+                divmod24(frame, p.T, 1.0f / (float)p.T, vid, t);
+            } else {
+                frame = mm / p.HW; t = frame % p.T;
+            }
+            row_off[g] = mm;
+            row_y[g] = t;
+            row_x[g] = 0;
+        }
+    }
+
+    __device__ __forceinline__ void set_tap(int t) {
+        tap = t;
+        if (AMODE == MOCA_A_LINEAR) {
+#pragma unroll
+            for (int g = 0; g < NAP; ++g) a_off[g] = row_ok[g] ? (unsigned)((row_off[g] + lch * 8) * 2) : OOB_OFF;
+        } else if (AMODE == MOCA_A_CONV3X3) {
+            const int ky = t / 3, kx = t - ky * 3;
+            const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
+#pragma unroll
+            for (int g = 0; g < NAP; ++g) {
+                int iy = row_y[g] + ky, ix = row_x[g] + kx;
+                const bool ok = t < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+                if (p.up) { iy >>= 1; ix >>= 1; }
+                a_off[g] = ok ? (unsigned)(((row_off[g] + (int64_t)iy * p.inW + ix) * p.C + lch * 8) * 2) : OOB_OFF;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < NAP; ++g) {
+                const int tt = row_y[g] + t - 1;
+                const bool ok = t < 3 && row_ok[g] && tt >= 0 && tt < p.T;
+                a_off[g] = ok ? (unsigned)(((row_off[g] + (int64_t)(t - 1) * p.HW) * p.C + lch * 8) * 2) : OOB_OFF;
+            }
+        }
+    }
+
+    // position the stream on the pair whose even tile is kt (one integer division, prologue only)
+    __device__ __forceinline__ void seek(int kt) {
+        kt_next = kt;
+        const int t = kt / tiles_per_tap;
+        tin = kt - t * tiles_per_tap;
+        set_tap(t);
+    }
+    // step to the following pair; past the end of the k range the last pair repeats (uniform DMA accounting)
+    __device__ __forceinline__ void advance() {
+        if (kt_next + 2 <= kt_last) {
+            kt_next += 2;
+            tin += 2;
+            if (tin >= tiles_per_tap) { tin = 0; set_tap(tap + 1); }
+        }
+    }
+    // block-uniform byte offsets of the pair's EVEN tile (the odd one is + KS*2 bytes)
+    __device__ __forceinline__ unsigned a_soff() const { return (unsigned)(tin * KS * 2); }
+    __device__ __forceinline__ unsigned w_soff() const { return (unsigned)(kt_next * KS * 2); }
+};
+
 // ---- epilogue stage 2 of the direct-to-LDS kernels: the fp16 tile staged in LDS (`rows` x `out_bn`, row pitch `pitch` bytes)
 //      leaves as 16-byte coalesced stores; the time-embedding row add and the residual are added in fp32 on the way ----
 template <int NTHREADS>
@@ -1165,7 +1266,13 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
     auto dma_piece = [&](int kt, int slot, int j, int odd) {
         const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
         if (j < 2) {
+#if defined(W80_A_HOT)       // diagnostic: every A piece re-fetches the block's first k-tile (L1-hot): instruction count and LDS writes kept, L2->L1 bytes gone
+            __builtin_amdgcn_global_load_lds((glb_ptr)(ga.a_base[j] + odd * KS), sa + (j * 8 + wave) * 1024, 16, 0, 0);
+#elif defined(W80_A_SKIP)    // diagnostic: A pieces only for one k-tile pair in nine (what an LDS-resident conv halo would fetch)
+            if ((kt >> 1) % 9 == 0) __builtin_amdgcn_global_load_lds((glb_ptr)ga.src(kt, j, odd), sa + (j * 8 + wave) * 1024, 16, 0, 0);
+#else
             __builtin_amdgcn_global_load_lds((glb_ptr)ga.src(kt, j, odd), sa + (j * 8 + wave) * 1024, 16, 0, 0);
+#endif
         } else if (j == 2) {
             const half_t* sA = ga.src(kt, 2, odd);
             const half_t* sw = w_row[0] + kt * KS;
@@ -1322,6 +1429,221 @@ __global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params
 #endif
 }
 
+// "w80b": the w80 kernel with BUFFER-addressed LDS-DMA (BGather above): descriptor in SGPRs + one 32-bit VGPR offset per row
+// slot + scalar k offsets, zero fill by the hardware range check.  Same tiles, ring, schedule, fragment reads and epilogue as
+// gemm_w80_kernel; only the source addressing of the DMA stream differs.  Fast-gather shapes only (C % 64 == 0 / K % 64 == 0).
+template <int AMODE>
+__global__ __launch_bounds__(512, 2) void gemm_w80b_kernel(const moca_gemm_params p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the launch stub; __amdgpu_buffer_rsrc_t is a device-only type)
+    constexpr int MT = 5, NT = 5, BN = 160, KS = 32, RB = 64;
+    constexpr int TM = 320;
+    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB;     // 20 + 10 KiB
+    constexpr int NS = 5;
+    constexpr int PPW = 4;                               // DMA instructions per wave per k-tile (30 pieces + 2 repeats)
+    constexpr int NAP = 3;                               // A piece slots per wave (the third one only for waves 0..3)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MOCA_STAMP(0);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    const int tiles_m = (p.M + TM - 1) / TM;
+    const int tiles_n = p.N / BN;
+    const int nblk = tiles_m * tiles_n * p.splits;
+    int logical;
+    remap_block<BN>(nblk, logical);
+    const int split = logical % p.splits;
+    const int tile = logical / p.splits;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int m0 = tile_m * TM, n0 = tile_n * BN;
+
+    const int nk_total = 2 * ((p.K + 63) / 64);
+    const int kts = 2 * (((p.K + 63) / 64 + p.splits - 1) / p.splits);      // split in 64-deep units, as the host sizes it
+    const int kt_begin = split * kts;
+    const int nk = min(kt_begin + kts, nk_total) - kt_begin;
+
+    // DMA piece = 16 rows x 64 B: lane -> row (lane >> 2), physical chunk lane & 3.  Wave w moves
+    //   j = 0: A piece w        j = 1: A piece 8 + w
+    //   j = 2: A piece 16 + w (w < 4)  or  W piece w - 4 (w >= 4)
+    //   j = 3: W piece 4 + w (w < 6)   or  W piece 2 + w (w = 6, 7: a repeat of what waves 4, 5 fetch)
+    const int lrow = lane >> 2, pch = lane & 3;
+    const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
+    const bool flex_is_a = wave < 4;
+    const int kt_last_pair = kt_begin + nk - 2;          // nk is even: the last (even, odd) pair of this block's k range
+    BGather<AMODE, NAP, KS> ga(p, lch, kt_begin, kt_last_pair);
+#pragma unroll
+    for (int g = 0; g < NAP; ++g) ga.init_row(g, m0 + (g < 2 ? g * 8 + wave : 16 + (wave & 3)) * 16 + lrow);
+    const int w_piece0 = wave & 3;                        // j = 2 (waves 4..7)
+    const int w_piece1 = wave < 6 ? 4 + wave : 2 + wave;  // j = 3
+    const unsigned w_off0 = (unsigned)(((int64_t)(n0 + w_piece0 * 16 + lrow) * p.ldw + lch * 8) * 2);
+    const unsigned w_off1 = (unsigned)(((int64_t)(n0 + w_piece1 * 16 + lrow) * p.ldw + lch * 8) * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, OOB_OFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, OOB_OFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_f = flex_is_a ? rsrc_a : rsrc_w;          // wave-uniform: piece j = 2 is an A piece for waves 0..3
+
+    // DMA instruction j (0..3) of this wave for the tile `odd` of the pair the gather stream stands on, into ring slot `slot`
+    // (the k offset of the odd tile goes into soffset, NOT the instruction's immediate: on an LDS-DMA the immediate offset is
+    //  added to the LDS address as well as to the memory address)
+    auto dma_piece = [&](int slot, int j, auto odd_tag) {
+        constexpr int odd = decltype(odd_tag)::value;
+        const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
+        if (j < 2) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, sa + (j * 8 + wave) * 1024, 16, ga.a_off[j], ga.a_soff() + odd * KS * 2, 0, 0);
+        } else if (j == 2) {
+            const unsigned voff = flex_is_a ? ga.a_off[2] : w_off0;
+            const unsigned soff = flex_is_a ? ga.a_soff() : ga.w_soff();
+            const lds_ptr dst = flex_is_a ? sa + (16 + (wave & 3)) * 1024 : sa + A_BYTES + w_piece0 * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_f, dst, 16, voff, soff + odd * KS * 2, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, sa + A_BYTES + w_piece1 * 1024, 16, w_off1, ga.w_soff() + odd * KS * 2, 0, 0);
+        }
+    };
+    // k-tiles are fetched in PAIRS (2m, 2m+1): the two 64-byte halves of every 128-byte line of A and W are requested back
+    // to back (see gemm_w80_kernel)
+    auto issue_pair = [&](int slot_even, int slot_odd) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            dma_piece(slot_even, j, int_c<0>{});
+            dma_piece(slot_odd, j, int_c<1>{});
+        }
+    };
+
+    const int fr = lane & 15, fg = lane >> 4;
+    // accumulators start from the bias of their 4 columns (n = wave_n*80 + nt*16 + 4*fg + r): the epilogue is then a pure
+    // fp32 -> fp16 conversion.  With split-k the bias is added once, by the reduce kernel.
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && p.splits == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + wave_n * 80 + nt * 16 + 4 * fg);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
+    }
+
+    // fragment byte offsets inside a slot; tile rows advance in steps of 16, which leaves the swizzle term unchanged
+    const int swz = (fg ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
+    const int a_off0 = (wave_m * 80 + fr) * RB + swz;
+    const int b_off0 = A_BYTES + (wave_n * 80 + fr) * RB + swz;
+
+    half8v af[2][MT], bf[2][NT];
+    auto read_frag = [&](auto set_tag, int slot, int r) {      // r-th fragment read of a tile: W first, then A
+        constexpr int S = decltype(set_tag)::value;
+        const char* cur = smem + slot * STAGE;
+        if (r < NT) bf[S][r] = *reinterpret_cast<const half8v*>(cur + b_off0 + r * 1024);
+        else af[S][r - NT] = *reinterpret_cast<const half8v*>(cur + a_off0 + (r - NT) * 1024);
+    };
+    auto sync_tiles = [&](auto n_tag) {      // at most n younger DMA groups of this wave in flight, then barrier
+        constexpr int n = decltype(n_tag)::value;
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n * PPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    int s_cur = 0, s_nxt = 1;          // ring slots of tiles i and i+1
+    constexpr int NMMA = MT * NT, NRD = MT + NT;
+    // phase i: MFMAs of tile i from fragment set S = i & 1; reads of tile i+1 into the other set; EVEN phases also issue the
+    // pair (i+4, i+5): tile i+4 goes to the slot of tile i-1, tile i+5 to the slot of tile i (both fully read by now).
+    auto phase = [&](auto set_tag, int i) {
+        constexpr int S = decltype(set_tag)::value;
+        const int s_prev = s_cur == 0 ? NS - 1 : s_cur - 1;
+        if constexpr (S == 0) ga.advance();               // the pair (i+4, i+5) (clamped to the last pair of the k range)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < NMMA; ++j) {
+            const int mt = j / NT, nt = j % NT;
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[S][nt], af[S][mt], acc[mt][nt], 0, 0, 0);   // D^T: lane = row m
+            // (the fences keep the first read BEHIND MFMA 0: the compiler cannot see the inline-asm waits, so it puts an
+            //  lgkmcnt(0) of its own in front of the first use of the fragment registers -- free while nothing is in flight)
+            if (j % 2 == 0 && j / 2 < NRD) {
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef W80_NO_READ
+                read_frag(int_c<1 - S>{}, s_nxt, j / 2);      // (past the last tile this reads a never-used slot into the idle set)
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (S == 0) {
+                if (j % 3 == 1 && j / 3 < 2 * PPW) {
+                    const int q = j / 3;                       // 0..7: piece q>>1 of the even tile, then of its odd partner
+                    __builtin_amdgcn_sched_barrier(0);
+#ifndef W80_NO_DMA
+                    if (q & 1) dma_piece(s_cur, q >> 1, int_c<1>{});
+                    else dma_piece(s_prev, q >> 1, int_c<0>{});
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        s_cur = s_nxt;
+        s_nxt = (s_nxt + 1 == NS) ? 0 : s_nxt + 1;
+    };
+
+    // ---- prologue: tiles 0..3 (two pairs) in flight, fragments of tile 0 in set 0 ----
+    // The DMA instructions of a pair are issued interleaved (even piece j, odd piece j, ...), so a pair lands as a unit:
+    // the waits count whole pairs (8 instructions per wave).
+    ga.seek(kt_begin);
+    issue_pair(0, 1);
+    ga.advance();
+    issue_pair(2, 3);
+    MOCA_STAMP(1);
+    sync_tiles(int_c<2>{});                          // pair (0, 1) landed; pair (2, 3) may fly
+    MOCA_STAMP(2);
+#pragma unroll
+    for (int r = 0; r < NRD; ++r) read_frag(int_c<0>{}, 0, r);
+    sync_tiles(int_c<2>{});                          // everyone has read tile 0 (its slot is reused by phase 0's DMA)
+    // even phase i issues pair (i+4, i+5) and then needs tile i+2: pair (i+2, i+3) complete, the new pair may fly;
+    // the odd phase i+1 issues nothing and needs tile i+3, which landed with its partner
+    for (int i = 0; i < nk; i += 2) {
+        phase(int_c<0>{}, i);
+        sync_tiles(int_c<2>{});
+        phase(int_c<1>{}, i + 1);
+        sync_tiles(int_c<2>{});
+    }
+    sync_tiles(int_c<0>{});            // every DMA (incl. the repeats) and fragment read is done: the ring is free for the epilogue
+    MOCA_STAMP(3);
+
+    // ---- epilogue: lane owns 4 consecutive columns n = wave_n*80 + nt*16 + 4*fg + r of row m = wave_m*80 + mt*16 + fr ----
+    if (p.splits > 1) {
+        float* ws = p.splitk_ws + (int64_t)split * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = m0 + wave_m * 80 + mt * 16 + fr;
+            if (row < p.M) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = n0 + wave_n * 80 + nt * 16 + 4 * fg;
+                    *reinterpret_cast<f32x4*>(ws + (int64_t)row * p.N + col) = acc[mt][nt];
+                }
+            }
+        }
+        return;
+    }
+    constexpr int pitch = BN * 2 + 16;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = wave_n * 80 + nt * 16 + 4 * fg;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = wave_m * 80 + mt * 16 + fr;
+            *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = __builtin_convertvector(acc[mt][nt], half4v);
+        }
+    }
+    __syncthreads();
+    MOCA_STAMP(4);
+    store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
+    MOCA_STAMP(5);
+#ifdef MOCA_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_stamps[blockIdx.x * STAMP_SLOTS + 6] = hw;
+        g_stamps[blockIdx.x * STAMP_SLOTS + 7] = xcc;
+    }
+#endif
+#endif
+}
+
 template <int AMODE, bool FAST>
 int launch_gemm_w80(const moca_gemm_params& p, hipStream_t st) {
     const int tiles_m = (p.M + 319) / 320, tiles_n = p.N / 160;
@@ -1339,7 +1661,289 @@ int launch_gemm_w80(const moca_gemm_params& p, hipStream_t st) {
     return MOCA_OK;
 }
 
+
+// =====================================================================================
+// "w80s" kernel: the 320 x 160 x 32 tile / 80 x 80 wave tile / 5-slot ring of w80b, with the main loop cut into
+// LOAD and MFMA SEGMENTS and the two waves of every SIMD running half an iteration apart.
+//
+// Why.  In w80/w80b every wave interleaves its own ds_reads and DMA instructions with its own MFMAs and all eight waves
+// run in lockstep (one barrier per k-tile), so the two waves of a SIMD want the matrix pipe at the same moments and issue
+// their memory instructions at the same moments.  Ablations on the same device (tools/ab_run1.sh): without the DMA
+// instructions the conv loop runs 20 % faster, without the fragment reads 18 %, without both 39 % (1.6-1.8 PFLOP/s) --
+// the costs ADD, i.e. nothing overlaps them; moving the DMA addressing to SGPR descriptors (w80b) or dropping 8 of 9 A
+// fetches changes nothing, so it is neither the address arithmetic nor the L2->LDS bytes: it is the in-order issue of
+// each wave.  Here a wave's MFMAs issue back to back from registers (25 per k-tile, nothing in between) while its SIMD
+// partner is in its LOAD segment (fragment reads for two k-tiles, or the 8 DMA instructions of a k-tile pair, and the
+// counted waits), and vice versa: waves 4..7 pass one extra barrier before the loop and waves 0..3 one after it, so the
+// halves stay exactly one barrier apart (MI355X_MICROARCH.md, "Two waves per SIMD", items 5 and 9).
+//
+// One iteration = two k-tiles (i, i+1), four barriers:
+//   LOADe : 10 ds_read_b128 -- the fragments of tile i;  lgkmcnt(0);  barrier
+//   MFMAe : 25 MFMAs of tile i with the 10 fragment reads of tile i+1 (second register set) in the gaps;  lgkmcnt(0);  barrier
+//   LOADo : 8 DMA instructions = the pair (i+4, i+5) into the slots of tiles i-1 and i (both in registers everywhere: the
+//           partner half finished its LOADe reads before the barrier this half has just passed);  vmcnt(8): the pair
+//           (i+2, i+3) of this wave has landed;  barrier
+//   MFMAo : 25 MFMAs of tile i+1;  barrier
+// A DMA has two k-tiles of time to land (as in w80); data is read two barriers after the wait that retires it.
+// =====================================================================================
+template <int AMODE>
+__global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_params p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the launch stub; __amdgpu_buffer_rsrc_t is a device-only type)
+    constexpr int MT = 5, NT = 5, BN = 160, KS = 32, RB = 64;
+    constexpr int TM = 320;
+    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB;     // 20 + 10 KiB
+    constexpr int NS = 5;
+    constexpr int PPW = 4;                               // DMA instructions per wave per k-tile (30 pieces + 2 repeats)
+    constexpr int NAP = 3;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const bool late = wave >= 4;                         // the half of the workgroup that runs one barrier behind
+
+    const int tiles_m = (p.M + TM - 1) / TM;
+    const int tiles_n = p.N / BN;
+    const int nblk = tiles_m * tiles_n * p.splits;
+    int logical;
+    remap_block<BN>(nblk, logical);
+    const int split = logical % p.splits;
+    const int tile = logical / p.splits;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int m0 = tile_m * TM, n0 = tile_n * BN;
+
+    const int nk_total = 2 * ((p.K + 63) / 64);
+    const int kts = 2 * (((p.K + 63) / 64 + p.splits - 1) / p.splits);
+    const int kt_begin = split * kts;
+    const int nk = min(kt_begin + kts, nk_total) - kt_begin;
+
+    // DMA pieces exactly as in w80 / w80b
+    const int lrow = lane >> 2, pch = lane & 3;
+    const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
+    const bool flex_is_a = wave < 4;
+    const int kt_last_pair = kt_begin + nk - 2;
+    BGather<AMODE, NAP, KS> ga(p, lch, kt_begin, kt_last_pair);
+#pragma unroll
+    for (int g = 0; g < NAP; ++g) ga.init_row(g, m0 + (g < 2 ? g * 8 + wave : 16 + (wave & 3)) * 16 + lrow);
+    const int w_piece0 = wave & 3;
+    const int w_piece1 = wave < 6 ? 4 + wave : 2 + wave;
+    const unsigned w_off0 = (unsigned)(((int64_t)(n0 + w_piece0 * 16 + lrow) * p.ldw + lch * 8) * 2);
+    const unsigned w_off1 = (unsigned)(((int64_t)(n0 + w_piece1 * 16 + lrow) * p.ldw + lch * 8) * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, OOB_OFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, OOB_OFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_f = flex_is_a ? rsrc_a : rsrc_w;
+
+    auto dma_piece = [&](int slot, int j, auto odd_tag) {
+        constexpr int odd = decltype(odd_tag)::value;
+        const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
+        if (j < 2) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, sa + (j * 8 + wave) * 1024, 16, ga.a_off[j], ga.a_soff() + odd * KS * 2, 0, 0);
+        } else if (j == 2) {
+            const unsigned voff = flex_is_a ? ga.a_off[2] : w_off0;
+            const unsigned soff = flex_is_a ? ga.a_soff() : ga.w_soff();
+            const lds_ptr dst = flex_is_a ? sa + (16 + (wave & 3)) * 1024 : sa + A_BYTES + w_piece0 * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_f, dst, 16, voff, soff + odd * KS * 2, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, sa + A_BYTES + w_piece1 * 1024, 16, w_off1, ga.w_soff() + odd * KS * 2, 0, 0);
+        }
+    };
+    auto issue_pair = [&](int slot_even, int slot_odd) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            dma_piece(slot_even, j, int_c<0>{});
+            dma_piece(slot_odd, j, int_c<1>{});
+        }
+    };
+
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && p.splits == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + wave_n * 80 + nt * 16 + 4 * fg);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
+    }
+
+    const int swz = (fg ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
+    const int a_off0 = (wave_m * 80 + fr) * RB + swz;
+    const int b_off0 = A_BYTES + (wave_n * 80 + fr) * RB + swz;
+
+    half8v af[2][MT], bf[2][NT];
+    auto read_tile = [&](auto set_tag, int slot) {
+        constexpr int S = decltype(set_tag)::value;
+        const char* cur = smem + slot * STAGE;
+#pragma unroll
+        for (int r = 0; r < NT; ++r) bf[S][r] = *reinterpret_cast<const half8v*>(cur + b_off0 + r * 1024);
+#pragma unroll
+        for (int r = 0; r < MT; ++r) af[S][r] = *reinterpret_cast<const half8v*>(cur + a_off0 + r * 1024);
+    };
+    auto mfma_tile = [&](auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[S][nt], af[S][mt], acc[mt][nt], 0, 0, 0);   // D^T: lane = row m
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: pairs (0,1) and (2,3) in flight, pair (0,1) landed everywhere ----
+    ga.seek(kt_begin);
+    issue_pair(0, 1);
+    ga.advance();
+    issue_pair(2, 3);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();            // from here on waves 4..7 run one barrier behind waves 0..3
+
+    int s0 = 0;                                          // ring slot of tile i
+    for (int i = 0; i < nk; i += 2) {
+        const int s1 = s0 + 1 == NS ? 0 : s0 + 1;        // tile i+1
+        const int sp = s0 == 0 ? NS - 1 : s0 - 1;        // tile i-1 (consumed) -> tile i+4
+#if defined(W80S_VARIANT) && W80S_VARIANT == 0    // (A/B build: both fragment sets read in LOADe, MFMAe pure; 1-3 % slower)
+        // ---- LOADe ----
+        read_tile(int_c<0>{}, s0);
+        read_tile(int_c<1>{}, s1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- MFMAe ----
+        mfma_tile(int_c<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+#else
+        // ---- LOADe: tile i only ----
+        read_tile(int_c<0>{}, s0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- MFMAe with the reads of tile i+1 in the gaps ----
+        {
+            const char* nx = smem + s1 * STAGE;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < MT * NT; ++j) {
+                const int mt = j / NT, nt = j % NT;
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][nt], af[0][mt], acc[mt][nt], 0, 0, 0);
+                if (j % 2 == 0 && j / 2 < MT + NT) {
+                    const int r = j / 2;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r < NT) bf[1][r] = *reinterpret_cast<const half8v*>(nx + b_off0 + r * 1024);
+                    else af[1][r - NT] = *reinterpret_cast<const half8v*>(nx + a_off0 + (r - NT) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+#endif
+        // ---- LOADo ----
+        ga.advance();
+        issue_pair(sp, s0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- MFMAo ----
+        mfma_tile(int_c<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        s0 = s1 + 1 == NS ? 0 : s1 + 1;
+    }
+    if (!late) __builtin_amdgcn_s_barrier();           // the halves meet again
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // every DMA (incl. the repeats) is done: the ring is free for the epilogue
+
+    // ---- epilogue (as w80): lane owns 4 consecutive columns n = wave_n*80 + nt*16 + 4*fg + r of row m = wave_m*80 + mt*16 + fr ----
+    if (p.splits > 1) {
+        float* ws = p.splitk_ws + (int64_t)split * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = m0 + wave_m * 80 + mt * 16 + fr;
+            if (row < p.M) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = n0 + wave_n * 80 + nt * 16 + 4 * fg;
+                    *reinterpret_cast<f32x4*>(ws + (int64_t)row * p.N + col) = acc[mt][nt];
+                }
+            }
+        }
+        return;
+    }
+    constexpr int pitch = BN * 2 + 16;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = wave_n * 80 + nt * 16 + 4 * fg;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = wave_m * 80 + mt * 16 + fr;
+            *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = __builtin_convertvector(acc[mt][nt], half4v);
+        }
+    }
+    __syncthreads();
+    store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
+#endif
+}
+
+template <int AMODE>
+int launch_gemm_w80s(const moca_gemm_params& p, hipStream_t st) {
+    const int tiles_m = (p.M + 319) / 320, tiles_n = p.N / 160;
+    const int nblk = tiles_m * tiles_n * p.splits;
+    constexpr int lds = 5 * (320 + 160) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w80s_kernel<AMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MOCA_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_w80s_kernel<AMODE>), dim3(nblk), dim3(512), lds, st, p);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+template <int AMODE>
+int launch_gemm_w80b(const moca_gemm_params& p, hipStream_t st) {
+    const int tiles_m = (p.M + 319) / 320, tiles_n = p.N / 160;
+    const int nblk = tiles_m * tiles_n * p.splits;
+    constexpr int lds = 5 * (320 + 160) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w80b_kernel<AMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MOCA_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_w80b_kernel<AMODE>), dim3(nblk), dim3(512), lds, st, p);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+// bytes spanned by the A operand / the W operand: the buffer-addressed kernels need every in-range offset below 2^31
+static inline int64_t a_span_bytes(const moca_gemm_params& p) {
+    if (p.a_mode == MOCA_A_LINEAR) return ((int64_t)p.M * p.lda + 64) * 2;
+    if (p.a_mode == MOCA_A_CONV3X3) return ((int64_t)(p.M / (p.outH * p.outW)) * p.inH * p.inW * p.C + 64) * 2;
+    return ((int64_t)p.M * p.C + 64) * 2;
+}
+static inline bool buffer_addressable(const moca_gemm_params& p) {
+    return a_span_bytes(p) < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
+}
+
 int launch_gemm_w80_mode(const moca_gemm_params& p, bool fastp, hipStream_t st) {
+    const char* e_buf = getenv("MOCA_GEMM_BUF");      // A/B runs: 0 = flat-address w80, 1 = buffer-addressed w80b, 2 (default) = staggered w80s
+    const int buf_mode = e_buf ? atoi(e_buf) : 2;
+    if (fastp && buf_mode == 2 && buffer_addressable(p)) {
+        if (p.a_mode == MOCA_A_LINEAR) return launch_gemm_w80s<MOCA_A_LINEAR>(p, st);
+        if (p.a_mode == MOCA_A_CONV3X3) return launch_gemm_w80s<MOCA_A_CONV3X3>(p, st);
+        return launch_gemm_w80s<MOCA_A_TCONV3>(p, st);
+    }
+    if (fastp && buf_mode == 1 && buffer_addressable(p)) {
+        if (p.a_mode == MOCA_A_LINEAR) return launch_gemm_w80b<MOCA_A_LINEAR>(p, st);
+        if (p.a_mode == MOCA_A_CONV3X3) return launch_gemm_w80b<MOCA_A_CONV3X3>(p, st);
+        return launch_gemm_w80b<MOCA_A_TCONV3>(p, st);
+    }
     if (p.a_mode == MOCA_A_LINEAR) return fastp ? launch_gemm_w80<MOCA_A_LINEAR, true>(p, st) : launch_gemm_w80<MOCA_A_LINEAR, false>(p, st);
     if (p.a_mode == MOCA_A_CONV3X3) return fastp ? launch_gemm_w80<MOCA_A_CONV3X3, true>(p, st) : launch_gemm_w80<MOCA_A_CONV3X3, false>(p, st);
     return fastp ? launch_gemm_w80<MOCA_A_TCONV3, true>(p, st) : launch_gemm_w80<MOCA_A_TCONV3, false>(p, st);

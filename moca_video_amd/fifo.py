@@ -49,14 +49,49 @@ def prepare_latents(args, input_path, sampler, model=None, data=None, initial_la
     return torch.cat(latents_list, dim=2)
 
 
-def shift_latents(latents, noise=None):
-    """funcs.py:86-99: dequeue frame 0, shift left, enqueue FreeInit-mixed noise."""
-    anchor_frame = latents[:, :, 0].clone().unsqueeze(2)
+def shift_latents(latents, davis_data=None, model=None, noise=None, anchor_noise=None):
+    """funcs.py:86-118: dequeue frame 0, shift left, enqueue FreeInit-mixed noise.
+
+    Prompt mode (`davis_data` None, :88-99): the FreeInit anchor is the dequeued frame.  Returns `latents`.
+    DAVIS mode (`davis_data = (frames [b,3|4,t,H,W], masks [b,1,t,h,w])`, :101-118): the anchor is the VAE encoding
+    (`model.encode_first_stage_2DAE`, a fresh posterior sample per call; `anchor_noise` [b,4,1,h,w] fixes the draw) of the
+    LAST DAVIS frame, and the mask queue is shifted with its tail refilled from its own last frame.  Returns
+    `(latents, (frames, masks))` like the reference."""
+    if davis_data is None:
+        anchor_frame = latents[:, :, 0].clone().unsqueeze(2)
+    else:
+        frames, masks = davis_data
+        anchor_frame = frames[:, :, -1].clone().unsqueeze(2)
+        if anchor_frame.shape[1] == 4:                        # RGBA -> RGB (:104-105)
+            anchor_frame = anchor_frame[:, :3]
+        anchor_frame = model.encode_first_stage_2DAE(anchor_frame.to(latents.device), noise=anchor_noise)
     latents[:, :, :-1] = latents[:, :, 1:].clone()
     new_noise = (torch.randn_like(latents[:, :, -1]) if noise is None else noise.to(latents.device, latents.dtype).reshape(latents[:, :, -1].shape)).unsqueeze(2)
     freq_filter = get_freq_filter(anchor_frame.shape, latents.device, "gaussian", 1, 0.25, 0.25)
     latents[:, :, -1] = freq_mix_3d(anchor_frame, new_noise, freq_filter).squeeze(2)
-    return latents
+    if davis_data is None:
+        return latents
+    masks[:, :, :-1] = masks[:, :, 1:].clone()
+    masks[:, :, -1] = masks[:, :, -1].clone()                 # :116 (the tail keeps the last DAVIS mask)
+    return latents, (frames, masks)
+
+
+def uncond_embedding(model, c_emb, uc_emb):
+    """The unconditional context of funcs.py:199-208 / :268-270: `model.uncond_type == "empty_seq"` (the YAML's value) is
+    the text encoding of the EMPTY PROMPT -- it needs the text encoder, so the caller must pass it (`uc_emb`, e.g.
+    `embed_text("")`); only `"zero_embed"` is zeros.  Passing nothing under "empty_seq" raises instead of silently
+    sampling with a different unconditional branch than the reference."""
+    if uc_emb is not None:
+        return uc_emb
+    utype = getattr(model, "uncond_type", "empty_seq")
+    if utype == "zero_embed":
+        return torch.zeros_like(c_emb)
+    if utype == "empty_seq":
+        if getattr(model, "cond_stage_model", None) is not None and hasattr(model, "empty_prompt_tokens"):
+            return model.get_learned_conditioning(model.empty_prompt_tokens.expand(c_emb.shape[0], -1))
+        raise ValueError('uncond_type == "empty_seq": classifier-free guidance needs the text encoding of the empty prompt; '
+                         'pass uc_emb=embed_text("") (funcs.py:199-203)')
+    raise NotImplementedError(f"uncond_type {utype!r}")
 
 
 def base_ddim_sampling(model, cond, noise_shape, ddim_steps=50, ddim_eta=1.0, cfg_scale=1.0, uc_emb=None,
@@ -67,9 +102,8 @@ def base_ddim_sampling(model, cond, noise_shape, ddim_steps=50, ddim_eta=1.0, cf
     sampler = DDIMSampler(model)
     uc = None
     if cfg_scale != 1.0:
-        if uc_emb is None:
-            c_emb = cond["c_crossattn"][0] if isinstance(cond, dict) else cond
-            uc_emb = torch.zeros_like(c_emb)              # uncond_type == "zero_embed" (:204-206)
+        c_emb = cond["c_crossattn"][0] if isinstance(cond, dict) else cond
+        uc_emb = uncond_embedding(model, c_emb, uc_emb)   # model.uncond_type (:199-206)
         if isinstance(cond, dict):
             uc = {key: cond[key] for key in cond.keys()}
             uc.update({'c_crossattn': [uc_emb]})
@@ -95,23 +129,27 @@ def fifo_windows(args):
 def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg_scale=1.0, uc_emb=None,
                        latents=None, latents_dir=None, conditioned_image=None, masks=None, gamma=0.5, emit=None,
                        n_iterations=None, batch_windows=True, noises=None, shift_noises=None, decode=False, decode_batch=8,
-                       **kwargs):
+                       davis_data=None, anchor_noises=None, **kwargs):
     """funcs.py:243-373: returns the list of emitted latent frames [B,4,1,h,w]; with decode=True (and a model built with
     `first_stage_config`) the list of decoded frames [B,3,1,8h,8w] instead -- `model.decode_first_stage_2DAE` of funcs.py:360,
     run on `decode_batch` emitted frames at a time rather than once per iteration.
-    `masks` [B,1,Q,h,w] (Q = queue length) plays the role of the DAVIS masks (:296-302,315).
+    `masks` [B,1,Q,h,w] (Q = queue length) plays the role of the DAVIS masks (:296-302,315).  With `davis_data = (frames,
+    masks)` (DAVIS-video mode) the masks come from it and every queue shift takes the reference's DAVIS branch of
+    `shift_latents` (anchor = VAE encoding of the last DAVIS frame, mask tail refill; funcs.py:101-118,368-369).
     batch_windows=True evaluates the 2n windows of an iteration as one batched UNet launch (SURVEY 8f N2);
     `noises[i][w]` / `shift_noises[i]` optionally fix the per-window DDIM noise and the enqueued noise."""
     kwargs.update({"clean_cond": True})
     cond = conditioning
     uc = None
     if cfg_scale != 1.0:
-        if uc_emb is None:
-            uc_emb = torch.zeros_like(cond["c_crossattn"][0])
+        uc_emb = uncond_embedding(model, cond["c_crossattn"][0], uc_emb)       # :268-270
         uc = {key: cond[key] for key in cond.keys()}
         uc.update({'c_crossattn': [uc_emb]})
+    if davis_data is not None:
+        davis_data = (davis_data[0].to(model.device), davis_data[1].to(model.device))     # :296-300
+        masks = davis_data[1]
     if latents is None:
-        latents = prepare_latents(args, latents_dir, ddim_sampler)
+        latents = prepare_latents(args, latents_dir, ddim_sampler, model=model, data=davis_data)
     f = args.video_length
     timesteps = ddim_sampler.ddim_timesteps
     indices = np.arange(args.num_inference_steps)
@@ -155,9 +193,14 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
                 pending = []
         else:
             frames.append(frame if emit is None else emit(frame))
-        latents = shift_latents(latents, noise=None if shift_noises is None else shift_noises[i])
-        if masks is not None:
-            masks[:, :, :-1] = masks[:, :, 1:].clone()
+        sn = None if shift_noises is None else shift_noises[i]
+        if davis_data is not None:                                                  # :367-369
+            latents, davis_data = shift_latents(latents, davis_data, model, noise=sn,
+                                                anchor_noise=None if anchor_noises is None else anchor_noises[i])
+        else:
+            latents = shift_latents(latents, noise=sn)
+            if masks is not None:            # masks handed in directly (prompt mode + precomputed masks): keep them aligned
+                masks[:, :, :-1] = masks[:, :, 1:].clone()
     if pending:
         frames.extend(decode_frames(model, pending))
     return frames

@@ -169,6 +169,13 @@ def save_frames(images, savedir, ext="png"):
         (im if hasattr(im, "save") else Image.fromarray(im)).save(os.path.join(savedir, f"{i}.{ext}"))
 
 
+def _empty_prompt_embedding(model, embed_text, uc_emb):
+    """the unconditional context of the drivers: `uncond_type == "empty_seq"` -> the text encoding of "" (funcs.py:199-203)"""
+    if uc_emb is None and getattr(model, "uncond_type", "empty_seq") == "empty_seq":
+        return embed_text("")
+    return uc_emb
+
+
 def run_prompts(args, model, embed_text, cond_image_fn=None, mask_fn=None, root=".", uc_emb=None, decode=True, rank=None,
                 num_processes=None, n_iterations=None):
     """The prompt-mode loop of videocrafter_main.py:176-232 on the drop-in classes.
@@ -177,6 +184,7 @@ def run_prompts(args, model, embed_text, cond_image_fn=None, mask_fn=None, root=
     cond_image_fn(row) -> conditioned-image latents [1,4,1,h,w]; mask_fn(row, shape) -> masks [1,1,Q,h,w] (the
     Grounded-SAM-2 output).  Rows go to `rank` by `indices[rank::num_processes]`.  Returns {row index: output path}."""
     rows = load_prompts(args.prompt_file, getattr(args, "prompt_index", None))
+    uc_emb = _empty_prompt_embedding(model, embed_text, uc_emb)
     rank = getattr(args, "rank", 0) if rank is None else rank
     nproc = getattr(args, "num_processes", 1) if num_processes is None else num_processes
     h, w = args.height // 8, args.width // 8
@@ -204,7 +212,7 @@ def run_prompts(args, model, embed_text, cond_image_fn=None, mask_fn=None, root=
         frames = fifo_ddim_sampling(args, model, cond, noise_shape, sampler, args.unconditional_guidance_scale, uc_emb=uc_emb,
                                     latents_dir=lat_dir, conditioned_image=cimg, masks=masks, gamma=data["gamma"],
                                     decode=decode, n_iterations=n_iterations)
-        keep = frames[-(args.new_video_length // 2):]                        # videocrafter_main.py:228-230
+        keep = frames[-args.new_video_length // 2:]                          # videocrafter_main.py:228-230 (verbatim: -N//2 floors)
         if decode:
             path = save_gif(torch.cat(keep, dim=2), out_dir, "fifo", duration_ms=int(1000 / args.output_fps))
         else:
@@ -229,14 +237,15 @@ def run_davis(args, model, embed_text, prompt, cond_image=None, root=".", uc_emb
     cond = {"c_crossattn": [embed_text(prompt)], "fps": fps}
     sampler = DDIMSampler(model)
     sampler.make_schedule(ddim_num_steps=args.num_inference_steps, ddim_eta=args.eta, verbose=False)
-    latents = prepare_latents(args, lat_dir, sampler, model=model, data=(frames, masks))
+    uc_emb = _empty_prompt_embedding(model, embed_text, uc_emb)
     masks = masks.to(model.device)
-    if masks.shape[2] < latents.shape[2]:                       # short clips: the remaining queue frames carry no mask
-        pad = torch.zeros(1, 1, latents.shape[2] - masks.shape[2], h, w, device=masks.device)
-        masks = torch.cat([masks, pad], dim=2)
+    if masks.shape[2] < Q:                                       # short clips: the remaining queue frames carry no mask
+        masks = torch.cat([masks, torch.zeros(1, 1, Q - masks.shape[2], h, w, device=masks.device)], dim=2)
+    # davis_data goes into the FIFO loop as in videocrafter_main.py:147-163: the queue is the VAE encoding of the frames
+    # (prepare_latents, funcs.py:38-48) and every shift takes the DAVIS branch of shift_latents (funcs.py:101-118)
     out = fifo_ddim_sampling(args, model, cond, [1, 4, f, h, w], sampler, args.unconditional_guidance_scale, uc_emb=uc_emb,
-                             latents=latents, conditioned_image=cond_image, masks=masks, gamma=getattr(args, "gamma", 0.5),
-                             decode=decode, n_iterations=n_iterations)
+                             latents_dir=lat_dir, conditioned_image=cond_image, gamma=getattr(args, "gamma", 0.5),
+                             decode=decode, n_iterations=n_iterations, davis_data=(frames.to(model.device), masks))
     keep = out[:args.new_video_length // 2]
     if decode:
         return save_gif(torch.cat(keep, dim=2), out_dir, args.video_name, duration_ms=int(1000 / args.output_fps))

@@ -59,6 +59,22 @@ class _PlanBase:
         self.graph_failed = False
         self.n_runs = 0
 
+    def close(self):
+        """release the instantiated hipGraph (moca_graph_destroy); the plan falls back to eager launches if used again"""
+        if self.graph is not None:
+            g, self.graph = self.graph, None
+            try:
+                torch.cuda.synchronize(self.device)
+                _l.load().moca_graph_destroy(g)
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # ------------------------------------------------------------------ emit helpers
     def _emit(self, fn, *args, **kw):
         self.steps.append(functools.partial(fn, *args, **kw))

@@ -189,6 +189,75 @@ class _FMap:
         return self.F * self.H * self.W
 
 
+
+def pack_tree(root, dev):
+    """Pack every block under `root` (a whole UNetModel, or a holder of ONE block: blockplan.BlockRunner) into GEMM operands.
+    Returns (P, emb_cols, kv_cols): P maps id(parameter module) -> packed operands; all ResBlock.emb_layers Linears share
+    the input SiLU(emb) and all cross-attention to_k/to_v share the text context, so each family is fused into ONE wide GEMM
+    per forward (P["emb_all"], P["ctx_kv_all"]; column offsets are multiples of 64) with the per-module column ranges in
+    emb_cols / kv_cols."""
+    P = {}
+    f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+    def norm(m):
+        P[id(m)] = (f32(m.weight), f32(m.bias))
+
+    def lin(m):
+        P[id(m)] = ops.pack_linear(m.weight.detach(), None if m.bias is None else m.bias.detach(), device=dev)
+
+    for mod in root.modules():
+        if isinstance(mod, _ResBlock):
+            norm(mod.in_layers[0]); norm(mod.out_layers[0])
+            c1 = mod.in_layers[2]
+            P[id(c1)] = ops.pack_conv3x3(c1.weight.detach(), c1.bias.detach(), device=dev)
+            c2 = mod.out_layers[3]
+            P[id(c2)] = ops.pack_conv3x3(c2.weight.detach(), c2.bias.detach(), device=dev)
+            if isinstance(mod.skip_connection, _Param):
+                sk = mod.skip_connection
+                P[id(sk)] = ops.pack_conv1x1(sk.weight.detach(), sk.bias.detach(), device=dev)
+        elif isinstance(mod, _TemporalConvBlock):
+            for name, idx in (("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3)):
+                sq = getattr(mod, name)
+                norm(sq[0])
+                P[id(sq[idx])] = ops.pack_tconv3(sq[idx].weight.detach(), sq[idx].bias.detach(), device=dev)
+        elif isinstance(mod, (_SpatialTransformer, _TemporalTransformer)):
+            norm(mod.norm); lin(mod.proj_in); lin(mod.proj_out)
+        elif isinstance(mod, _BasicTransformerBlock):
+            norm(mod.norm1); norm(mod.norm2); norm(mod.norm3)
+            for att in (mod.attn1, mod.attn2):
+                if att.is_self:
+                    P[id(att)] = ops.pack_linear_cat([att.to_q.weight.detach(), att.to_k.weight.detach(), att.to_v.weight.detach()], device=dev)
+                else:
+                    P[id(att)] = ops.pack_linear(att.to_q.weight.detach(), device=dev)
+                lin(att.to_out[0])
+            g = mod.ff.net[0].proj
+            P[id(g)] = ops.pack_geglu(g.weight.detach().to(dev), g.bias.detach().to(dev), device=dev)
+            lin(mod.ff.net[2])
+        elif isinstance(mod, _Downsample):
+            P[id(mod.op)] = ops.pack_conv3x3(mod.op.weight.detach(), mod.op.bias.detach(), device=dev)
+        elif isinstance(mod, _Upsample):
+            P[id(mod.conv)] = ops.pack_conv3x3(mod.conv.weight.detach(), mod.conv.bias.detach(), device=dev)
+    res = [m for m in root.modules() if isinstance(m, _ResBlock)]
+    emb_cols, off = {}, 0
+    for m in res:
+        emb_cols[id(m)] = (off, m.cout)
+        off += m.cout
+    if res:
+        P["emb_all"] = ops.pack_linear_cat([m.emb_layers[1].weight.detach() for m in res],
+                                           [m.emb_layers[1].bias.detach() for m in res], device=dev)
+    cross = [b.attn2 for b in root.modules() if isinstance(b, _BasicTransformerBlock) and not b.attn2.is_self]
+    kv_cols, off = {}, 0
+    ws = []
+    for a in cross:
+        inner = a.to_k.weight.shape[0]
+        kv_cols[id(a)] = (off, inner)
+        off += 2 * inner
+        ws += [a.to_k.weight.detach(), a.to_v.weight.detach()]
+    if ws:
+        P["ctx_kv_all"] = ops.pack_linear_cat(ws, device=dev)
+    return P, emb_cols, kv_cols
+
+
 # --------------------------------------------------------------------------------------
 # the model
 # --------------------------------------------------------------------------------------
@@ -294,6 +363,8 @@ class UNetModel(nn.Module):
     # ---- weights -----------------------------------------------------------------------
     def _invalidate(self):
         self._packed = None
+        for pl in getattr(self, "_plans", {}).values():      # the hipGraphExec of a dropped plan is a device-side object
+            pl.close()
         self._plans = {}
 
     def _apply(self, fn, recurse=True):   # .cuda()/.to() moves parameters: re-pack lazily
@@ -305,71 +376,14 @@ class UNetModel(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("moca_video_amd.UNetModel runs on an MI355X only; call .cuda() first (no CPU path)")
-        P = {}
+        P, self._emb_cols, self._kv_cols = pack_tree(self, dev)
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
-
-        def norm(m):
-            P[id(m)] = (f32(m.weight), f32(m.bias))
-
-        def lin(m):
-            P[id(m)] = ops.pack_linear(m.weight.detach(), None if m.bias is None else m.bias.detach(), device=dev)
-
-        for mod in self.modules():
-            if isinstance(mod, _ResBlock):
-                norm(mod.in_layers[0]); norm(mod.out_layers[0])
-                c1 = mod.in_layers[2]
-                P[id(c1)] = ops.pack_conv3x3(c1.weight.detach(), c1.bias.detach(), device=dev)
-                c2 = mod.out_layers[3]
-                P[id(c2)] = ops.pack_conv3x3(c2.weight.detach(), c2.bias.detach(), device=dev)
-                if isinstance(mod.skip_connection, _Param):
-                    s = mod.skip_connection
-                    P[id(s)] = ops.pack_conv1x1(s.weight.detach(), s.bias.detach(), device=dev)
-            elif isinstance(mod, _TemporalConvBlock):
-                for name, idx in (("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3)):
-                    sq = getattr(mod, name)
-                    norm(sq[0])
-                    P[id(sq[idx])] = ops.pack_tconv3(sq[idx].weight.detach(), sq[idx].bias.detach(), device=dev)
-            elif isinstance(mod, (_SpatialTransformer, _TemporalTransformer)):
-                norm(mod.norm); lin(mod.proj_in); lin(mod.proj_out)
-            elif isinstance(mod, _BasicTransformerBlock):
-                norm(mod.norm1); norm(mod.norm2); norm(mod.norm3)
-                for att in (mod.attn1, mod.attn2):
-                    if att.is_self:
-                        P[id(att)] = ops.pack_linear_cat([att.to_q.weight.detach(), att.to_k.weight.detach(), att.to_v.weight.detach()], device=dev)
-                    else:
-                        P[id(att)] = ops.pack_linear(att.to_q.weight.detach(), device=dev)
-                    lin(att.to_out[0])
-                g = mod.ff.net[0].proj
-                P[id(g)] = ops.pack_geglu(g.weight.detach().to(dev), g.bias.detach().to(dev), device=dev)
-                lin(mod.ff.net[2])
-            elif isinstance(mod, _Downsample):
-                P[id(mod.op)] = ops.pack_conv3x3(mod.op.weight.detach(), mod.op.bias.detach(), device=dev)
-            elif isinstance(mod, _Upsample):
-                P[id(mod.conv)] = ops.pack_conv3x3(mod.conv.weight.detach(), mod.conv.bias.detach(), device=dev)
-        # All ResBlock.emb_layers Linears share the input SiLU(emb) and all cross-attention to_k/to_v share the
-        # text context: fuse each family into ONE wide GEMM per forward (column offsets are multiples of 64).
-        res = [m for m in self.modules() if isinstance(m, _ResBlock)]
-        self._emb_cols, off = {}, 0
-        for m in res:
-            self._emb_cols[id(m)] = (off, m.cout)
-            off += m.cout
-        P["emb_all"] = ops.pack_linear_cat([m.emb_layers[1].weight.detach() for m in res],
-                                           [m.emb_layers[1].bias.detach() for m in res], device=dev)
-        cross = [b.attn2 for b in self.modules() if isinstance(b, _BasicTransformerBlock) and not b.attn2.is_self]
-        self._kv_cols, off = {}, 0
-        ws = []
-        for a in cross:
-            inner = a.to_k.weight.shape[0]
-            self._kv_cols[id(a)] = (off, inner)
-            off += 2 * inner
-            ws += [a.to_k.weight.detach(), a.to_v.weight.detach()]
-        if ws:
-            P["ctx_kv_all"] = ops.pack_linear_cat(ws, device=dev)
         for sq in (self.time_embed,) + ((self.fps_embedding,) if self.fps_cond else ()):
-            lin(sq[0]); lin(sq[2])
+            for m in (sq[0], sq[2]):
+                P[id(m)] = ops.pack_linear(m.weight.detach(), m.bias.detach(), device=dev)
         cin = self.input_blocks[0][0]
         P[id(cin)] = ops.pack_conv3x3(cin.weight.detach(), cin.bias.detach(), cpad=8, device=dev)
-        norm(self.out[0])
+        P[id(self.out[0])] = (f32(self.out[0].weight), f32(self.out[0].bias))
         P[id(self.out[2])] = ops.pack_conv3x3(self.out[2].weight.detach(), self.out[2].bias.detach(), device=dev)
         self._packed = P
 

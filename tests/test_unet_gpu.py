@@ -1,7 +1,8 @@
 """GPU parity of the HIP UNet (through the drop-in UNetModel / DiffusionWrapper boundary, i.e.
 through the C-ABI) against (a) golden outputs of the real reference and (b) the CPU oracle on
 the same seeded inputs.  fp16 storage / fp32 accumulate vs the fp32 reference:
-tolerance = 2e-2 * max|ref| on the UNet output (stated fp16 tolerance), 6e-3 per block."""
+tolerances (stated fp16 tolerance): whole-UNet output max|err| <= 6e-3 * max|ref| AND rms(err) <= 5e-3 * rms(ref)
+(observed 2.2e-3 max-norm at the full 1.41 B-parameter width, 3.2e-3 / 2.8e-3 on the reduced UNet); single blocks likewise."""
 import numpy as np
 import pytest
 import torch
@@ -10,8 +11,79 @@ pytestmark = pytest.mark.gpu
 
 from helpers import REDUCED, golden, inp, relerr, state_dict_for  # noqa: E402
 
-TOL_UNET = 2e-2
+TOL_UNET = 6e-3        # max-norm, 2.7x the observed 2.2e-3
 TOL_BLOCK = 6e-3
+TOL_RMS = 5e-3         # relative RMS (observed 2.8e-3 on the reduced-width UNet, where K is short and every tensor is small): a
+                       # wrong epilogue in a low-magnitude region cannot hide under the max-norm bound
+
+
+def rmserr(got, ref):
+    got, ref = torch.as_tensor(got).float(), torch.as_tensor(ref).float()
+    return ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-20)).item()
+
+
+def check(got, ref, tol_max, what):
+    e, r = relerr(got, ref), rmserr(got, ref)
+    print(f"[parity] {what}: max-norm rel err {e:.2e}, rel rms {r:.2e}")
+    assert e < tol_max and r < TOL_RMS, f"{what}: max-norm rel err {e:.3e} (tol {tol_max:.0e}), rel rms {r:.3e} (tol {TOL_RMS:.1e})"
+    return e, r
+
+
+def _filled(block, seed):
+    block.load_state_dict(state_dict_for(block, seed), strict=True)
+    return block.cuda()
+
+
+# ---- single blocks against goldens of the REAL reference blocks (tools/make_golden.py::blocks) -------------------------
+@pytest.mark.parametrize("name,cout,seed", [("block_resblock", 128, 1), ("block_resblock_same", 64, 2)])
+def test_block_resblock_vs_reference_golden(name, cout, seed):
+    """ResBlock._forward + TemporalConvBlock (openaimodel3d.py:208-234,269-276): GroupNorm+SiLU, conv3x3 + emb row add,
+    skip 1x1 conv, residual epilogue, 4 x (5-D GroupNorm + temporal conv), b=2, t=4"""
+    from moca_video_amd.blockplan import BlockRunner
+    from moca_video_amd.unet import _ResBlock
+    run = BlockRunner(_filled(_ResBlock(64, 256, cout, True), seed), B=2, T=4, H=6, W=10)
+    x, emb = inp("rb.x", (8, 64, 6, 10)).cuda(), inp("rb.emb", (8, 256)).cuda()
+    ref = golden(name)["y"]
+    for it in range(3):          # eager, capture, replay
+        check(run(x, emb=emb).cpu(), ref, TOL_BLOCK, f"{name} pass {it}")
+
+
+def test_block_spatial_transformer_vs_reference_golden():
+    """SpatialTransformer (attention.py:262-278): GroupNorm, proj_in, self-attn, cross-attn on a 77-token context per frame,
+    GEGLU feed-forward, proj_out + residual"""
+    from moca_video_amd.blockplan import BlockRunner
+    from moca_video_amd.unet import _SpatialTransformer
+    run = BlockRunner(_filled(_SpatialTransformer(128, 2, 64, 1, 96, True), 3), B=4, T=1, H=6, W=10, L=77, context_dim=96)
+    x, ctx = inp("st.x", (4, 128, 6, 10)).cuda(), inp("st.ctx", (4, 77, 96)).cuda()
+    for it in range(3):
+        check(run(x, context=ctx).cpu(), golden("block_spatial_transformer")["y"], TOL_BLOCK, f"spatial transformer pass {it}")
+
+
+def test_block_temporal_transformers_vs_reference_golden():
+    """TemporalTransformer (attention.py:331-373): the linear-projection flavour (T=8) and the Conv1d-projected 8-head
+    `init_attn` flavour (T=16)"""
+    from moca_video_amd.blockplan import BlockRunner
+    from moca_video_amd.unet import _TemporalTransformer
+    run = BlockRunner(_filled(_TemporalTransformer(128, 2, 64, 1, True), 4), B=2, T=8, H=3, W=5)
+    x5 = inp("tt.x", (2, 128, 8, 3, 5))
+    ref = torch.from_numpy(golden("block_temporal_transformer")["y"])          # [b, c, t, h, w]
+    y = run(x5.permute(0, 2, 1, 3, 4).reshape(16, 128, 3, 5).cuda()).cpu().reshape(2, 8, 128, 3, 5).permute(0, 2, 1, 3, 4)
+    check(y, ref, TOL_BLOCK, "temporal transformer")
+    run = BlockRunner(_filled(_TemporalTransformer(64, 8, 64, 1, False), 5), B=1, T=16, H=3, W=5)
+    x5 = inp("ti.x", (1, 64, 16, 3, 5))
+    ref = torch.from_numpy(golden("block_init_attn")["y"])
+    y = run(x5.permute(0, 2, 1, 3, 4).reshape(16, 64, 3, 5).cuda()).cpu().reshape(1, 16, 64, 3, 5).permute(0, 2, 1, 3, 4)
+    check(y, ref, TOL_BLOCK, "init_attn")
+
+
+def test_block_down_up_vs_reference_golden():
+    """Downsample (stride-2 conv) / Upsample (nearest x2 fused into the conv gather), openaimodel3d.py:56-121"""
+    from moca_video_amd.blockplan import BlockRunner
+    from moca_video_amd.unet import _Downsample, _Upsample
+    g = golden("block_down_up")
+    x = inp("ud.x", (3, 64, 6, 10)).cuda()
+    check(BlockRunner(_filled(_Downsample(64), 6), B=3, T=1, H=6, W=10)(x).cpu(), g["down"], TOL_BLOCK, "downsample")
+    check(BlockRunner(_filled(_Upsample(64), 7), B=3, T=1, H=6, W=10)(x).cpu(), g["up"], TOL_BLOCK, "upsample")
 
 
 @pytest.fixture(scope="module")
@@ -35,8 +107,7 @@ def test_unet_reduced_vs_reference_golden(reduced_model, case, B):
     for it in range(3):     # eager pass, graph-capture pass, graph replay: all must agree
         y = reduced_model(x, t, context=ctx, fps=fps, clean_cond=True, gamma=0.5)
         assert y.shape == ref.shape and y.dtype == x.dtype
-        e = relerr(y.cpu(), ref)
-        assert e < TOL_UNET, f"{case} pass {it}: rel err {e:.3e}"
+        check(y.cpu(), ref, TOL_UNET, f"{case} pass {it}")
     plan = next(iter(reduced_model._plans.values()))
     assert any(p.graph is not None for p in reduced_model._plans.values()), "hipGraph replay path was not taken"
 
@@ -50,7 +121,7 @@ def test_unet_reduced_vs_oracle_fresh_inputs(reduced_model):
     t = torch.arange(0, 960, 60, dtype=torch.long)
     ref = UO.unet_forward(sd, x, t, ctx, fps=torch.tensor([10]))
     y = reduced_model(x.cuda(), t.cuda(), context=ctx.cuda(), fps=torch.tensor([10]).cuda())
-    assert relerr(y.cpu(), ref) < TOL_UNET
+    check(y.cpu(), ref, TOL_UNET, "fresh inputs vs oracle")
 
 
 def test_diffusion_wrapper_boundary():
@@ -66,7 +137,7 @@ def test_diffusion_wrapper_boundary():
     t = torch.from_numpy(g["fifo__t"]).cuda()
     cond = {"c_crossattn": [ctx[:, :77], ctx[:, 77:]], "fps": torch.tensor([10]).cuda()}
     y = dm.apply_model(x, t, cond, clean_cond=True)
-    assert relerr(y.cpu(), torch.from_numpy(g["fifo"])) < TOL_UNET
+    check(y.cpu(), torch.from_numpy(g["fifo"]), TOL_UNET, "wrapper boundary")
 
 
 def test_unet_rejects_cpu_and_bad_shapes(reduced_model):
@@ -126,7 +197,7 @@ def test_forward_concurrent_equals_forward(reduced_model):
         o1, o2 = reduced_model.forward_concurrent([dict(x=x, timesteps=t, context=c1, fps=16),
                                                    dict(x=x, timesteps=t, context=c2, fps=16)])
         assert torch.equal(o1, ref1) and torch.equal(o2, ref2)
-    assert relerr(o1.cpu(), torch.from_numpy(g["uniform"])) < TOL_UNET
+    check(o1.cpu(), torch.from_numpy(g["uniform"]), TOL_UNET, "concurrent")
 
 
 def test_unet_full_width_vs_reference_golden():
@@ -150,8 +221,8 @@ def test_unet_full_width_vs_reference_golden():
             t = torch.from_numpy(g[name + "__t"]).cuda()
             fps = torch.from_numpy(np.atleast_1d(g[name + "__fps"])).cuda()
             y = m(x, t, context=ctx, fps=fps, clean_cond=True, gamma=0.5)
-            e = relerr(y.cpu(), torch.from_numpy(g[name]))
-            assert e < TOL_UNET, f"{tag}.{name}: rel err {e:.3e}"
+            e, r = check(y.cpu(), torch.from_numpy(g[name]), TOL_UNET, f"{tag}.{name}")
+            print(f"{tag}.{name}: max-norm rel err {e:.2e}, rel rms {r:.2e}")
     # size-independent properties at the headline shape [.,4,16,40,64] (no oracle needed):
     xs = [inp(f"prop.x{i}", (1, 4, 16, 40, 64)).cuda() for i in range(2)]
     cs = [inp(f"prop.c{i}", (1, 77, 1024)).cuda() for i in range(2)]
