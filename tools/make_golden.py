@@ -147,19 +147,22 @@ def unet_reduced(om):
     ])
 
 
-def unet_full(om):
+def unet_full(om, only_cfgN=False):
     import yaml
     with open(os.path.join(REF, "configs/inference_t2v_512_v2.0.yaml")) as f:
         params = yaml.safe_load(f)["model"]["params"]["unet_config"]["params"]
     params = dict(params)
     params["use_checkpoint"] = False   # no effect on results under no_grad (common.py:80-94)
-    unet_cases(om, params, "full", (4, 8, 32, 32), 1024, [
-        ("cfg0_uniform", 1, [500], 77, [10]),
-        ("cfg0_fifo", 1, [int(v) for v in np.linspace(999, 0, 8).round()], 154, [10]),
-    ])
+    if not only_cfgN:
+        unet_cases(om, params, "full", (4, 8, 32, 32), 1024, [
+            ("cfg0_uniform", 1, [500], 77, [10]),
+            ("cfg0_fifo", 1, [int(v) for v in np.linspace(999, 0, 8).round()], 154, [10]),
+        ])
     # cfgN: the headline shape, FIFO window call
     unet_cases(om, params, "full_cfgN", (4, 16, 40, 64), 1024, [
         ("fifo16", 1, [int(v) for v in np.linspace(999, 0, 16).round()], 77, [10]),
+        ("fifo16_154", 1, [int(v) for v in np.linspace(999, 0, 16).round()], 154, [10]),     # the MoCA FIFO call: two prompts
+        ("uniform_77", 1, [500], 77, [10]),                                                     # the base-sampling call (configs[1])
     ])
 
 
@@ -454,6 +457,7 @@ def main():
     if "fifo" in todo: fifo_cases()
     if "vae" in todo: vae_cases()
     if "full" in todo: unet_full(om)
+    if "fullN" in todo: unet_full(om, only_cfgN=True)
 
 
 if __name__ == "__main__":
