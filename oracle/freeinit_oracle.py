@@ -63,10 +63,23 @@ def prepare_latents(z, ddim_alphas, num_inference_steps, video_length, lookahead
     return torch.cat(out, dim=2)
 
 
-def shift_latents(latents, noise):
-    """funcs.py:86-99"""
-    anchor = latents[:, :, 0].clone().unsqueeze(2)
+def shift_latents(latents, noise, davis_data=None, encode=None):
+    """funcs.py:86-118.  Prompt mode: anchor = the dequeued frame.  DAVIS mode (`davis_data = (frames, masks)`): anchor =
+    `encode(last DAVIS frame, RGB)` (the caller's restatement of encode_first_stage_2DAE with its sample noise), and the mask
+    queue shifts with its tail kept; returns (latents, masks) then."""
+    if davis_data is None:
+        anchor = latents[:, :, 0].clone().unsqueeze(2)
+    else:
+        frames, masks = davis_data
+        anchor = frames[:, :, -1].clone().unsqueeze(2)
+        if anchor.shape[1] == 4:
+            anchor = anchor[:, :3]
+        anchor = encode(anchor)
     latents[:, :, :-1] = latents[:, :, 1:].clone()
     lpf = get_freq_filter(anchor.shape, "gaussian", 1, 0.25, 0.25)
     latents[:, :, -1] = freq_mix_3d(anchor, noise.unsqueeze(2), lpf).squeeze(2)
-    return latents
+    if davis_data is None:
+        return latents
+    masks[:, :, :-1] = masks[:, :, 1:].clone()
+    masks[:, :, -1] = masks[:, :, -1].clone()
+    return latents, masks

@@ -254,3 +254,48 @@ def test_davis_mode_driver_end_to_end(tmp_path):
     path = run_davis(args, dm, embed, "a bear walking, cat.", cond_image=cimg, root=str(tmp_path), uc_emb=embed(""), n_iterations=4)
     im = Image.open(path)
     assert im.n_frames == 3 and im.size == (64, 64)           # first new_video_length // 2 of the 4 emitted frames
+
+
+def _davis_shift_inputs():
+    h, w, Q = 8, 8, 72
+    frames = (inp("fifo.davis.frames", (1, 4, 3, 8 * h, 8 * w)) * 0.5).clamp(-1, 1)
+    masks = (inp("fifo.davis.masks", (1, 1, Q, h, w)) > 0.3).float()
+    lat = inp("fifo.davis.lat", (1, 4, Q, h, w))
+    anchor_nz = [inp(f"fifo.davis.anchor_nz{i}", (1, 4, h, w)) for i in range(2)]
+    nz = [inp(f"fifo.davis.nz{i}", (1, 4, h, w)) for i in range(2)]
+    return frames, masks, lat, anchor_nz, nz
+
+
+def test_oracle_davis_shift_latents_vs_reference_golden():
+    """DAVIS branch of shift_latents (funcs.py:101-118) of the REAL reference, two consecutive shifts: anchor = posterior
+    sample of the VAE encoding of the last DAVIS frame, FreeInit mix into the queue tail, mask queue shift"""
+    from oracle import freeinit_oracle as FO
+    g = golden("fifo_davis_shift")
+    sd = state_dict_for(_model(64), 5)
+    frames, masks, lat, anchor_nz, nz = _davis_shift_inputs()
+    for i in range(2):
+        enc = lambda x, _i=i: VO.encode_first_stage_2DAE(sd, x, 0.18215, anchor_nz[_i].unsqueeze(2))
+        lat, masks = FO.shift_latents(lat, nz[i], davis_data=(frames, masks), encode=enc)
+        assert relerr(lat, g[f"lat{i + 1}"]) < 2e-5
+        assert torch.equal(masks, torch.from_numpy(g[f"masks{i + 1}"]))
+
+
+@pytest.mark.gpu
+def test_hip_davis_shift_latents_vs_reference_golden():
+    """moca_video_amd.fifo.shift_latents(davis_data=...) (HIP VAE encoder + FreeInit kernels) against the same golden"""
+    from moca_video_amd import DenoiseModel
+    from moca_video_amd.fifo import shift_latents
+    from helpers import REDUCED
+    g = golden("fifo_davis_shift")
+    dm = DenoiseModel({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": REDUCED},
+                      first_stage_config={"target": "lvdm.models.autoencoder.AutoencoderKL",
+                                          "params": {"embed_dim": 4, "ddconfig": dict(VAE_DD, ch=64), "lossconfig": {"target": "torch.nn.Identity"}}},
+                      scale_factor=0.18215)
+    dm.first_stage_model.load_state_dict(state_dict_for(dm.first_stage_model, 5), strict=True)
+    dm = dm.cuda()
+    frames, masks, lat, anchor_nz, nz = _davis_shift_inputs()
+    lat, data = lat.cuda(), (frames.cuda(), masks.cuda())
+    for i in range(2):
+        lat, data = shift_latents(lat, data, dm, noise=nz[i].cuda(), anchor_noise=anchor_nz[i].unsqueeze(2).cuda())
+        assert relerr(lat.cpu(), g[f"lat{i + 1}"]) < TOL_HIP
+        assert torch.equal(data[1].cpu(), torch.from_numpy(g[f"masks{i + 1}"]))

@@ -375,6 +375,7 @@ def fifo_cases():
     sys.modules["torchvision.transforms"] = stub_t.transforms
     from scripts.evaluation import funcs as Fn
     from lvdm.models.samplers import ddim as D
+    D.DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)   # drop hard-coded .to("cuda") (:53-60)
     fm = FakeModel()
     s = D.DDIMSampler(fm, use_self_attention=True)
     s.make_schedule(64, ddim_eta=1.0, verbose=False)
@@ -406,6 +407,49 @@ def fifo_cases():
         torch.randn_like = real_randn_like
         torch.Tensor.to = real_to
     save("fifo_queue", prepared=lat, shifted=shifted, n_noise_prepare=np.asarray(n_prep), n_noise_total=np.asarray(len(noises)))
+
+    # DAVIS branch of shift_latents (funcs.py:101-118): anchor = encode_first_stage_2DAE of the LAST DAVIS frame (a fresh
+    # posterior sample, drawn with torch.randn inside DiagonalGaussianDistribution.sample), mask tail refill.  The model is
+    # the real ddpm3d method on a holder with the real (reduced-width) AutoencoderKL.
+    from lvdm.models.autoencoder import AutoencoderKL
+    from lvdm.models import ddpm3d
+    ae = AutoencoderKL(ddconfig=dict(VAE_DD, ch=64), lossconfig={"target": "torch.nn.Identity"}, embed_dim=4).eval()
+    fill(ae, seed=5)
+
+    class Holder:
+        first_stage_model = ae
+        scale_factor = 0.18215
+        get_first_stage_encoding = ddpm3d.LatentDiffusion.get_first_stage_encoding
+        encode_first_stage_2DAE = ddpm3d.LatentDiffusion.encode_first_stage_2DAE
+    h, w, Q = 8, 8, 72
+    frames = (inp("fifo.davis.frames", (1, 4, 3, 8 * h, 8 * w)) * 0.5).clamp(-1, 1)          # RGBA, 3 frames
+    masks0 = (inp("fifo.davis.masks", (1, 1, Q, h, w)) > 0.3).float()
+    lat0 = inp("fifo.davis.lat", (1, 4, Q, h, w))
+    real_randn = torch.randn
+    draws = []
+
+    def rec_randn(*shape, **k):
+        shp = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else tuple(shape)
+        n = inp(f"fifo.davis.anchor_nz{len(draws)}", shp)
+        draws.append(n)
+        return n.clone()
+    nz_like = []
+
+    def rec_randn_like2(t, *a, **k):
+        n = inp(f"fifo.davis.nz{len(nz_like)}", tuple(t.shape))
+        nz_like.append(n)
+        return n.clone()
+    torch.randn = rec_randn
+    torch.randn_like = rec_randn_like2
+    try:
+        with torch.no_grad():
+            lat1, (fr1, mk1) = Fn.shift_latents(lat0.clone(), (frames.clone(), masks0.clone()), Holder())
+            lat2, (fr2, mk2) = Fn.shift_latents(lat1.clone(), (fr1, mk1.clone()), Holder())
+    finally:
+        torch.randn = real_randn
+        torch.randn_like = real_randn_like
+    save("fifo_davis_shift", lat1=lat1, masks1=mk1, lat2=lat2, masks2=mk2, n_anchor_draws=np.asarray(len(draws)),
+         n_noise_draws=np.asarray(len(nz_like)), anchor_noise_shape=np.asarray(draws[0].shape))
 
 
 
