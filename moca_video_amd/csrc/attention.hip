@@ -20,6 +20,7 @@
 //   channels-last token matrix, so the reference's (b t) c h w <-> (b h w) t c
 //   reshuffles (attention.py:335-338,367) never touch memory.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -28,7 +29,9 @@ constexpr int KT = 64;       // keys per LDS tile
 constexpr int QB = 128;      // queries per block
 constexpr int ROWB = 128;    // bytes per LDS row (64 halves)
 
+template <int V> struct int_c { static constexpr int value = V; };
 typedef short short4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char* lds_c_ptr;
 typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
 
 // ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block of 16-bit elements and receives it
@@ -211,6 +214,209 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     }
 }
 
+// ---- "v4": the VALU-lean flash attention for long key sequences ---------------------------------------------------------
+// rocprofv3 counters of attention_kernel at N = 2560 (tools/pmc_attn.sh): 222 VALU instructions per wave per 64-key tile,
+// the VALU active in 61 % of all SIMD cycles, the matrix pipe in 30 % -- at head dim 64 the kernel is VALU-bound, so v4 removes
+// vector instructions instead of re-arranging them.  Per score element the first-generation kernel spends
+// fma (scale, - max) + exp + add (row sum) + 0.5 max3 + ~1.5 conversions + its share of zero-initialising the score
+// accumulators and of LDS / global address arithmetic.  Here:
+//   * Q is multiplied by scale*log2(e) once, when it is loaded (one fp16 rounding of Q more), and the running reference
+//     maximum enters through the ACCUMULATOR INPUT of the first score MFMA (a 16-register operand holding -m_ref, rebuilt
+//     only when m_ref moves): S'' = K.Q'^T - m_ref comes out of the matrix pipe ready for exp2 -- no fma, no zero fill;
+//   * the reference maximum is lazy (cdna_hip_programming.md T13): it is moved (O, l rescaled) only when a tile maximum
+//     exceeds it by more than THR = 8, i.e. P <= 2^8 in fp16, whose relative precision does not depend on magnitude; the
+//     first tile always sets it;
+//   * the row sums come from the matrix pipe too: l^T += 1^T.P^T, one more MFMA per 16 keys with an all-ones A operand
+//     (every lane ends up with the complete sum of its query: no adds, no final cross-lane exchange);
+//   * P is packed with v_cvt_pk_f16_f32 only; LDS fragment addresses are per-lane constants + immediates (key loop
+//     unrolled over the two buffers); the staging pointers advance by one 64-bit add per tile.
+// What is left per element: 0.5 max3 + exp + 0.5 cvt_pk.  Tiles, LDS images and fragment maps are those of attention_kernel.
+constexpr float LAZY_THR = 8.0f;
+
+__global__ __launch_bounds__(256, 2) void attention_v4_kernel(
+    const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, half_t* __restrict__ out,
+    int heads, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, int kv_div, float scale_log2e) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (__amdgpu_buffer_rsrc_t is a device-only type; the host pass only needs the launch stub)
+    __shared__ __attribute__((aligned(16))) char smem[4 * KT * ROWB];      // sK[0], sK[1], sV[0], sV[1]
+    constexpr int TILE = KT * ROWB;                                       // 8 KiB
+    char* const sK = smem;
+    char* const sV = smem + 2 * TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bq = blockIdx.y / heads, head = blockIdx.y % heads;
+    const int bkv = bq / kv_div;
+    const int q0 = blockIdx.x * QB + wave * 32;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    const half_t* qb = q + (int64_t)bq * Nq * ldq + head * D;
+    // Q' = Q * scale * log2(e), B operand of S^T = K.Q'^T: lane (q = fr, h = fh) holds Q'[q][16 ks + 8 h + j]
+    half8v qf[4];
+    const int qrow = q0 + fr;
+    const bool q_ok = qrow < Nq;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        half8v t = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q_ok) t = *reinterpret_cast<const half8v*>(qb + (int64_t)qrow * ldq + ks * 16 + fh * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = (half_t)((float)t[j] * scale_log2e);
+        qf[ks] = t;
+    }
+
+    f32x16 o[2], osum, negm;          // O^T accumulators, row-sum accumulator (all rows equal), -m_ref replicated
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; osum[r] = 0.f; negm[r] = 0.f; }
+    float m_ref = 0.f;
+    half8v ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (half_t)1.0f;
+
+    // staging by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write): a 1 KiB piece = 8 key rows x 128 B,
+    // lane -> row (lane >> 3), PHYSICAL chunk lane & 7; the swizzles of the two LDS images go on the per-lane SOURCE address
+    // (logical chunk = physical ^ swizzle(row)).  Wave w moves pieces w and w + 4 of K and of V (rows 8w.., 32 + 8w..): 4 DMA
+    // instructions per wave per key tile.  Rows >= Nk lie beyond num_records of the descriptors: the range check writes zeros.
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int lr = lane >> 3, pc = lane & 7;
+    const int srow = wv * 8 + lr;                                          // + 32 for the second piece (same swizzles)
+    const unsigned k_voff = (unsigned)(srow * ldk * 2 + ((pc ^ ((srow >> 1) & 7)) << 4));
+    const unsigned v_voff = (unsigned)(srow * ldv * 2 + ((pc ^ (((srow >> 1) & 1) << 2)) << 4));
+    const half_t* kbase = k + (int64_t)bkv * Nk * ldk + head * D;
+    const half_t* vbase = v + (int64_t)bkv * Nk * ldv + head * D;
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kbase), 0, (unsigned)(Nk * ldk * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(vbase), 0, (unsigned)(Nk * ldv * 2), 0x00020000);
+    auto dma_k = [&](int kt, int buf) {
+        const lds_c_ptr dk = (lds_c_ptr)sK + buf * TILE + wv * 1024;
+        const unsigned ks0 = (unsigned)(kt * KT * ldk * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, dk, 16, k_voff, ks0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, dk + 4096, 16, k_voff, ks0 + (unsigned)(32 * ldk * 2), 0, 0);
+    };
+    auto dma_v = [&](int kt, int buf) {
+        const lds_c_ptr dv = (lds_c_ptr)sV + buf * TILE + wv * 1024;
+        const unsigned vs0 = (unsigned)(kt * KT * ldv * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, dv, 16, v_voff, vs0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, dv + 4096, 16, v_voff, vs0 + (unsigned)(32 * ldv * 2), 0, 0);
+    };
+    // fragment read offsets inside a tile: per-lane constants; (sub, ss, buffer) only add immediates
+    int k_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) k_off[ks] = fr * ROWB + (((ks * 2 + fh) ^ ((fr >> 1) & 7)) << 4);       // + sub * 32 * ROWB
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tcol16 = (lane >> 4) & 1;
+    int v_off[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int dcol = dt * 32 + tcol16 * 16 + 4 * tp;
+        const int row = 4 * fh + tq;                                      // + sub*32 + ss*16 (+8): leaves ((row >> 1) & 1) unchanged
+        v_off[dt] = row * ROWB + (((dcol >> 3) ^ (((row >> 1) & 1) << 2)) << 4) + (dcol & 7) * 2;
+    }
+    const int nkt = (Nk + KT - 1) / KT;
+
+    // scores of one key tile: S'' = K.Q'^T - m_ref (the accumulator input of the first MFMA of each chain is -m_ref)
+    auto qk = [&](const char* kbuf, f32x16 (&s)[2]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const half8v kf = *reinterpret_cast<const half8v*>(kbuf + k_off[ks] + sub * 32 * ROWB);
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? negm : s[sub], 0, 0, 0);
+            }
+    };
+    // one key tile (K and V in slot B): scores, lazy reference, exp2/pack in four 16-key groups each followed by its 3 MFMAs
+    // (row sum + two O tiles), so a group's MFMAs run under the next group's exp2
+    auto tile = [&](auto b_tag, f32x16 (&sc)[2], int kt) {
+        constexpr int VB = decltype(b_tag)::value;
+        qk(sK + VB * TILE, sc);
+        if ((kt + 1) * KT > Nk) {                     // keys beyond Nk (last tile only)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * KT + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (key >= Nk) sc[sub][r] = -INFINITY;
+                }
+        }
+        float t4[4];                                  // tile maximum as four independent chains
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            t4[c] = fmaxf(sc[0][c], sc[1][c]);
+#pragma unroll
+            for (int r = 4 + c; r < 16; r += 4) t4[c] = fmaxf(t4[c], fmaxf(sc[0][r], sc[1][r]));
+        }
+        float tmax = fmaxf(fmaxf(t4[0], t4[1]), fmaxf(t4[2], t4[3]));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));      // both key halves of this query: the two lanes agree from here on
+        if (kt == 0 || __any(tmax > LAZY_THR)) {      // move the reference (always on the first tile)
+            const float delta = kt == 0 ? tmax : fmaxf(tmax, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);          // (kt == 0: O and l are still zero)
+            m_ref += delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o[0][r] *= alpha; o[1][r] *= alpha; osum[r] *= alpha;
+                sc[0][r] -= delta; sc[1][r] -= delta;
+                negm[r] = -m_ref;
+            }
+        }
+        const char* vbuf = sV + VB * TILE;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                half2v h[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p0 = __builtin_amdgcn_exp2f(sc[sub][ss * 8 + 2 * j]);
+                    const float p1 = __builtin_amdgcn_exp2f(sc[sub][ss * 8 + 2 * j + 1]);
+                    h[j] = __builtin_convertvector(f32x2{p0, p1}, half2v);
+                }
+                const half4v plo = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3);
+                const half4v phi = __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3);
+                const half8v pf = __builtin_shufflevector(plo, phi, 0, 1, 2, 3, 4, 5, 6, 7);
+                osum = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, osum, 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* a0 = vbuf + v_off[dt] + (sub * 32 + ss * 16) * ROWB;
+                    const half4v lo = tr_read(a0);
+                    const half4v hi = tr_read(a0 + 8 * ROWB);
+                    const half8v vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+    };
+
+    // tile kt+1 is fetched while tile kt is computed: DMA issued after the barrier that retired the buffer's last readers,
+    // awaited (vmcnt(0): a whole tile of compute later) before the barrier that publishes it.  (A software-pipelined variant
+    // -- scores of tile kt+1 issued under the softmax of tile kt, `step(...)` with two score register sets -- needs 196 VGPRs =
+    // two waves per SIMD and measured 446 us against 401 us for this form at 157 VGPRs = three waves per SIMD: occupancy wins.)
+    f32x16 sa[2];
+    dma_k(0, 0); dma_v(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        if (kt + 1 < nkt) { dma_k(kt + 1, 1); dma_v(kt + 1, 1); }
+        tile(int_c<0>{}, sa, kt);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nkt) {
+            if (kt + 2 < nkt) { dma_k(kt + 2, 0); dma_v(kt + 2, 0); }
+            tile(int_c<1>{}, sa, kt + 1);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    const float inv = 1.0f / osum[0];
+    if (q_ok) {
+        half_t* ob = out + ((int64_t)bq * Nq + qrow) * ldo + head * D;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4v h4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h4[j] = (half_t)(o[dt][g * 4 + j] * inv);
+                *reinterpret_cast<half4v*>(ob + dt * 32 + 8 * g + 4 * fh) = h4;
+            }
+    }
+#endif
+}
+
 // ---- temporal attention: one wavefront per (video, pixel, head), T <= 16 -------
 constexpr int TV_ROWB = 144;  // 128 B + 16 B pad per V row in LDS
 
@@ -311,6 +517,15 @@ extern "C" int moca_attention_f16(const void* q, const void* k, const void* v, v
     if (ldq < heads * D || ldk < heads * D || ldv < heads * D || ldo < heads * D) return MOCA_E_BADARG;
     if ((int64_t)Bq * heads > 65535) return MOCA_E_BADARG;
     const dim3 grid((Nq + QB - 1) / QB, Bq * heads), block(256);
+    const char* e_v4 = getenv("MOCA_ATTN_V4");       // A/B runs: 0 = the first-generation kernel everywhere
+    if ((!e_v4 || atoi(e_v4) != 0) && Nk >= 2 * KT) {
+        hipLaunchKernelGGL(attention_v4_kernel, grid, block, 0, moca_stream(stream),
+                           reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
+                           reinterpret_cast<const half_t*>(v), reinterpret_cast<half_t*>(out),
+                           heads, Nq, Nk, ldq, ldk, ldv, ldo, kv_div, scale * 1.4426950408889634f);
+        MOCA_CHECK_LAUNCH();
+        return MOCA_OK;
+    }
     hipLaunchKernelGGL(attention_kernel<false>, grid, block, 0, moca_stream(stream),
                        reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
                        reinterpret_cast<const half_t*>(v), reinterpret_cast<half_t*>(out),
