@@ -40,6 +40,10 @@ extern "C" {
                            /* 64-row groups: 32 value rows then their 32 gate rows           */
 #define MOCA_EP_OUT_F32 2  /* out is float32 instead of fp16                                 */
 #define MOCA_FORCE_SMALL_TILE 4  /* tuning/testing: use the 128-row register-staged kernel   */
+#define MOCA_EP_COLSUM 16  /* also write per-(row tile, column) sums and sums of squares of   */
+                           /* the stored values to p.colsum (GroupNorm statistics of the     */
+                           /* consumer: openaimodel3d.py:149,173,253-262; attention.py:238): */
+                           /* only where moca_gemm_colsum_rows() > 0                         */
 #define MOCA_EP_GELU    8  /* out = gelu(acc + bias) (exact erf GELU; 128-row kernel only:   */
                            /* M <= 128 or MOCA_FORCE_SMALL_TILE, splits = 1)                  */
 
@@ -68,6 +72,9 @@ typedef struct moca_gemm_params {
                               bottom/right (F.pad(x,(0,1,0,1)) + conv pad 0: ae_modules.py Downsample.forward);
                               0 = the symmetric padding 1 of every other 3x3 conv                              */
     int32_t reserved_;
+    float*      colsum;    /* MOCA_EP_COLSUM: f32 [ceil(M/rows)][N][2] = (sum, sum of squares) over the rows of each
+                              row tile (rows = moca_gemm_colsum_rows()), of the values as stored (after bias / row add /
+                              residual, before the fp16 rounding)                                                      */
 } moca_gemm_params;
 
 /* Replaces F.conv2d 3x3 (openaimodel3d.py:152,177,66-70,96-106,376,531),
@@ -77,6 +84,10 @@ typedef struct moca_gemm_params {
  * (openaimodel3d.py:228,276; attention.py:217-219,278,373) / GEGLU
  * (attention.py:381-383) folded into the epilogue.                              */
 int moca_gemm_f16(const moca_gemm_params* p, void* stream);
+/* Rows per row tile of the MOCA_EP_COLSUM output for this call (320), or 0 when this call cannot produce column sums
+ * (it would not run on the 320-row direct-to-LDS kernel: N % 160, split-K, GEGLU, fp32 output, slow gather ...).
+ * The GroupNorm that consumes the sums (moca_groupnorm_colsum_f16) needs H*W % rows == 0.                            */
+int moca_gemm_colsum_rows(const moca_gemm_params* p);
 /* bytes of split-K workspace moca_gemm_f16 needs for (M,N,splits) */
 int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits);
 
@@ -91,6 +102,12 @@ int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma, const fl
                             int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
                             float eps, int32_t silu, float* ws, void* stream);
 int64_t moca_groupnorm_ws_bytes(int32_t F, int32_t HW, int32_t C);
+/* The same GroupNorm when the producer of x was a moca_gemm_f16 call with MOCA_EP_COLSUM: the statistics pass over x
+ * is replaced by a reduction of colsum [F*HW/tile_rows][C][2] (HW % tile_rows == 0); two launches (finalize, apply)
+ * instead of three and x is read once.  ws as above.                                                                */
+int moca_groupnorm_colsum_f16(const void* x, void* y, const float* gamma, const float* beta, const float* colsum,
+                              int32_t tile_rows, int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
+                              float eps, int32_t silu, float* ws, void* stream);
 
 /* LayerNorm over the last dim of fp16 x[M][C] (eps 1e-5): attention.py:199-201 */
 int moca_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta,

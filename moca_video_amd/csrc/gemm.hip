@@ -675,6 +675,57 @@ __device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const
     }
 }
 
+// ---- store loop of the 320 x 160 kernels with GroupNorm statistics (MOCA_EP_COLSUM): as store_fp16_tile, but every thread
+//      keeps a FIXED 16-byte column chunk (thread -> chunk tid % 20, rows tid / 20 + 25 i) so that it can accumulate the sum and
+//      the sum of squares of its 8 columns in registers on the way out (fp32 values after row add / residual, i.e. what the
+//      consumer's GroupNorm would read back, before the fp16 rounding); the 25 row subsets are then combined through LDS in a
+//      fixed order (deterministic) and the block writes colsum[tile_m][n0 .. n0+160)[2].  `red` = 32 000 B of LDS scratch
+//      behind the staged tile.
+__device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p, const char* stage, float* red, int pitch,
+                                                       int m0, int n0, int tile_m, int tid) {
+    constexpr int ROWS = 320, BNC = 160, CPR = BNC / 8, RS = 25;          // 20 chunks per row, 25 row subsets (500 of 512 threads)
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    const int ch = tid % CPR, rs = tid / CPR;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (rs < RS) {
+        const int col = n0 + ch * 8;
+        for (int row = rs; row < ROWS; row += RS) {
+            const int m = m0 + row;
+            if (m >= p.M) break;
+            const half8v h = *reinterpret_cast<const half8v*>(stage + row * pitch + ch * 16);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+            if (rowadd) {
+                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            }
+            if (resid) {
+                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            }
+            half8v o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o[j] = (half_t)v[j]; s[j] += v[j]; q[j] += v[j] * v[j]; }
+            *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = o;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[(rs * BNC + ch * 8 + j) * 2] = s[j]; red[(rs * BNC + ch * 8 + j) * 2 + 1] = q[j]; }
+    }
+    __syncthreads();
+    if (tid < 2 * BNC) {                                 // thread -> (column, sum | sum of squares)
+        float a = 0.f;
+#pragma unroll 5
+        for (int r = 0; r < RS; ++r) a += red[r * BNC * 2 + tid];
+        p.colsum[((int64_t)tile_m * p.N + n0) * 2 + tid] = a;
+    }
+}
+
 typedef __attribute__((address_space(3))) char* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
 
@@ -1885,7 +1936,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         }
     }
     __syncthreads();
-    store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
+    if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
+    else store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
 #endif
 }
 
@@ -1931,9 +1983,27 @@ static inline bool buffer_addressable(const moca_gemm_params& p) {
     return a_span_bytes(p) < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
 }
 
+static inline int w80_variant() {                     // A/B runs: 0 = flat-address w80, 1 = buffer-addressed w80b, 2 (default) = staggered w80s
+    const char* e_buf = getenv("MOCA_GEMM_BUF");
+    return e_buf ? atoi(e_buf) : 2;
+}
+static inline bool fast_gather(const moca_gemm_params& p) {
+    return (p.a_mode == MOCA_A_LINEAR) ? (p.K % BK == 0 && p.K <= 8192) : (p.C % BK == 0 && p.C <= 8192);
+}
+// does this (validated, split-normalised) call run on the 320 x 160 kernels / on their staggered buffer-addressed form?
+static inline bool takes_w80(const moca_gemm_params& p) {
+    const char* e_w80 = getenv("MOCA_GEMM_W80");
+    const int w80_mode = e_w80 ? atoi(e_w80) : 1;
+    const int tiles320 = ((p.M + 319) / 320) * (p.N / 160);
+    return w80_mode && p.N % 160 == 0 && !(p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32 | MOCA_FORCE_SMALL_TILE)) && p.M > 160 &&
+           (tiles320 * p.splits >= 200 || w80_mode == 2);
+}
+static inline bool takes_w80s(const moca_gemm_params& p) {
+    return takes_w80(p) && fast_gather(p) && w80_variant() == 2 && buffer_addressable(p);
+}
+
 int launch_gemm_w80_mode(const moca_gemm_params& p, bool fastp, hipStream_t st) {
-    const char* e_buf = getenv("MOCA_GEMM_BUF");      // A/B runs: 0 = flat-address w80, 1 = buffer-addressed w80b, 2 (default) = staggered w80s
-    const int buf_mode = e_buf ? atoi(e_buf) : 2;
+    const int buf_mode = w80_variant();
     if (fastp && buf_mode == 2 && buffer_addressable(p)) {
         if (p.a_mode == MOCA_A_LINEAR) return launch_gemm_w80s<MOCA_A_LINEAR>(p, st);
         if (p.a_mode == MOCA_A_CONV3X3) return launch_gemm_w80s<MOCA_A_CONV3X3>(p, st);
@@ -2006,6 +2076,23 @@ int launch_gemm(const moca_gemm_params& p, hipStream_t st) {
 
 }  // namespace
 
+static void normalise_splits(moca_gemm_params& p) {
+    if (p.splits < 1) p.splits = 1;
+    if (p.splits > (p.K + BK - 1) / BK) p.splits = (p.K + BK - 1) / BK;
+    if (p.splits > 1) {   // no empty k range: every split writes its slab
+        const int nkt = (p.K + BK - 1) / BK, kts = (nkt + p.splits - 1) / p.splits;
+        p.splits = (nkt + kts - 1) / kts;
+    }
+}
+
+extern "C" int moca_gemm_colsum_rows(const moca_gemm_params* pp) {
+    if (!pp) return 0;
+    moca_gemm_params p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
+    normalise_splits(p);
+    return (p.splits == 1 && takes_w80s(p)) ? 320 : 0;
+}
+
 extern "C" int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits) {
     return splits > 1 ? (int64_t)splits * M * N * 4 : 0;
 }
@@ -2023,11 +2110,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     if (p.splits > 1 && !p.splitk_ws) return MOCA_E_BADARG;
     // the plain-GELU epilogue (CLIP text MLP) exists in the 128-row kernel only
     if ((p.flags & MOCA_EP_GELU) && (geglu || p.splits != 1 || !((p.flags & MOCA_FORCE_SMALL_TILE) || p.M <= 128))) return MOCA_E_BADARG;
-    if (p.splits > (p.K + BK - 1) / BK) p.splits = (p.K + BK - 1) / BK;
-    if (p.splits > 1) {   // no empty k range: every split writes its slab
-        const int nkt = (p.K + BK - 1) / BK, kts = (nkt + p.splits - 1) / p.splits;
-        p.splits = (nkt + kts - 1) / kts;
-    }
+    normalise_splits(p);
     switch (p.a_mode) {
         case MOCA_A_LINEAR:
             if (p.lda % 8 || p.lda < p.K) return MOCA_E_BADARG;
@@ -2053,7 +2136,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     // large-tile direct-to-LDS kernel whenever a 256-row tile is at least half full
     const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
     const bool use_big = big_bn != 0 && p.M > 128 && !(p.flags & MOCA_FORCE_SMALL_TILE);
-    const bool fastp = (p.a_mode == MOCA_A_LINEAR) ? (p.K % BK == 0 && p.K <= 8192) : (p.C % BK == 0 && p.C <= 8192);
+    const bool fastp = fast_gather(p);
     // g4 (4 waves, two blocks per CU) wins where the epilogue is VALU-heavy and K is short (GEGLU at C = 320 / 640:
     // one block's erf-GELU epilogue runs under the other block's MFMAs, -5 % on the same device); the 8-wave kernel's
     // deeper pipeline wins everywhere else (K >= 1280: 1137 vs 880 TFLOP/s).  MOCA_GEMM_G4=0/2 forces never/always.
@@ -2062,11 +2145,8 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     const bool use_g4 = !(p.flags & MOCA_EP_OUT_F32) && (g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640));
     // w80 (320 x 160 tiles, 80 x 80 wave tiles): every non-GEGLU contraction whose N is a multiple of 160 and whose
     // 320-row tiles fill the chip.  MOCA_GEMM_W80=0 disables it (A/B against the 256-row kernel), 2 drops the tile-count rule.
-    const char* e_w80 = getenv("MOCA_GEMM_W80");
-    const int w80_mode = e_w80 ? atoi(e_w80) : 1;
-    const int tiles320 = ((p.M + 319) / 320) * (p.N / 160);
-    const bool use_w80 = w80_mode && p.N % 160 == 0 && !geglu && !(p.flags & (MOCA_EP_OUT_F32 | MOCA_FORCE_SMALL_TILE)) &&
-                         p.M > 160 && (tiles320 * p.splits >= 200 || w80_mode == 2);
+    const bool use_w80 = takes_w80(p);
+    if ((p.flags & MOCA_EP_COLSUM) && !(p.colsum && p.splits == 1 && takes_w80s(p))) return MOCA_E_BADARG;   // ask moca_gemm_colsum_rows() first
     if (use_w80) {
         rc = launch_gemm_w80_mode(p, fastp, st);
     } else if (use_big && big_bn == 128 && use_g4) {

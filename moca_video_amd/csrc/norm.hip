@@ -86,6 +86,31 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
 }
 
+// ---- K2': the same from the column sums a MOCA_EP_COLSUM GEMM left behind: colsum[row tile][C][2], a statistics group
+// (sg, g) = tiles [sg*tps, (sg+1)*tps) x channels [g*cpg, (g+1)*cpg); one wavefront per (sg, g), fp64 accumulation in a
+// fixed order ----
+__global__ __launch_bounds__(64) void gn_finalize_colsum_kernel(const float* __restrict__ colsum, float* __restrict__ meanrstd,
+                                                                int tps, int C, int cpg, double inv_count, float eps) {
+    const int sg = blockIdx.x, g = blockIdx.y, l = threadIdx.x;
+    const int n = tps * cpg;
+    double a = 0.0, b = 0.0;
+    for (int i = l; i < n; i += 64) {
+        const int t = i / cpg, c = g * cpg + (i - t * cpg);
+        const float2 v = *reinterpret_cast<const float2*>(colsum + (((int64_t)sg * tps + t) * C + c) * 2);
+        a += (double)v.x;
+        b += (double)v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (l == 0) {
+        const double mean = a * inv_count;
+        double var = b * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        meanrstd[((int64_t)sg * GN_GROUPS + g) * 2] = (float)mean;
+        meanrstd[((int64_t)sg * GN_GROUPS + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 // ---- K3: apply (x - mean) * rstd * gamma + beta, optional SiLU ----------------
 __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -335,6 +360,31 @@ extern "C" int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamm
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(F / frames_per_stat, GN_GROUPS), dim3(64), 0, st, partial, meanrstd,
                        frames_per_stat, nchunk, inv_count, eps);
     MOCA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, reinterpret_cast<const half_t*>(x), reinterpret_cast<half_t*>(y),
+                       gamma, beta, meanrstd, HW, C, nchunk, frames_per_stat, silu);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_groupnorm_colsum_f16(const void* x, void* y, const float* gamma, const float* beta, const float* colsum,
+                                         int32_t tile_rows, int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
+                                         float eps, int32_t silu, float* ws, void* stream) {
+    if (!x || !y || !gamma || !beta || !ws || !colsum) return MOCA_E_BADARG;
+    if (F <= 0 || HW <= 0 || C <= 0 || C % 8 || C % GN_GROUPS || frames_per_stat <= 0 || F % frames_per_stat) return MOCA_E_BADARG;
+    if (tile_rows <= 0 || HW % tile_rows) return MOCA_E_BADARG;         // a row tile must not straddle two frames
+    const int nch8 = C / 8;
+    if (nch8 > 1024) return MOCA_E_BADARG;
+    int ppb = 256 / nch8;
+    if (ppb < 1) ppb = 1;
+    const int nchunk = gn_nchunk(F, HW);
+    float* meanrstd = ws + (int64_t)F * nchunk * GN_GROUPS * 2;         // same workspace layout as the three-launch path
+    hipStream_t st = moca_stream(stream);
+    const double inv_count = 1.0 / ((double)frames_per_stat * HW * (C / GN_GROUPS));
+    const int tps = frames_per_stat * (HW / tile_rows);                   // row tiles per statistics group
+    hipLaunchKernelGGL(gn_finalize_colsum_kernel, dim3(F / frames_per_stat, GN_GROUPS), dim3(64), 0, st, colsum, meanrstd,
+                       tps, C, C / GN_GROUPS, inv_count, eps);
+    MOCA_CHECK_LAUNCH();
+    const dim3 grid(F, nchunk), block(nch8, ppb);
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, reinterpret_cast<const half_t*>(x), reinterpret_cast<half_t*>(y),
                        gamma, beta, meanrstd, HW, C, nchunk, frames_per_stat, silu);
     MOCA_CHECK_LAUNCH();

@@ -110,13 +110,10 @@ def pack_geglu(weight, bias, device="cuda"):
 # --------------------------------------------------------------------------------------
 # kernel wrappers
 # --------------------------------------------------------------------------------------
-def gemm(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
-         residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False):
-    """out[M][:] = epilogue(gather(a) @ pw.w^T).  conv = (C, inH, inW, outH, outW, stride, up);
-    tconv = (C, T, HW)."""
-    lib = _l.load()
+def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
+                 residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None):
     p = _l.GemmParams()
-    p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), out.data_ptr()
+    p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), (out.data_ptr() if out is not None else None)
     p.bias = pw.bias.data_ptr() if pw.bias is not None else None
     p.rowadd = rowadd.data_ptr() if rowadd is not None else None
     p.residual = residual.data_ptr() if residual is not None else None
@@ -124,7 +121,7 @@ def gemm(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd
     p.M, p.N, p.K = M, pw.N, pw.K
     p.lda = lda if lda is not None else (a.stride(-2) if a.dim() >= 2 else pw.K)
     p.ldw = pw.w.stride(0)
-    p.ldo = out.stride(-2)
+    p.ldo = out.stride(-2) if out is not None else pw.N
     p.ldr = residual.stride(-2) if residual is not None else 0
     p.ld_rowadd = rowadd.stride(-2) if rowadd is not None else 0
     p.rowadd_div = rowadd_div
@@ -135,16 +132,38 @@ def gemm(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd
     if tconv is not None:
         p.C, p.T, p.HW = tconv
     p.flags = (_l.MOCA_EP_GEGLU if pw.geglu else 0) | (_l.MOCA_EP_OUT_F32 if out_f32 else 0) | \
-              ((_l.MOCA_EP_GELU | _l.MOCA_FORCE_SMALL_TILE) if gelu else 0)
+              ((_l.MOCA_EP_GELU | _l.MOCA_FORCE_SMALL_TILE) if gelu else 0) | (_l.MOCA_EP_COLSUM if colsum is not None else 0)
+    p.colsum = colsum.data_ptr() if colsum is not None else None
     p.splits = splits
-    _l.check(lib.moca_gemm_f16(C.byref(p), _st()), "moca_gemm_f16")
+    return p
+
+
+def gemm(a, pw: PackedWeight, out, **kw):
+    """out[M][:] = epilogue(gather(a) @ pw.w^T).  conv = (C, inH, inW, outH, outW, stride, up);
+    tconv = (C, T, HW); colsum = f32 [ceil(M/320)][N][2] buffer for the consumer GroupNorm's statistics
+    (only where gemm_colsum_rows(...) > 0)."""
+    p = _gemm_params(a, pw, out, **kw)
+    _l.check(_l.load().moca_gemm_f16(C.byref(p), _st()), "moca_gemm_f16")
     return out
+
+
+def gemm_colsum_rows(a, pw: PackedWeight, **kw):
+    """rows per row tile of the MOCA_EP_COLSUM output of this call, 0 if it cannot produce column sums"""
+    p = _gemm_params(a, pw, None, **kw)
+    return int(_l.load().moca_gemm_colsum_rows(C.byref(p)))
 
 
 def groupnorm(x, y, gamma, beta, *, F, HW, Cn, frames_per_stat, eps, silu, ws):
     _l.check(_l.load().moca_groupnorm_nhwc_f16(_l.ptr(x), _l.ptr(y), _l.ptr(gamma), _l.ptr(beta), F, HW, Cn,
                                                frames_per_stat, eps, 1 if silu else 0, _l.ptr(ws), _st()),
              "moca_groupnorm_nhwc_f16")
+    return y
+
+
+def groupnorm_colsum(x, y, gamma, beta, colsum, *, tile_rows, F, HW, Cn, frames_per_stat, eps, silu, ws):
+    _l.check(_l.load().moca_groupnorm_colsum_f16(_l.ptr(x), _l.ptr(y), _l.ptr(gamma), _l.ptr(beta), _l.ptr(colsum), tile_rows, F, HW, Cn,
+                                                 frames_per_stat, eps, 1 if silu else 0, _l.ptr(ws), _st()),
+             "moca_groupnorm_colsum_f16")
     return y
 
 

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import os
 import warnings
 
 import torch
@@ -90,22 +91,30 @@ class _PlanBase:
     def _splits(self, M, pw):
         return gemm_splits(M, pw)
 
-    def _gemm(self, a, pw, M, *, out_cols=None, **kw):
+    def _gemm(self, a, pw, M, *, out_cols=None, want_colsum=False, **kw):
+        """returns `out`, or `(out, colsum)` with want_colsum: colsum = (f32 [row tiles][N][2], rows per tile) when this launch
+        can leave the GroupNorm statistics of its output behind (moca_gemm_colsum_rows), else None"""
         n_out = pw.n_out if pw.geglu else pw.N
         out = self.pool.get(M, n_out)
         splits = self._splits(M, pw)
         ws = None
         if splits > 1:
             ws = self.pool.get(splits * M, pw.N, torch.float32)
-        self._emit(ops.gemm, a, pw, out, M=M, splits=splits, splitk_ws=ws, **kw)
+        cs = None
+        if want_colsum and os.environ.get("MOCA_GN_COLSUM", "1") != "0":     # (0: A/B runs against the three-launch GroupNorm)
+            rows = ops.gemm_colsum_rows(a, pw, M=M, splits=splits, **kw)
+            if rows > 0:
+                cs = (self.pool.get((M + rows - 1) // rows, 2 * pw.N, torch.float32), rows)
+        self._emit(ops.gemm, a, pw, out, M=M, splits=splits, splitk_ws=ws, colsum=None if cs is None else cs[0], **kw)
         if ws is not None:
             self.pool.put(ws)
-        return out
+        return (out, cs) if want_colsum else out
 
-    def linear(self, a, M, pw, residual=None, lda=None):
-        return self._gemm(a, pw, M, lda=lda if lda is not None else a.stride(-2), residual=residual)
+    def linear(self, a, M, pw, residual=None, lda=None, want_colsum=False):
+        return self._gemm(a, pw, M, lda=lda if lda is not None else a.stride(-2), residual=residual, want_colsum=want_colsum)
 
     def conv(self, fm, pw, *, stride=1, up=0, rowadd=None, rowadd_div=1, residual=None):
+        """3x3 conv; the output carries its GroupNorm statistics when the launch can produce them"""
         if up:
             oH, oW = fm.H * 2, fm.W * 2
         elif stride == 2:
@@ -113,21 +122,36 @@ class _PlanBase:
         else:
             oH, oW = fm.H, fm.W
         M = fm.F * oH * oW
-        out = self._gemm(fm.buf, pw, M, mode=_l.MOCA_A_CONV3X3, conv=(fm.C, fm.H, fm.W, oH, oW, stride, up),
-                         rowadd=rowadd, rowadd_div=rowadd_div, residual=residual)
-        return _FMap(out, fm.F, oH, oW, pw.N)
+        out, cs = self._gemm(fm.buf, pw, M, mode=_l.MOCA_A_CONV3X3, conv=(fm.C, fm.H, fm.W, oH, oW, stride, up),
+                             rowadd=rowadd, rowadd_div=rowadd_div, residual=residual, want_colsum=True)
+        return _FMap(out, fm.F, oH, oW, pw.N, cs)
 
     def tconv(self, fm, pw, residual=None):
-        out = self._gemm(fm.buf, pw, fm.M, mode=_l.MOCA_A_TCONV3, tconv=(fm.C, self.T, fm.H * fm.W), residual=residual)
-        return _FMap(out, fm.F, fm.H, fm.W, pw.N)
+        out, cs = self._gemm(fm.buf, pw, fm.M, mode=_l.MOCA_A_TCONV3, tconv=(fm.C, self.T, fm.H * fm.W), residual=residual,
+                             want_colsum=True)
+        return _FMap(out, fm.F, fm.H, fm.W, pw.N, cs)
 
     def gn(self, fm, gb, *, fps, eps, silu):
+        """GroupNorm(32) (+SiLU).  With `fm.colsum` (left by the producing GEMM) and row tiles that do not straddle frames the
+        statistics pass over x disappears: finalize-from-column-sums + apply; otherwise the three-launch / slab path."""
         y = self.pool.get(fm.M, fm.C)
-        ws = self.pool.get(1, ops.groupnorm_ws_floats(fm.F, fm.H * fm.W, fm.C), torch.float32)
-        self._emit(ops.groupnorm, fm.buf, y, gb[0], gb[1], F=fm.F, HW=fm.H * fm.W, Cn=fm.C, frames_per_stat=fps,
-                   eps=eps, silu=silu, ws=ws)
+        HW = fm.H * fm.W
+        ws = self.pool.get(1, ops.groupnorm_ws_floats(fm.F, HW, fm.C), torch.float32)
+        cs = fm.colsum
+        if cs is not None and HW % cs[1] == 0:
+            self._emit(ops.groupnorm_colsum, fm.buf, y, gb[0], gb[1], cs[0], tile_rows=cs[1], F=fm.F, HW=HW, Cn=fm.C,
+                       frames_per_stat=fps, eps=eps, silu=silu, ws=ws)
+        else:
+            self._emit(ops.groupnorm, fm.buf, y, gb[0], gb[1], F=fm.F, HW=HW, Cn=fm.C, frames_per_stat=fps,
+                       eps=eps, silu=silu, ws=ws)
         self.pool.put(ws)
         return y
+
+    def _drop_colsum(self, fm):
+        """the statistics buffer of a feature map goes back to the pool once its GroupNorm consumer has been recorded"""
+        if fm.colsum is not None:
+            self.pool.put(fm.colsum[0])
+            fm.colsum = None
 
     def ln(self, x, M, Cn, gb):
         y = self.pool.get(M, Cn)
@@ -192,6 +216,7 @@ class _Plan(_PlanBase):
         self._release(g1)
         g2 = self.gn(h1, P[id(mod.out_layers[0])], fps=1, eps=1e-5, silu=True)
         self._release(h1.buf)
+        self._drop_colsum(h1)
         if isinstance(mod.skip_connection, torch.nn.Identity):
             sk = x.buf
         else:
@@ -208,6 +233,7 @@ class _Plan(_PlanBase):
         for i, (name, idx) in enumerate((("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3))):
             sq = getattr(tc, name)
             g = self.gn(cur, P[id(sq[0])], fps=self.T, eps=1e-5, silu=True)
+            self._drop_colsum(cur)
             nxt = self.tconv(_FMap(g, cur.F, cur.H, cur.W, cur.C), P[id(sq[idx])], residual=h2.buf if i == 3 else None)
             self._release(g)
             if cur is not h2:
@@ -269,9 +295,9 @@ class _Plan(_PlanBase):
         self._release(n)
         for blk in mod.transformer_blocks:
             h = self.tblock(blk, h, x.M, mod.inner, mod.heads, spatial, x.F, x.H * x.W)
-        out = self.linear(h, x.M, P[id(mod.proj_out)], residual=x.buf)
+        out, cs = self.linear(h, x.M, P[id(mod.proj_out)], residual=x.buf, want_colsum=True)
         self._release(h)
-        return _FMap(out, x.F, x.H, x.W, x.C)
+        return _FMap(out, x.F, x.H, x.W, x.C, cs)
 
     def run_seq(self, seq, h):
         """TimestepEmbedSequential.forward, openaimodel3d.py:36-48"""
@@ -289,6 +315,7 @@ class _Plan(_PlanBase):
             else:
                 raise TypeError(type(layer))
             self._release(h.buf)
+            self._drop_colsum(h)
             h = nh
         return h
 
@@ -347,6 +374,7 @@ class _Plan(_PlanBase):
             h = self.run_seq(module, _FMap(cat, h.F, h.H, h.W, h.C + skip.C))
         g = self.gn(h, P[id(m.out[0])], fps=1, eps=1e-5, silu=True)
         self._release(h.buf)
+        self._drop_colsum(h)
         o = self.conv(_FMap(g, h.F, h.H, h.W, h.C), P[id(m.out[2])])
         self._release(g)
         self._emit(ops.nhwc_to_ncthw, o.buf, o.C, self.out, B=B, Cout=m.out_channels, T=T, HW=H * W)

@@ -178,11 +178,12 @@ class _Pool:
 
 
 class _FMap:
-    """channels-last feature map: buf [F*H*W][C] fp16"""
-    __slots__ = ("buf", "F", "H", "W", "C")
+    """channels-last feature map: buf [F*H*W][C] fp16; `colsum` = (f32 [row tiles][C][2] buffer, rows per tile) when the
+    GEMM that produced it also left per-(row tile, channel) sums and sums of squares behind (GroupNorm statistics)"""
+    __slots__ = ("buf", "F", "H", "W", "C", "colsum")
 
-    def __init__(self, buf, F, H, W, C):
-        self.buf, self.F, self.H, self.W, self.C = buf, F, H, W, C
+    def __init__(self, buf, F, H, W, C, colsum=None):
+        self.buf, self.F, self.H, self.W, self.C, self.colsum = buf, F, H, W, C, colsum
 
     @property
     def M(self):

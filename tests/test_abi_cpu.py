@@ -42,7 +42,7 @@ def test_gemm_params_struct_matches_header():
         decl = re.sub(r"^(const\s+)?(void|float|int32_t)\s*\*?\s*", "", line)
         names += [n.strip().lstrip("*") for n in decl.split(",") if n.strip()]
     assert names == [f[0] for f in lib.GemmParams._fields_]
-    assert C.sizeof(lib.GemmParams) == 152   # 7 pointers + 23 int32 (incl. nopad_lo, reserved_), padded to 8
+    assert C.sizeof(lib.GemmParams) == 160   # 7 pointers + 23 int32 (incl. nopad_lo, reserved_) padded to 8, + the colsum pointer
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

@@ -151,6 +151,57 @@ def test_groupnorm(Fr, HW, C, fps, silu, eps, path, monkeypatch):
     check(y, ref, TOL16, "groupnorm")
 
 
+@pytest.mark.parametrize("mode,Fr,HW,C,N,fps,with_res", [("tconv", 32, 1280, 320, 320, 16, True), ("conv", 8, 2560, 64, 640, 1, False),
+                                                            ("linear", 16, 1280, 320, 640, 8, True)])
+def test_gemm_colsum_feeds_groupnorm(mode, Fr, HW, C, N, fps, with_res):
+    """MOCA_EP_COLSUM: the 320-row GEMM leaves per-(row tile, column) sums / sums of squares of what it stores; the GroupNorm
+    that consumes them (finalize-from-column-sums + apply) must equal GroupNorm of the stored tensor (ref: torch)."""
+    M = Fr * HW
+    b = rnd(N, dtype=torch.float32)
+    res = rnd(M, N) if with_res else None
+    if mode == "linear":
+        a, w = rnd(M, C), rnd(N, C, scale=C ** -0.5)
+        pw, kw = ops.pack_linear(w, b), {}
+        ref = a.float() @ w.float().t() + b
+    elif mode == "conv":
+        H, W = 40, HW // 40
+        x = rnd(Fr, C, H, W)
+        w = rnd(N, C, 3, 3, scale=(9 * C) ** -0.5)
+        pw = ops.pack_conv3x3(w, b)
+        a = nhwc(x).reshape(M, C)
+        kw = dict(mode=L.MOCA_A_CONV3X3, conv=(C, H, W, H, W, 1, 0))
+        ref = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    else:
+        T = 16
+        x = rnd(Fr // T, C, T, HW, 1)
+        w = rnd(N, C, 3, 1, 1, scale=(3 * C) ** -0.5)
+        pw = ops.pack_tconv3(w, b)
+        a = x.permute(0, 2, 3, 4, 1).reshape(M, C).contiguous()
+        kw = dict(mode=L.MOCA_A_TCONV3, tconv=(C, T, HW))
+        ref = F.conv3d(x.float(), w.float(), b, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(M, N)
+    if res is not None:
+        ref = ref + res.float()
+    rows = ops.gemm_colsum_rows(a, pw, M=M, residual=res, **kw)
+    assert rows == 320, "this shape is expected on the 320-row kernel"
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    cs = torch.full((M // rows, 2 * N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm(a, pw, out, M=M, residual=res, colsum=cs, **kw)
+    check(out, ref, TOL16, f"gemm+colsum {mode}")
+    tiles = ref.view(M // rows, rows, N)
+    cs = cs.view(M // rows, N, 2)
+    assert relerr(cs[..., 0], tiles.sum(1)) < 2e-3 and relerr(cs[..., 1], (tiles * tiles).sum(1)) < 2e-3
+    g = rnd(N, dtype=torch.float32) * 0.2 + 1.0
+    be = rnd(N, dtype=torch.float32) * 0.2
+    y = torch.empty_like(out)
+    ws = torch.empty(ops.groupnorm_ws_floats(Fr, HW, N), dtype=torch.float32, device=DEV)
+    ops.groupnorm_colsum(out, y, g, be, cs, tile_rows=rows, F=Fr, HW=HW, Cn=N, frames_per_stat=fps, eps=1e-5, silu=True, ws=ws)
+    xr = out.float().view(Fr // fps, fps * HW, N).permute(0, 2, 1)
+    gref = F.silu(F.group_norm(xr, 32, g, be, 1e-5)).permute(0, 2, 1).reshape(Fr * HW, N)
+    check(y, gref, TOL16, f"groupnorm from column sums ({mode})")
+    # a shape the 320-row kernel does not take reports 0 (the plan then keeps the three-launch GroupNorm)
+    assert ops.gemm_colsum_rows(rnd(100, 64), ops.pack_linear(rnd(128, 64), None), M=100) == 0
+
+
 @pytest.mark.parametrize("M,C", [(500, 320), (333, 640), (200, 1280), (64, 512), (10, 2560),
                                  (16390, 320), (16385, 1280), (20001, 2560)])     # >= 16384 rows: four rows per wave (+ tails)
 def test_layernorm(M, C):
