@@ -44,6 +44,9 @@ extern "C" {
                            /* the stored values to p.colsum (GroupNorm statistics of the     */
                            /* consumer: openaimodel3d.py:149,173,253-262; attention.py:238): */
                            /* only where moca_gemm_colsum_rows() > 0                         */
+#define MOCA_EP_LN     32  /* also write ln_out = LayerNorm(out row) * ln_gamma + ln_beta    */
+                           /* (attention.py:199-201,216-219: the norm1/2/3 that follows the  */
+                           /* proj_in / to_out linears): only where moca_gemm_ln_ok() != 0   */
 #define MOCA_EP_GELU    8  /* out = gelu(acc + bias) (exact erf GELU; 128-row kernel only:   */
                            /* M <= 128 or MOCA_FORCE_SMALL_TILE, splits = 1)                  */
 
@@ -75,6 +78,11 @@ typedef struct moca_gemm_params {
     float*      colsum;    /* MOCA_EP_COLSUM: f32 [ceil(M/rows)][N][2] = (sum, sum of squares) over the rows of each
                               row tile (rows = moca_gemm_colsum_rows()), of the values as stored (after bias / row add /
                               residual, before the fp16 rounding)                                                      */
+    const float* ln_gamma; /* MOCA_EP_LN: LayerNorm weight / bias [N] f32                                              */
+    const float* ln_beta;
+    void*       ln_out;    /* MOCA_EP_LN: fp16 [M][ld_ln] second output                                                */
+    int32_t     ld_ln;
+    float       ln_eps;
 } moca_gemm_params;
 
 /* Replaces F.conv2d 3x3 (openaimodel3d.py:152,177,66-70,96-106,376,531),
@@ -88,6 +96,9 @@ int moca_gemm_f16(const moca_gemm_params* p, void* stream);
  * (it would not run on the 320-row direct-to-LDS kernel: N % 160, split-K, GEGLU, fp32 output, slow gather ...).
  * The GroupNorm that consumes the sums (moca_groupnorm_colsum_f16) needs H*W % rows == 0.                            */
 int moca_gemm_colsum_rows(const moca_gemm_params* p);
+/* 1 when this call can also produce the LayerNorm of its output rows (MOCA_EP_LN): a plain linear with N == 320 (a block of
+ * the 160 x 320 tiling owns complete rows), fast gather, no split-K, enough rows to fill the chip; else 0.               */
+int moca_gemm_ln_ok(const moca_gemm_params* p);
 /* bytes of split-K workspace moca_gemm_f16 needs for (M,N,splits) */
 int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits);
 

@@ -726,6 +726,72 @@ __device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p
     }
 }
 
+// ---- store loop of the 160 x 320 tile with LayerNorm (MOCA_EP_LN, N == 320: the block owns complete rows): 8 lanes per row,
+//      lane l8 -> 16-byte chunks l8, l8 + 8, ..., l8 + 32 (40 columns), 64 rows per pass.  Adds the residual in fp32, stores
+//      x = the linear's output (fp16) AND ln_out = LayerNorm(x) * gamma + beta (fp16; statistics of the fp32 values, variance
+//      two-pass from registers, reduced over the 8 lanes of a row with shuffles).
+__device__ __forceinline__ void store_fp16_tile_ln(const moca_gemm_params& p, const char* stage, float* gb, int pitch, int m0, int tid) {
+    constexpr int ROWS = 160, NC = 320, CPL = 5;
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    const int l8 = tid & 7, rsub = tid >> 3;
+    // gamma / beta go through LDS (`gb` = 2 x 320 floats behind the staged tile): 80 more live registers per thread would not
+    // fit beside the row
+    for (int i = tid; i < 2 * NC; i += 512) gb[i] = i < NC ? p.ln_gamma[i] : p.ln_beta[i - NC];
+    __syncthreads();
+    for (int row = rsub; row < ROWS; row += 64) {
+        const int m = m0 + row;
+        const bool ok = m < p.M;                         // (all 8 lanes of a row agree; the shuffles below need every lane)
+        float v[CPL][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int col = (l8 + 8 * c) * 8;
+            const half8v h = *reinterpret_cast<const half8v*>(stage + row * pitch + col * 2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = (float)h[j];
+            if (rowadd && ok) {
+                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[c][j] += (float)e[j];
+            }
+            if (resid && ok) {
+                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[c][j] += (float)e[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[c][j];
+        }
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        const float mean = s * (1.0f / NC);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; q += d * d; }
+        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+        const float rstd = rsqrtf(q * (1.0f / NC) + p.ln_eps);
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int col = (l8 + 8 * c) * 8;
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gb + col), g1 = *reinterpret_cast<const f32x4*>(gb + col + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(gb + NC + col), b1 = *reinterpret_cast<const f32x4*>(gb + NC + col + 4);
+                half8v o, n;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (half_t)v[c][j]; o[4 + j] = (half_t)v[c][4 + j];
+                    n[j] = (half_t)((v[c][j] - mean) * rstd * g0[j] + b0[j]);
+                    n[4 + j] = (half_t)((v[c][4 + j] - mean) * rstd * g1[j] + b1[j]);
+                }
+                *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = o;
+                *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.ln_out) + (int64_t)m * p.ld_ln + col) = n;
+            }
+        }
+    }
+}
+
 typedef __attribute__((address_space(3))) char* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
 
@@ -1737,21 +1803,25 @@ int launch_gemm_w80(const moca_gemm_params& p, hipStream_t st) {
 //   MFMAo : 25 MFMAs of tile i+1;  barrier
 // A DMA has two k-tiles of time to land (as in w80); data is read two barriers after the wait that retires it.
 // =====================================================================================
-template <int AMODE>
+// WIDE = false: 320 x 160 block tile, waves 4 (M) x 2 (N).  WIDE = true ("w80t"): 160 x 320, waves 2 x 4 -- the same 80 x 80 wave
+// tiles, ring and DMA stream with the roles of A and W swapped (10 A pieces + 20 W pieces per k-tile): a block then owns
+// COMPLETE output rows when N = 320, so A is fetched once instead of once per 160-column tile and the LayerNorm that follows the
+// attention / projection linears of the 320-channel level (attention.py:199-201,216-219) runs in the store loop (MOCA_EP_LN).
+template <int AMODE, bool WIDE>
 __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_params p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the launch stub; __amdgpu_buffer_rsrc_t is a device-only type)
-    constexpr int MT = 5, NT = 5, BN = 160, KS = 32, RB = 64;
-    constexpr int TM = 320;
-    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB;     // 20 + 10 KiB
+    constexpr int MT = 5, NT = 5, KS = 32, RB = 64;
+    constexpr int TM = WIDE ? 160 : 320, BN = WIDE ? 320 : 160;
+    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB;     // 30 KiB per k-tile either way
     constexpr int NS = 5;
     constexpr int PPW = 4;                               // DMA instructions per wave per k-tile (30 pieces + 2 repeats)
-    constexpr int NAP = 3;
+    constexpr int NAP = WIDE ? 2 : 3;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int wave_m = WIDE ? wave >> 2 : wave >> 1, wave_n = WIDE ? wave & 3 : wave & 1;
     const bool late = wave >= 4;                         // the half of the workgroup that runs one barrier behind
 
     const int tiles_m = (p.M + TM - 1) / TM;
@@ -1769,34 +1839,56 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     const int kt_begin = split * kts;
     const int nk = min(kt_begin + kts, nk_total) - kt_begin;
 
-    // DMA pieces exactly as in w80 / w80b
+    // DMA pieces (16 rows x 64 B each; lane -> row lane >> 2, physical chunk lane & 3).  The operand with 20 pieces ("big": A of
+    // the tall tile, W of the wide one) and the one with 10 ("small") are spread over the 8 waves as in w80 / w80b:
+    //   j = 0: big piece w      j = 1: big piece 8 + w      j = 2: big piece 16 + w (w < 4)  or  small piece w - 4 (w >= 4)
+    //   j = 3: small piece 4 + w (w < 6)  or  small piece 2 + w (w = 6, 7: a repeat, so that every wave issues 4 per k-tile)
     const int lrow = lane >> 2, pch = lane & 3;
     const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
-    const bool flex_is_a = wave < 4;
+    const bool flex_is_big = wave < 4;
     const int kt_last_pair = kt_begin + nk - 2;
     BGather<AMODE, NAP, KS> ga(p, lch, kt_begin, kt_last_pair);
+    const int small1 = wave < 6 ? 4 + wave : 2 + wave;    // j = 3
+    unsigned w_off[3];
+    if constexpr (!WIDE) {
 #pragma unroll
-    for (int g = 0; g < NAP; ++g) ga.init_row(g, m0 + (g < 2 ? g * 8 + wave : 16 + (wave & 3)) * 16 + lrow);
-    const int w_piece0 = wave & 3;
-    const int w_piece1 = wave < 6 ? 4 + wave : 2 + wave;
-    const unsigned w_off0 = (unsigned)(((int64_t)(n0 + w_piece0 * 16 + lrow) * p.ldw + lch * 8) * 2);
-    const unsigned w_off1 = (unsigned)(((int64_t)(n0 + w_piece1 * 16 + lrow) * p.ldw + lch * 8) * 2);
+        for (int g = 0; g < NAP; ++g) ga.init_row(g, m0 + (g < 2 ? g * 8 + wave : 16 + (wave & 3)) * 16 + lrow);
+        w_off[0] = (unsigned)(((int64_t)(n0 + (wave & 3) * 16 + lrow) * p.ldw + lch * 8) * 2);      // j = 2 (waves 4..7)
+        w_off[1] = (unsigned)(((int64_t)(n0 + small1 * 16 + lrow) * p.ldw + lch * 8) * 2);           // j = 3
+        w_off[2] = 0;
+    } else {
+        ga.init_row(0, m0 + (wave & 3) * 16 + lrow);                                                   // j = 2 (waves 4..7)
+        ga.init_row(1, m0 + small1 * 16 + lrow);                                                       // j = 3
+        w_off[0] = (unsigned)(((int64_t)(n0 + wave * 16 + lrow) * p.ldw + lch * 8) * 2);             // j = 0
+        w_off[1] = (unsigned)(((int64_t)(n0 + (8 + wave) * 16 + lrow) * p.ldw + lch * 8) * 2);       // j = 1
+        w_off[2] = (unsigned)(((int64_t)(n0 + (16 + (wave & 3)) * 16 + lrow) * p.ldw + lch * 8) * 2); // j = 2 (waves 0..3)
+    }
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, OOB_OFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, OOB_OFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_f = flex_is_a ? rsrc_a : rsrc_w;
+    const __amdgpu_buffer_rsrc_t rsrc_f = (flex_is_big != WIDE) ? rsrc_a : rsrc_w;      // descriptor of this wave's j = 2 piece
 
     auto dma_piece = [&](int slot, int j, auto odd_tag) {
         constexpr int odd = decltype(odd_tag)::value;
         const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
-        if (j < 2) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, sa + (j * 8 + wave) * 1024, 16, ga.a_off[j], ga.a_soff() + odd * KS * 2, 0, 0);
-        } else if (j == 2) {
-            const unsigned voff = flex_is_a ? ga.a_off[2] : w_off0;
-            const unsigned soff = flex_is_a ? ga.a_soff() : ga.w_soff();
-            const lds_ptr dst = flex_is_a ? sa + (16 + (wave & 3)) * 1024 : sa + A_BYTES + w_piece0 * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_f, dst, 16, voff, soff + odd * KS * 2, 0, 0);
+        const unsigned a_s = ga.a_soff() + odd * KS * 2, w_s = ga.w_soff() + odd * KS * 2;
+        if constexpr (!WIDE) {
+            if (j < 2) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, sa + (j * 8 + wave) * 1024, 16, ga.a_off[j], a_s, 0, 0);
+            } else if (j == 2) {
+                const lds_ptr dst = flex_is_big ? sa + (16 + (wave & 3)) * 1024 : sa + A_BYTES + (wave & 3) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_f, dst, 16, flex_is_big ? ga.a_off[2] : w_off[0], flex_is_big ? a_s : w_s, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, sa + A_BYTES + small1 * 1024, 16, w_off[1], w_s, 0, 0);
+            }
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, sa + A_BYTES + w_piece1 * 1024, 16, w_off1, ga.w_soff() + odd * KS * 2, 0, 0);
+            if (j < 2) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, sa + A_BYTES + (j * 8 + wave) * 1024, 16, w_off[j], w_s, 0, 0);
+            } else if (j == 2) {
+                const lds_ptr dst = flex_is_big ? sa + A_BYTES + (16 + (wave & 3)) * 1024 : sa + (wave & 3) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_f, dst, 16, flex_is_big ? w_off[2] : ga.a_off[0], flex_is_big ? w_s : a_s, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, sa + small1 * 1024, 16, ga.a_off[1], a_s, 0, 0);
+            }
         }
     };
     auto issue_pair = [&](int slot_even, int slot_odd) {
@@ -1936,23 +2028,28 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         }
     }
     __syncthreads();
-    if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
-    else store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
+    if constexpr (WIDE) {
+        if (p.flags & MOCA_EP_LN) store_fp16_tile_ln(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, tid);
+        else store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
+    } else {
+        if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
+        else store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
+    }
 #endif
 }
 
-template <int AMODE>
+template <int AMODE, bool WIDE>
 int launch_gemm_w80s(const moca_gemm_params& p, hipStream_t st) {
-    const int tiles_m = (p.M + 319) / 320, tiles_n = p.N / 160;
+    const int tiles_m = WIDE ? (p.M + 159) / 160 : (p.M + 319) / 320, tiles_n = WIDE ? p.N / 320 : p.N / 160;
     const int nblk = tiles_m * tiles_n * p.splits;
     constexpr int lds = 5 * (320 + 160) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w80s_kernel<AMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w80s_kernel<AMODE, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MOCA_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_w80s_kernel<AMODE>), dim3(nblk), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_w80s_kernel<AMODE, WIDE>), dim3(nblk), dim3(512), lds, st, p);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
@@ -2001,13 +2098,25 @@ static inline bool takes_w80(const moca_gemm_params& p) {
 static inline bool takes_w80s(const moca_gemm_params& p) {
     return takes_w80(p) && fast_gather(p) && w80_variant() == 2 && buffer_addressable(p);
 }
+static inline bool takes_w80t_ln(const moca_gemm_params& p) {     // the 160 x 320 tiling with the LayerNorm store loop
+    return p.a_mode == MOCA_A_LINEAR && p.N == 320 && p.splits == 1 && takes_w80s(p) && !(p.flags & MOCA_EP_COLSUM);
+}
 
 int launch_gemm_w80_mode(const moca_gemm_params& p, bool fastp, hipStream_t st) {
     const int buf_mode = w80_variant();
     if (fastp && buf_mode == 2 && buffer_addressable(p)) {
-        if (p.a_mode == MOCA_A_LINEAR) return launch_gemm_w80s<MOCA_A_LINEAR>(p, st);
-        if (p.a_mode == MOCA_A_CONV3X3) return launch_gemm_w80s<MOCA_A_CONV3X3>(p, st);
-        return launch_gemm_w80s<MOCA_A_TCONV3>(p, st);
+        if (p.a_mode == MOCA_A_LINEAR) {
+            // the 160 x 320 tiling: required by the LayerNorm store loop; also taken by the other N = 320 linears with a long K (A is
+            // fetched once instead of twice: 95 vs 101 us at M = 81920, K = 1280; equal at K = 320).  MOCA_GEMM_WIDE=0/1 = never / for
+            // every N % 320 == 0 linear (A/B runs)
+            const char* e_wide = getenv("MOCA_GEMM_WIDE");
+            const int wide_mode = e_wide ? atoi(e_wide) : 2;
+            const bool wide = (p.flags & MOCA_EP_LN) || (!(p.flags & MOCA_EP_COLSUM) && p.N % 320 == 0 &&
+                                                         (wide_mode == 1 || (wide_mode == 2 && p.N == 320 && p.K >= 640)));
+            return wide ? launch_gemm_w80s<MOCA_A_LINEAR, true>(p, st) : launch_gemm_w80s<MOCA_A_LINEAR, false>(p, st);
+        }
+        if (p.a_mode == MOCA_A_CONV3X3) return launch_gemm_w80s<MOCA_A_CONV3X3, false>(p, st);
+        return launch_gemm_w80s<MOCA_A_TCONV3, false>(p, st);
     }
     if (fastp && buf_mode == 1 && buffer_addressable(p)) {
         if (p.a_mode == MOCA_A_LINEAR) return launch_gemm_w80b<MOCA_A_LINEAR>(p, st);
@@ -2093,6 +2202,14 @@ extern "C" int moca_gemm_colsum_rows(const moca_gemm_params* pp) {
     return (p.splits == 1 && takes_w80s(p)) ? 320 : 0;
 }
 
+extern "C" int moca_gemm_ln_ok(const moca_gemm_params* pp) {
+    if (!pp) return 0;
+    moca_gemm_params p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
+    normalise_splits(p);
+    return takes_w80t_ln(p) ? 1 : 0;
+}
+
 extern "C" int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits) {
     return splits > 1 ? (int64_t)splits * M * N * 4 : 0;
 }
@@ -2147,6 +2264,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     // 320-row tiles fill the chip.  MOCA_GEMM_W80=0 disables it (A/B against the 256-row kernel), 2 drops the tile-count rule.
     const bool use_w80 = takes_w80(p);
     if ((p.flags & MOCA_EP_COLSUM) && !(p.colsum && p.splits == 1 && takes_w80s(p))) return MOCA_E_BADARG;   // ask moca_gemm_colsum_rows() first
+    if ((p.flags & MOCA_EP_LN) && !(p.ln_gamma && p.ln_beta && p.ln_out && p.ld_ln % 8 == 0 && takes_w80t_ln(p))) return MOCA_E_BADARG;   // ask moca_gemm_ln_ok() first
     if (use_w80) {
         rc = launch_gemm_w80_mode(p, fastp, st);
     } else if (use_big && big_bn == 128 && use_g4) {

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOCA_HIP_LIB") or os.path.join(_HERE, "libmoca_hip.so")
 
 MOCA_A_LINEAR, MOCA_A_CONV3X3, MOCA_A_TCONV3 = 0, 1, 2
-MOCA_EP_GEGLU, MOCA_EP_OUT_F32, MOCA_FORCE_SMALL_TILE, MOCA_EP_GELU, MOCA_EP_COLSUM = 1, 2, 4, 8, 16
+MOCA_EP_GEGLU, MOCA_EP_OUT_F32, MOCA_FORCE_SMALL_TILE, MOCA_EP_GELU, MOCA_EP_COLSUM, MOCA_EP_LN = 1, 2, 4, 8, 16, 32
 
 _ERR = {0: "ok", -1: "bad argument (shape/alignment contract)", -2: "HIP launch/runtime error",
         -3: "no gfx950 device", -4: "graph capture/replay failed"}
@@ -36,7 +36,8 @@ class GemmParams(C.Structure):
         ("inH", C.c_int32), ("inW", C.c_int32), ("outH", C.c_int32), ("outW", C.c_int32),
         ("stride", C.c_int32), ("up", C.c_int32), ("T", C.c_int32), ("HW", C.c_int32),
         ("flags", C.c_int32), ("splits", C.c_int32), ("nopad_lo", C.c_int32), ("reserved_", C.c_int32),
-        ("colsum", C.c_void_p),
+        ("colsum", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out", C.c_void_p),
+        ("ld_ln", C.c_int32), ("ln_eps", C.c_float),
     ]
 
 
@@ -46,6 +47,7 @@ SIGNATURES = {
     "moca_gemm_f16": (C.c_int, [C.POINTER(GemmParams), _vp]),
     "moca_gemm_splitk_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "moca_gemm_colsum_rows": (C.c_int, [C.POINTER(GemmParams)]),
+    "moca_gemm_ln_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_groupnorm_colsum_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "moca_groupnorm_nhwc_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "moca_groupnorm_ws_bytes": (_i64, [_i32, _i32, _i32]),

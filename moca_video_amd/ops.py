@@ -111,7 +111,7 @@ def pack_geglu(weight, bias, device="cuda"):
 # kernel wrappers
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
-                 residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None):
+                 residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None):
     p = _l.GemmParams()
     p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), (out.data_ptr() if out is not None else None)
     p.bias = pw.bias.data_ptr() if pw.bias is not None else None
@@ -134,6 +134,12 @@ def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR
     p.flags = (_l.MOCA_EP_GEGLU if pw.geglu else 0) | (_l.MOCA_EP_OUT_F32 if out_f32 else 0) | \
               ((_l.MOCA_EP_GELU | _l.MOCA_FORCE_SMALL_TILE) if gelu else 0) | (_l.MOCA_EP_COLSUM if colsum is not None else 0)
     p.colsum = colsum.data_ptr() if colsum is not None else None
+    if ln is not None:                       # (gamma f32 [N], beta f32 [N], ln_out fp16 [M][ld] or None when only probing, eps)
+        p.flags |= _l.MOCA_EP_LN
+        p.ln_gamma, p.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
+        p.ln_out = ln[2].data_ptr() if ln[2] is not None else None
+        p.ld_ln = ln[2].stride(-2) if ln[2] is not None else pw.N
+        p.ln_eps = ln[3]
     p.splits = splits
     return p
 
@@ -145,6 +151,12 @@ def gemm(a, pw: PackedWeight, out, **kw):
     p = _gemm_params(a, pw, out, **kw)
     _l.check(_l.load().moca_gemm_f16(C.byref(p), _st()), "moca_gemm_f16")
     return out
+
+
+def gemm_ln_ok(a, pw: PackedWeight, **kw):
+    """can this call also write the LayerNorm of its output rows (MOCA_EP_LN)?"""
+    p = _gemm_params(a, pw, None, **kw)
+    return bool(_l.load().moca_gemm_ln_ok(C.byref(p)))
 
 
 def gemm_colsum_rows(a, pw: PackedWeight, **kw):

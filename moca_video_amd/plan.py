@@ -267,34 +267,52 @@ class _Plan(_PlanBase):
         self._release(q)
         return o
 
-    def tblock(self, blk, h, M, Cn, heads, spatial, F, HW):
-        """BasicTransformerBlock._forward, attention.py:216-220"""
+    def linear_ln(self, a, M, pw, gb, residual=None):
+        """`out = linear(a) (+ residual)` and `l = LayerNorm(out)` (eps 1e-5, attention.py:199-201).  ONE launch where the
+        160 x 320 tiling applies (N = 320: a block owns whole rows and normalises them in its store loop, MOCA_EP_LN);
+        otherwise the linear followed by the LayerNorm kernel."""
+        lda = a.stride(-2)
+        splits = self._splits(M, pw)
+        if os.environ.get("MOCA_GEMM_LN", "1") != "0" and \
+                ops.gemm_ln_ok(a, pw, M=M, lda=lda, residual=residual, splits=splits, ln=(gb[0], gb[1], None, 1e-5)):
+            out, l = self.pool.get(M, pw.N), self.pool.get(M, pw.N)
+            self._emit(ops.gemm, a, pw, out, M=M, lda=lda, residual=residual, splits=1, ln=(gb[0], gb[1], l, 1e-5))
+            return out, l
+        out = self.linear(a, M, pw, residual=residual)
+        return out, self.ln(out, M, pw.N, gb)
+
+    def tblock(self, blk, h, l, M, Cn, heads, spatial, F, HW, next_gb=None):
+        """BasicTransformerBlock._forward, attention.py:216-220.  `l` = norm1(h), already computed by the producer of h;
+        returns (h_out, norm1 of the NEXT block applied to it, or None)."""
         P = self.P
-        for att, nrm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):
-            l = self.ln(h, M, Cn, P[id(nrm)])
+        for att, nxt in ((blk.attn1, blk.norm2), (blk.attn2, blk.norm3)):
             if att.is_self:
                 o = self._attn_self(att, l, M, Cn, heads, spatial, F, HW)
             else:
                 o = self._attn_cross(att, l, M, Cn, heads, F, HW)
             self._release(l)
-            nh = self.linear(o, M, P[id(att.to_out[0])], residual=h)
+            nh, l = self.linear_ln(o, M, P[id(att.to_out[0])], P[id(nxt)], residual=h)
             self._release(o, h)
             h = nh
-        l = self.ln(h, M, Cn, P[id(blk.norm3)])
         ff = self.linear(l, M, P[id(blk.ff.net[0].proj)])        # GEGLU fused into the epilogue
         self._release(l)
-        nh = self.linear(ff, M, P[id(blk.ff.net[2])], residual=h)
+        if next_gb is not None:
+            nh, l = self.linear_ln(ff, M, P[id(blk.ff.net[2])], next_gb, residual=h)
+        else:
+            nh, l = self.linear(ff, M, P[id(blk.ff.net[2])], residual=h), None
         self._release(ff, h)
-        return nh
+        return nh, l
 
     def transformer(self, mod, x, spatial):
         """SpatialTransformer.forward attention.py:262-278 / TemporalTransformer.forward :331-373"""
         P = self.P
         n = self.gn(x, P[id(mod.norm)], fps=1 if spatial else self.T, eps=1e-6, silu=False)
-        h = self.linear(n, x.M, P[id(mod.proj_in)])
+        blocks = list(mod.transformer_blocks)
+        h, l = self.linear_ln(n, x.M, P[id(mod.proj_in)], P[id(blocks[0].norm1)])
         self._release(n)
-        for blk in mod.transformer_blocks:
-            h = self.tblock(blk, h, x.M, mod.inner, mod.heads, spatial, x.F, x.H * x.W)
+        for i, blk in enumerate(blocks):
+            nxt = P[id(blocks[i + 1].norm1)] if i + 1 < len(blocks) else None
+            h, l = self.tblock(blk, h, l, x.M, mod.inner, mod.heads, spatial, x.F, x.H * x.W, next_gb=nxt)
         out, cs = self.linear(h, x.M, P[id(mod.proj_out)], residual=x.buf, want_colsum=True)
         self._release(h)
         return _FMap(out, x.F, x.H, x.W, x.C, cs)

@@ -42,7 +42,7 @@ def test_gemm_params_struct_matches_header():
         decl = re.sub(r"^(const\s+)?(void|float|int32_t)\s*\*?\s*", "", line)
         names += [n.strip().lstrip("*") for n in decl.split(",") if n.strip()]
     assert names == [f[0] for f in lib.GemmParams._fields_]
-    assert C.sizeof(lib.GemmParams) == 160   # 7 pointers + 23 int32 (incl. nopad_lo, reserved_) padded to 8, + the colsum pointer
+    assert C.sizeof(lib.GemmParams) == 192   # 7 pointers + 23 int32 padded to 8, + colsum, ln_gamma, ln_beta, ln_out pointers + ld_ln + ln_eps
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

@@ -202,6 +202,31 @@ def test_gemm_colsum_feeds_groupnorm(mode, Fr, HW, C, N, fps, with_res):
     assert ops.gemm_colsum_rows(rnd(100, 64), ops.pack_linear(rnd(128, 64), None), M=100) == 0
 
 
+@pytest.mark.parametrize("M,K,with_res", [(40000, 320, True), (33000, 1280, False)])
+def test_gemm_layernorm_epilogue(M, K, with_res):
+    """MOCA_EP_LN: the 160 x 320 tiling writes the linear's output (+residual) AND its LayerNorm in one launch
+    (attention.py:199-201,216-219); M tail rows, both outputs against torch."""
+    N = 320
+    a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+    b = rnd(N, dtype=torch.float32)
+    res = rnd(M, N) if with_res else None
+    g = rnd(N, dtype=torch.float32) * 0.2 + 1.0
+    be = rnd(N, dtype=torch.float32) * 0.2
+    pw = ops.pack_linear(w, b)
+    assert ops.gemm_ln_ok(a, pw, M=M, residual=res, ln=(g, be, None, 1e-5))
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ln = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+    ops.gemm(a, pw, out, M=M, residual=res, ln=(g, be, ln, 1e-5))
+    ref = a.float() @ w.float().t() + b
+    if res is not None:
+        ref = ref + res.float()
+    check(out, ref, TOL16, "linear (+res) of the LN launch")
+    check(ln, F.layer_norm(ref, (N,), g, be, 1e-5), TOL16, "LayerNorm epilogue")
+    # not available for other widths / short M: the plan falls back to linear + layernorm kernel
+    assert not ops.gemm_ln_ok(rnd(40000, 640), ops.pack_linear(rnd(640, 640), None), M=40000, ln=(g, be, None, 1e-5))
+    assert not ops.gemm_ln_ok(rnd(1000, 320), pw, M=1000, ln=(g, be, None, 1e-5))
+
+
 @pytest.mark.parametrize("M,C", [(500, 320), (333, 640), (200, 1280), (64, 512), (10, 2560),
                                  (16390, 320), (16385, 1280), (20001, 2560)])     # >= 16384 rows: four rows per wave (+ tails)
 def test_layernorm(M, C):
