@@ -39,10 +39,14 @@ with torch.cuda.stream(st):
             mode = {0: "lin", 1: "conv", 2: "tconv"}[kw.get("mode", 0)]
             key = f"gemm {mode:5s} M={kw['M']:6d} N={pw.N:5d} K={pw.K:5d}" + (" geglu" if pw.geglu else "") + \
                   (" +res" if kw.get("residual") is not None else "") + (" +rowadd" if kw.get("rowadd") is not None else "") + \
-                  (f" splits={kw['splits']}" if kw.get("splits", 1) > 1 else "") + (" f32" if kw.get("out_f32") else "")
+                  (f" splits={kw['splits']}" if kw.get("splits", 1) > 1 else "") + (" f32" if kw.get("out_f32") else "") + \
+                  (" +colsum" if kw.get("colsum") is not None else "") + (" +LN" if kw.get("ln") is not None else "")
             flop = 2.0 * kw["M"] * pw.N * pw.w.shape[1]
             if kw.get("conv") is not None and kw["conv"][6]:
                 pass
+        elif fn == "groupnorm_colsum":
+            key = f"groupnorm(colsum) F={kw['F']} HW={kw['HW']} C={kw['Cn']} fps={kw['frames_per_stat']}"
+            flop = 0
         elif fn == "groupnorm":
             key = f"groupnorm F={kw['F']} HW={kw['HW']} C={kw['Cn']} fps={kw['frames_per_stat']}"
             flop = 0

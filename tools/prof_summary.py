@@ -9,16 +9,20 @@ for r in rows:
     n = r['Name']
     if any(x in n for x in ('distribution_elementwise', 'rocclr', 'FillFunctor', 'direct_copy', 'float16_copy', 'CatArray', 'index_', 'arange', 'gather_kernel', 'reduce_kernel', 'AbsFunctor', 'CompareEq', 'MulFunctor', 'CUDAFunctorOnSelf')):
         k = 'torch(init/host glue)'
-    elif 'gemm_w80' in n: k = 'gemm_w80 (320x160)'
+    elif 'gemm_w80s' in n and 'ELb1E' in n: k = 'gemm_w80s wide (160x320, +LN)'
+    elif 'gemm_w80s' in n: k = 'gemm_w80s (320x160, staggered)'
+    elif 'gemm_w80' in n: k = 'gemm_w80/w80b (320x160)'
     elif 'gemm_g4' in n: k = 'gemm_g4 (GEGLU K<=640)'
     elif 'gemm_glds' in n: k = 'gemm_glds (256xBN)'
     elif 'gemm_f16' in n: k = 'gemm_small'
     elif 'splitk' in n: k = 'splitk_reduce'
     elif 'temporal_attention' in n: k = 'temporal_attn'
-    elif 'attention_kernel' in n: k = 'attention'
+    elif 'attention_v4' in n: k = 'attention_v4 (long keys)'
+    elif 'attention_kernel' in n: k = 'attention (short keys / causal)'
     elif 'gn_slab' in n: k = 'gn_slab (single launch)'
     elif 'gn_partial' in n: k = 'gn_partial'
     elif 'gn_apply' in n: k = 'gn_apply'
+    elif 'gn_finalize_colsum' in n: k = 'gn_finalize (from GEMM column sums)'
     elif 'gn_final' in n: k = 'gn_finalize'
     elif 'layernorm' in n: k = 'layernorm'
     else: k = 'other moca kernels'
