@@ -146,10 +146,11 @@ def video_leg(dm, ae, device, T, H, W):
                                 latents=lat, conditioned_image=cimg, masks=mask, decode=True, batch_windows=True)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    ok = len(frames) == 148 and all(bool(torch.isfinite(f).all()) for f in frames[-4:]) and tuple(frames[0].shape) == (1, 3, 1, 8 * H, 8 * W)
+    n_finite = sum(int(bool(torch.isfinite(f).all())) for f in frames)
     dm.first_stage_model = None
     return {"video_s": round(t2 - t0, 2), "base_sampling_s": round(t1 - t0, 2), "fifo_148_iterations_incl_decode_s": round(t2 - t1, 2),
-            "unet_steps": 2 * 64 + 148 * 16, "frames_decoded": 16 + 148, "output_ok": ok,
+            "unet_steps": 2 * 64 + 148 * 16, "frames_decoded": 16 + 148, "frames_emitted": len(frames),
+            "frame_shape": list(frames[0].shape), "frames_finite": n_finite, "base_latents_finite": bool(torch.isfinite(samples).all()),
             "note": "measured, one prompt, 1 GPU: 64 CFG base steps + prepare_latents + 148 FIFO iterations (8 batched windows, 154-token "
                     "cond / 77-token uncond, mask injection, FreeInit shift) + VAE decode of every emitted frame"}
 
