@@ -2108,11 +2108,11 @@ int launch_gemm_w80_mode(const moca_gemm_params& p, bool fastp, hipStream_t st) 
         if (p.a_mode == MOCA_A_LINEAR) {
             // the 160 x 320 tiling: required by the LayerNorm store loop; also taken by the other N = 320 linears (A is fetched once
             // instead of twice: 37 vs 38 us at M = 81920, K = 320; 99 vs 103 at K = 1280; 182 vs 193 / 366 vs 384 at M = 327680).
-            // MOCA_GEMM_WIDE=0/1 = never / for every N % 320 == 0 linear (A/B runs)
+            // MOCA_GEMM_WIDE=0 = only with MOCA_EP_LN (A/B runs)
             const char* e_wide = getenv("MOCA_GEMM_WIDE");
             const int wide_mode = e_wide ? atoi(e_wide) : 2;
             const bool wide = (p.flags & MOCA_EP_LN) || (!(p.flags & MOCA_EP_COLSUM) && p.N % 320 == 0 &&
-                                                         (wide_mode == 1 || (wide_mode == 2 && p.N == 320)));
+                                                         (wide_mode == 1 || wide_mode == 2));      // (N = 640 / 960 / 1920 linears: 0..-10 % as well)
             return wide ? launch_gemm_w80s<MOCA_A_LINEAR, true>(p, st) : launch_gemm_w80s<MOCA_A_LINEAR, false>(p, st);
         }
         if (p.a_mode == MOCA_A_CONV3X3) return launch_gemm_w80s<MOCA_A_CONV3X3, false>(p, st);
