@@ -394,8 +394,8 @@ def main():
         "achieved_tflops": round(value / world * FLOP_PER_UNET_STEP / 1e12, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic_bytes if not concurrent else None, "traffic_source": traffic_src if not concurrent else None,
-                     "kernel": "UNet forward launch sequence (hipGraph of ~0.9k launches; the implicit-GEMM conv/linear kernels "
-                               "gemm_w80/gemm_glds/gemm_g4 are 75% of it)" + (", two B=1 graphs on two streams" if concurrent else ", batch 2"),
+                     "kernel": "UNet forward launch sequence (hipGraph of ~0.75k launches; the implicit-GEMM conv/linear kernels "
+                               "gemm_w80s/gemm_glds/gemm_g4 are 78% of it)" + (", two B=1 graphs on two streams" if concurrent else ", batch 2"),
                      "flop_per_launch": flop_per_launch, "avg_launch_ms": round(avg_launch_ms, 3), "launches": len(unet_ms)},
     }
     if world == 1 and not args.no_fifo:
