@@ -681,9 +681,10 @@ __device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const
 //      consumer's GroupNorm would read back, before the fp16 rounding); the 25 row subsets are then combined through LDS in a
 //      fixed order (deterministic) and the block writes colsum[tile_m][n0 .. n0+160)[2].  `red` = 32 000 B of LDS scratch
 //      behind the staged tile.
+template <int ROWS, int BNC>
 __device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p, const char* stage, float* red, int pitch,
                                                        int m0, int n0, int tile_m, int tid) {
-    constexpr int ROWS = 320, BNC = 160, CPR = BNC / 8, RS = 25;          // 20 chunks per row, 25 row subsets (500 of 512 threads)
+    constexpr int CPR = BNC / 8, RS = 512 / CPR;          // 320 x 160: 20 chunks per row, 25 row subsets; 160 x 320: 40 and 12
     const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
     const int ch = tid % CPR, rs = tid / CPR;
@@ -718,11 +719,11 @@ __device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p
         for (int j = 0; j < 8; ++j) { red[(rs * BNC + ch * 8 + j) * 2] = s[j]; red[(rs * BNC + ch * 8 + j) * 2 + 1] = q[j]; }
     }
     __syncthreads();
-    if (tid < 2 * BNC) {                                 // thread -> (column, sum | sum of squares)
+    for (int i = tid; i < 2 * BNC; i += 512) {
         float a = 0.f;
-#pragma unroll 5
-        for (int r = 0; r < RS; ++r) a += red[r * BNC * 2 + tid];
-        p.colsum[((int64_t)tile_m * p.N + n0) * 2 + tid] = a;
+#pragma unroll 4
+        for (int r = 0; r < RS; ++r) a += red[r * BNC * 2 + i];
+        p.colsum[((int64_t)tile_m * p.N + n0) * 2 + i] = a;
     }
 }
 
@@ -2030,9 +2031,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     __syncthreads();
     if constexpr (WIDE) {
         if (p.flags & MOCA_EP_LN) store_fp16_tile_ln(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, tid);
+        else if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
         else store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
     } else {
-        if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
+        if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
         else store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
     }
 #endif
@@ -2098,6 +2100,18 @@ static inline bool takes_w80(const moca_gemm_params& p) {
 static inline bool takes_w80s(const moca_gemm_params& p) {
     return takes_w80(p) && fast_gather(p) && w80_variant() == 2 && buffer_addressable(p);
 }
+// which form of the staggered kernel a call that takes_w80s() runs on.  The 160 x 320 tiling is required by the LayerNorm store
+// loop and taken by every N % 320 == 0 contraction: A is fetched once per 320 columns instead of once per 160 (linears: 37 vs 38 us
+// at M = 81920, N = K = 320; 99 vs 103 at K = 1280; 182 vs 193 / 366 vs 384 at M = 327680; N = 640: 22.7 vs 25.1).
+// Convs / temporal convs gain nothing from it (+-1 %, A/B on one device) and stay on the 320 x 160 form.
+// MOCA_GEMM_WIDE = 0: only with MOCA_EP_LN; 1 (default): linears; 2: convs / temporal convs too (A/B runs)
+static inline bool w80s_wide(const moca_gemm_params& p) {
+    if (p.flags & MOCA_EP_LN) return true;
+    const char* e_wide = getenv("MOCA_GEMM_WIDE");
+    const int mode = e_wide ? atoi(e_wide) : 1;
+    if (mode == 0 || p.N % 320) return false;
+    return p.a_mode == MOCA_A_LINEAR || mode == 2;
+}
 static inline bool takes_w80t_ln(const moca_gemm_params& p) {     // the 160 x 320 tiling with the LayerNorm store loop
     return p.a_mode == MOCA_A_LINEAR && p.N == 320 && p.splits == 1 && takes_w80s(p) && !(p.flags & MOCA_EP_COLSUM);
 }
@@ -2105,18 +2119,10 @@ static inline bool takes_w80t_ln(const moca_gemm_params& p) {     // the 160 x 3
 int launch_gemm_w80_mode(const moca_gemm_params& p, bool fastp, hipStream_t st) {
     const int buf_mode = w80_variant();
     if (fastp && buf_mode == 2 && buffer_addressable(p)) {
-        if (p.a_mode == MOCA_A_LINEAR) {
-            // the 160 x 320 tiling: required by the LayerNorm store loop; also taken by the other N = 320 linears (A is fetched once
-            // instead of twice: 37 vs 38 us at M = 81920, K = 320; 99 vs 103 at K = 1280; 182 vs 193 / 366 vs 384 at M = 327680).
-            // MOCA_GEMM_WIDE=0 = only with MOCA_EP_LN (A/B runs)
-            const char* e_wide = getenv("MOCA_GEMM_WIDE");
-            const int wide_mode = e_wide ? atoi(e_wide) : 2;
-            const bool wide = (p.flags & MOCA_EP_LN) || (!(p.flags & MOCA_EP_COLSUM) && p.N % 320 == 0 &&
-                                                         (wide_mode == 1 || wide_mode == 2));      // (N = 640 / 960 / 1920 linears: 0..-10 % as well)
-            return wide ? launch_gemm_w80s<MOCA_A_LINEAR, true>(p, st) : launch_gemm_w80s<MOCA_A_LINEAR, false>(p, st);
-        }
-        if (p.a_mode == MOCA_A_CONV3X3) return launch_gemm_w80s<MOCA_A_CONV3X3, false>(p, st);
-        return launch_gemm_w80s<MOCA_A_TCONV3, false>(p, st);
+        const bool wide = w80s_wide(p);
+        if (p.a_mode == MOCA_A_LINEAR) return wide ? launch_gemm_w80s<MOCA_A_LINEAR, true>(p, st) : launch_gemm_w80s<MOCA_A_LINEAR, false>(p, st);
+        if (p.a_mode == MOCA_A_CONV3X3) return wide ? launch_gemm_w80s<MOCA_A_CONV3X3, true>(p, st) : launch_gemm_w80s<MOCA_A_CONV3X3, false>(p, st);
+        return wide ? launch_gemm_w80s<MOCA_A_TCONV3, true>(p, st) : launch_gemm_w80s<MOCA_A_TCONV3, false>(p, st);
     }
     if (fastp && buf_mode == 1 && buffer_addressable(p)) {
         if (p.a_mode == MOCA_A_LINEAR) return launch_gemm_w80b<MOCA_A_LINEAR>(p, st);
@@ -2199,7 +2205,7 @@ extern "C" int moca_gemm_colsum_rows(const moca_gemm_params* pp) {
     moca_gemm_params p = *pp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
     normalise_splits(p);
-    return (p.splits == 1 && takes_w80s(p)) ? 320 : 0;
+    return (p.splits == 1 && takes_w80s(p)) ? (w80s_wide(p) ? 160 : 320) : 0;
 }
 
 extern "C" int moca_gemm_ln_ok(const moca_gemm_params* pp) {
