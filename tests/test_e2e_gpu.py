@@ -1,7 +1,7 @@
 """End-to-end parity of the whole pipelines on the reduced-width UNet: the HIP path driven through the drop-in classes
 (DenoiseModel / DDIMSampler / fifo_ddim_sampling) against the SAME pipelines composed from the oracle's pieces (UNet +
 p_sample_ddim + ddim_step + prepare/shift_latents), with every random draw fixed.  The denoising loop feeds its own output
-back in, so the fp16-storage error of the UNet accumulates: tolerance 6e-2 * max|ref| after 10 CFG steps / 2 FIFO iterations
+back in, so the fp16-storage error of the UNet accumulates: tolerance 3e-2 * max|ref| after 10 CFG steps / 2 FIFO iterations
 (observed ~1e-2), still far below what a wrong coefficient, index or mask would produce (O(1))."""
 import types
 
@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 from helpers import REDUCED, inp, relerr, state_dict_for  # noqa: E402
 
-TOL = 6e-2
+TOL = 3e-2
 
 
 @pytest.fixture(scope="module")
