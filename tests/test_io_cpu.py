@@ -114,3 +114,39 @@ def test_load_davis_data_layout(tmp_path):
     assert f2.shape[2] == 8 and abs(float(f2[0, 0, 1].mean()) - ((20 / 255 - 0.5) * 2)) < 0.05    # stride 2 -> frame 2
     with pytest.raises(ValueError):
         load_davis_data("bear", str(tmp_path), sampling_strategy="nope")
+
+
+def test_uncond_embedding_follows_uncond_type():
+    """funcs.py:199-206: `uncond_type == "empty_seq"` (the YAML) is the text encoding of "" -- the caller must supply it; only
+    "zero_embed" is zeros.  A missing uc_emb must not silently become zeros."""
+    from moca_video_amd.fifo import uncond_embedding
+    c = torch.randn(1, 77, 16)
+    uc = torch.randn(1, 77, 16)
+    assert uncond_embedding(types.SimpleNamespace(uncond_type="empty_seq"), c, uc) is uc
+    with pytest.raises(ValueError):
+        uncond_embedding(types.SimpleNamespace(uncond_type="empty_seq"), c, None)
+    z = uncond_embedding(types.SimpleNamespace(uncond_type="zero_embed"), c, None)
+    assert z.shape == c.shape and not z.any()
+    with pytest.raises(NotImplementedError):
+        uncond_embedding(types.SimpleNamespace(uncond_type="other"), c, None)
+
+
+def test_driver_default_unconditional_is_the_empty_prompt():
+    from moca_video_amd.io import _empty_prompt_embedding
+    calls = []
+    embed = lambda s: calls.append(s) or torch.full((1, 77, 4), float(len(s)))
+    m = types.SimpleNamespace(uncond_type="empty_seq")
+    uc = _empty_prompt_embedding(m, embed, None)
+    assert calls == [""] and float(uc.max()) == 0.0
+    given = torch.ones(1, 77, 4)
+    assert _empty_prompt_embedding(m, embed, given) is given and calls == [""]
+    assert _empty_prompt_embedding(types.SimpleNamespace(uncond_type="zero_embed"), embed, None) is None
+
+
+def test_kept_frames_slice_is_the_reference_expression():
+    """videocrafter_main.py:228-230 keeps `video_frames[-args.new_video_length//2:]`: for odd lengths -N//2 floors (-101//2 == -51)"""
+    import inspect
+    from moca_video_amd import io
+    assert "frames[-args.new_video_length // 2:]" in inspect.getsource(io.run_prompts)
+    frames = list(range(148))
+    assert len(frames[-101 // 2:]) == 51 and len(frames[-100 // 2:]) == 50

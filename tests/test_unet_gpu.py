@@ -239,3 +239,21 @@ def test_unet_full_width_vs_reference_golden():
     a = m(xs[0], t16, context=cs[0], fps=fps[:1])
     b = m(xs[0], torch.tensor([500]).cuda(), context=cs[0], fps=fps[:1])
     assert relerr(a.cpu(), b.cpu()) < 1e-6
+
+
+def test_reloading_weights_releases_the_old_graphs(reduced_model):
+    """`load_state_dict` / `.to()` drop the recorded plans: their instantiated hipGraphs must be destroyed and the
+    next forward must re-record and give the same result."""
+    g = golden("unet_reduced")
+    x = inp("reduced.uniform.x", (1, 4, 8, 16, 16)).cuda()
+    ctx = inp("reduced.uniform.ctx", (1, 77, 128)).cuda()
+    t = torch.from_numpy(g["uniform__t"]).cuda()
+    for _ in range(3):
+        y0 = reduced_model(x, t, context=ctx, fps=16)
+    old = list(reduced_model._plans.values())
+    assert old and all(p.graph is not None for p in old)
+    reduced_model.load_state_dict(state_dict_for(reduced_model, 11), strict=True)
+    assert not reduced_model._plans and all(p.graph is None for p in old), "old plans must have released their graphs"
+    for _ in range(3):
+        y1 = reduced_model(x, t, context=ctx, fps=16)
+    assert torch.equal(y0, y1)
