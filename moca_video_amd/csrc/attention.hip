@@ -226,11 +226,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 //   * the reference maximum is lazy (cdna_hip_programming.md T13): it is moved (O, l rescaled) only when a tile maximum
 //     exceeds it by more than THR = 8, i.e. P <= 2^8 in fp16, whose relative precision does not depend on magnitude; the
 //     first tile always sets it;
-//   * the row sums come from the matrix pipe too: l^T += 1^T.P^T, one more MFMA per 16 keys with an all-ones A operand
-//     (every lane ends up with the complete sum of its query: no adds, no final cross-lane exchange);
+//   * the row sums are v_dot2_f32_f16 of the PACKED P against (1, 1): 16 instructions per tile instead of 32 adds (a variant
+//     that takes them from the matrix pipe -- l^T += 1^T.P^T, one more MFMA per 16 keys -- is 5 % slower: the matrix pipe is
+//     the longer pole once the VALU work is cut; -DMOCA_ATTN_SUM_MFMA);
 //   * P is packed with v_cvt_pk_f16_f32 only; LDS fragment addresses are per-lane constants + immediates (key loop
 //     unrolled over the two buffers); the staging pointers advance by one 64-bit add per tile.
-// What is left per element: 0.5 max3 + exp + 0.5 cvt_pk.  Tiles, LDS images and fragment maps are those of attention_kernel.
+// What is left per element: 0.5 max3 + exp + 0.5 cvt_pk + 0.5 dot2.  121 VGPRs: four waves per SIMD.  Tiles, LDS images and fragment maps are those of attention_kernel.
 constexpr float LAZY_THR = 8.0f;
 
 __global__ __launch_bounds__(256, 2) void attention_v4_kernel(
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(256, 2) void attention_v4_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; osum[r] = 0.f; negm[r] = 0.f; }
     float m_ref = 0.f;
+    float lsum = 0.f;          // this lane's share of the row sum (its 32 of the 64 keys of every tile)
     half8v ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (half_t)1.0f;
@@ -323,6 +325,10 @@ __global__ __launch_bounds__(256, 2) void attention_v4_kernel(
     // (row sum + two O tiles), so a group's MFMAs run under the next group's exp2
     auto tile = [&](auto b_tag, f32x16 (&sc)[2], int kt) {
         constexpr int VB = decltype(b_tag)::value;
+#ifndef MOCA_ATTN_NEGM_PERSISTENT   // -m_ref rebuilt per tile (16 v_mov) instead of living across it: 141 -> 121 VGPRs = 4 waves per SIMD, +3.5 %
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
+#endif
         qk(sK + VB * TILE, sc);
         if ((kt + 1) * KT > Nk) {                     // keys beyond Nk (last tile only)
 #pragma unroll
@@ -349,8 +355,11 @@ __global__ __launch_bounds__(256, 2) void attention_v4_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 o[0][r] *= alpha; o[1][r] *= alpha; osum[r] *= alpha;
+                if (r == 0) lsum *= alpha;
                 sc[0][r] -= delta; sc[1][r] -= delta;
+#ifdef MOCA_ATTN_NEGM_PERSISTENT
                 negm[r] = -m_ref;
+#endif
             }
         }
         const char* vbuf = sV + VB * TILE;
@@ -368,7 +377,12 @@ __global__ __launch_bounds__(256, 2) void attention_v4_kernel(
                 const half4v plo = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3);
                 const half4v phi = __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3);
                 const half8v pf = __builtin_shufflevector(plo, phi, 0, 1, 2, 3, 4, 5, 6, 7);
+#ifndef MOCA_ATTN_SUM_MFMA      // row sums by v_dot2_f32_f16 on the packed P (+5 % over a 4th "ones" MFMA per 16 keys, and 16 registers fewer)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lsum = __builtin_amdgcn_fdot2(h[j], half2v{(half_t)1.0f, (half_t)1.0f}, lsum, false);
+#else
                 osum = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, osum, 0, 0, 0);
+#endif
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     const char* a0 = vbuf + v_off[dt] + (sub * 32 + ss * 16) * ROWB;
@@ -401,7 +415,11 @@ __global__ __launch_bounds__(256, 2) void attention_v4_kernel(
         }
     }
 
+#ifndef MOCA_ATTN_SUM_MFMA
+    const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32, 64));
+#else
     const float inv = 1.0f / osum[0];
+#endif
     if (q_ok) {
         half_t* ob = out + ((int64_t)bq * Nq + qrow) * ldo + head * D;
 #pragma unroll
