@@ -1808,15 +1808,21 @@ int launch_gemm_w80(const moca_gemm_params& p, hipStream_t st) {
 // tiles, ring and DMA stream with the roles of A and W swapped (10 A pieces + 20 W pieces per k-tile): a block then owns
 // COMPLETE output rows when N = 320, so A is fetched once instead of once per 160-column tile and the LayerNorm that follows the
 // attention / projection linears of the 320-channel level (attention.py:199-201,216-219) runs in the store loop (MOCA_EP_LN).
-template <int AMODE, bool WIDE>
+// SHAPE 2 ("sq256"): 256 x 256 block tile, waves 4 x 2, wave tile 64 x 128 (4 x 8 MFMA tiles, 32 MFMAs per k-tile) -- the same
+// staggered structure for the wide projections (GEGLU N = 2560 / 5120 / 10240, QKV N = 3840): 7.8 B of L2->LDS traffic per kFLOP
+// against 9.4 for 320 x 160 and 11.7 for 256 x 128; 16 + 16 DMA pieces per k-tile = 4 per wave, no repeats; the ring takes all
+// 160 KiB of LDS.  GEGLU epilogue: a wave's 128 packed columns = two 64-column groups of 32 value + 32 gate columns.
+template <int AMODE, int SHAPE>
 __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_params p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the launch stub; __amdgpu_buffer_rsrc_t is a device-only type)
-    constexpr int MT = 5, NT = 5, KS = 32, RB = 64;
-    constexpr int TM = WIDE ? 160 : 320, BN = WIDE ? 320 : 160;
-    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB;     // 30 KiB per k-tile either way
+    constexpr bool WIDE = SHAPE == 1, SQ = SHAPE == 2;
+    constexpr int MT = SQ ? 4 : 5, NT = SQ ? 8 : 5, KS = 32, RB = 64;
+    constexpr int WTM = 16 * MT, WTN = 16 * NT;          // wave tile: 80 x 80, or 64 x 128
+    constexpr int TM = SQ ? 256 : (WIDE ? 160 : 320), BN = SQ ? 256 : (WIDE ? 320 : 160);
+    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB;     // 30 KiB per k-tile (32 KiB for 256 x 256)
     constexpr int NS = 5;
-    constexpr int PPW = 4;                               // DMA instructions per wave per k-tile (30 pieces + 2 repeats)
-    constexpr int NAP = WIDE ? 2 : 3;
+    constexpr int PPW = 4;                               // DMA instructions per wave per k-tile (30 pieces + 2 repeats; 32 pieces)
+    constexpr int NAP = SQ ? 2 : (WIDE ? 2 : 3);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1851,7 +1857,13 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     BGather<AMODE, NAP, KS> ga(p, lch, kt_begin, kt_last_pair);
     const int small1 = wave < 6 ? 4 + wave : 2 + wave;    // j = 3
     unsigned w_off[3];
-    if constexpr (!WIDE) {
+    if constexpr (SQ) {                                  // A pieces w and 8 + w, W pieces w and 8 + w
+        ga.init_row(0, m0 + wave * 16 + lrow);
+        ga.init_row(1, m0 + (8 + wave) * 16 + lrow);
+        w_off[0] = (unsigned)(((int64_t)(n0 + wave * 16 + lrow) * p.ldw + lch * 8) * 2);
+        w_off[1] = (unsigned)(((int64_t)(n0 + (8 + wave) * 16 + lrow) * p.ldw + lch * 8) * 2);
+        w_off[2] = 0;
+    } else if constexpr (!WIDE) {
 #pragma unroll
         for (int g = 0; g < NAP; ++g) ga.init_row(g, m0 + (g < 2 ? g * 8 + wave : 16 + (wave & 3)) * 16 + lrow);
         w_off[0] = (unsigned)(((int64_t)(n0 + (wave & 3) * 16 + lrow) * p.ldw + lch * 8) * 2);      // j = 2 (waves 4..7)
@@ -1872,7 +1884,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         constexpr int odd = decltype(odd_tag)::value;
         const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
         const unsigned a_s = ga.a_soff() + odd * KS * 2, w_s = ga.w_soff() + odd * KS * 2;
-        if constexpr (!WIDE) {
+        if constexpr (SQ) {
+            if (j < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, sa + (j * 8 + wave) * 1024, 16, ga.a_off[j], a_s, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, sa + A_BYTES + ((j - 2) * 8 + wave) * 1024, 16, w_off[j - 2], w_s, 0, 0);
+        } else if constexpr (!WIDE) {
             if (j < 2) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, sa + (j * 8 + wave) * 1024, 16, ga.a_off[j], a_s, 0, 0);
             } else if (j == 2) {
@@ -1905,14 +1920,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && p.splits == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + wave_n * 80 + nt * 16 + 4 * fg);
+        if (p.bias && p.splits == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + wave_n * WTN + nt * 16 + 4 * fg);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
     }
 
     const int swz = (fg ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
-    const int a_off0 = (wave_m * 80 + fr) * RB + swz;
-    const int b_off0 = A_BYTES + (wave_n * 80 + fr) * RB + swz;
+    const int a_off0 = (wave_m * WTM + fr) * RB + swz;
+    const int b_off0 = A_BYTES + (wave_n * WTN + fr) * RB + swz;
 
     half8v af[2][MT], bf[2][NT];
     auto read_tile = [&](auto set_tag, int slot) {
@@ -2007,29 +2022,53 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         float* ws = p.splitk_ws + (int64_t)split * p.M * p.N;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int row = m0 + wave_m * 80 + mt * 16 + fr;
+            const int row = m0 + wave_m * WTM + mt * 16 + fr;
             if (row < p.M) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int col = n0 + wave_n * 80 + nt * 16 + 4 * fg;
+                    const int col = n0 + wave_n * WTN + nt * 16 + 4 * fg;
                     *reinterpret_cast<f32x4*>(ws + (int64_t)row * p.N + col) = acc[mt][nt];
                 }
             }
         }
         return;
     }
+    if constexpr (SQ) {
+        if (p.flags & MOCA_EP_GEGLU) {                   // per 64-column group: value tiles +0, +1 and their gate tiles +2, +3 (bias is in the accumulators)
+            constexpr int gpitch = (BN / 2) * 2 + 16;
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int row = wave_m * WTM + mt * 16 + fr;
+                        const f32x4 va = acc[mt][4 * grp + nt], gt = acc[mt][4 * grp + nt + 2];
+                        const f32x2 lo = moca_geglu2(f32x2{va[0], va[1]}, f32x2{gt[0], gt[1]});
+                        const f32x2 hi = moca_geglu2(f32x2{va[2], va[3]}, f32x2{gt[2], gt[3]});
+                        half4v h;
+                        h[0] = (half_t)lo[0]; h[1] = (half_t)lo[1]; h[2] = (half_t)hi[0]; h[3] = (half_t)hi[1];
+                        *reinterpret_cast<half4v*>(smem + row * gpitch + (wave_n * 64 + grp * 32 + nt * 16 + 4 * fg) * 2) = h;
+                    }
+            __syncthreads();
+            store_fp16_tile<512>(p, smem, gpitch, TM, BN / 2, m0, n0 / 2, tid);
+            return;
+        }
+    }
     constexpr int pitch = BN * 2 + 16;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int col = wave_n * 80 + nt * 16 + 4 * fg;
+        const int col = wave_n * WTN + nt * 16 + 4 * fg;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int row = wave_m * 80 + mt * 16 + fr;
+            const int row = wave_m * WTM + mt * 16 + fr;
             *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = __builtin_convertvector(acc[mt][nt], half4v);
         }
     }
     __syncthreads();
-    if constexpr (WIDE) {
+    if constexpr (SQ) {
+        store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
+    } else if constexpr (WIDE) {
         if (p.flags & MOCA_EP_LN) store_fp16_tile_ln(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, tid);
         else if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
         else store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
@@ -2040,18 +2079,19 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
 #endif
 }
 
-template <int AMODE, bool WIDE>
+template <int AMODE, int SHAPE>
 int launch_gemm_w80s(const moca_gemm_params& p, hipStream_t st) {
-    const int tiles_m = WIDE ? (p.M + 159) / 160 : (p.M + 319) / 320, tiles_n = WIDE ? p.N / 320 : p.N / 160;
+    constexpr int TM = SHAPE == 2 ? 256 : (SHAPE == 1 ? 160 : 320), BN = SHAPE == 2 ? 256 : (SHAPE == 1 ? 320 : 160);
+    const int tiles_m = (p.M + TM - 1) / TM, tiles_n = p.N / BN;
     const int nblk = tiles_m * tiles_n * p.splits;
-    constexpr int lds = 5 * (320 + 160) * 64;
+    constexpr int lds = 5 * (TM + BN) * 64;              // 150 KiB (160 KiB for 256 x 256); the fp16 epilogue tile fits inside the ring
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w80s_kernel<AMODE, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w80s_kernel<AMODE, SHAPE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MOCA_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_w80s_kernel<AMODE, WIDE>), dim3(nblk), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_w80s_kernel<AMODE, SHAPE>), dim3(nblk), dim3(512), lds, st, p);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
@@ -2082,6 +2122,10 @@ static inline bool buffer_addressable(const moca_gemm_params& p) {
     return a_span_bytes(p) < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
 }
 
+static inline int sq256_mode() {
+    const char* e = getenv("MOCA_GEMM_SQ256");
+    return e ? atoi(e) : 1;
+}
 static inline int w80_variant() {                     // A/B runs: 0 = flat-address w80, 1 = buffer-addressed w80b, 2 (default) = staggered w80s
     const char* e_buf = getenv("MOCA_GEMM_BUF");
     return e_buf ? atoi(e_buf) : 2;
@@ -2120,9 +2164,9 @@ int launch_gemm_w80_mode(const moca_gemm_params& p, bool fastp, hipStream_t st) 
     const int buf_mode = w80_variant();
     if (fastp && buf_mode == 2 && buffer_addressable(p)) {
         const bool wide = w80s_wide(p);
-        if (p.a_mode == MOCA_A_LINEAR) return wide ? launch_gemm_w80s<MOCA_A_LINEAR, true>(p, st) : launch_gemm_w80s<MOCA_A_LINEAR, false>(p, st);
-        if (p.a_mode == MOCA_A_CONV3X3) return wide ? launch_gemm_w80s<MOCA_A_CONV3X3, true>(p, st) : launch_gemm_w80s<MOCA_A_CONV3X3, false>(p, st);
-        return wide ? launch_gemm_w80s<MOCA_A_TCONV3, true>(p, st) : launch_gemm_w80s<MOCA_A_TCONV3, false>(p, st);
+        if (p.a_mode == MOCA_A_LINEAR) return wide ? launch_gemm_w80s<MOCA_A_LINEAR, 1>(p, st) : launch_gemm_w80s<MOCA_A_LINEAR, 0>(p, st);
+        if (p.a_mode == MOCA_A_CONV3X3) return wide ? launch_gemm_w80s<MOCA_A_CONV3X3, 1>(p, st) : launch_gemm_w80s<MOCA_A_CONV3X3, 0>(p, st);
+        return wide ? launch_gemm_w80s<MOCA_A_TCONV3, 1>(p, st) : launch_gemm_w80s<MOCA_A_TCONV3, 0>(p, st);
     }
     if (fastp && buf_mode == 1 && buffer_addressable(p)) {
         if (p.a_mode == MOCA_A_LINEAR) return launch_gemm_w80b<MOCA_A_LINEAR>(p, st);
@@ -2273,6 +2317,12 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     if ((p.flags & MOCA_EP_LN) && !(p.ln_gamma && p.ln_beta && p.ln_out && p.ld_ln % 8 == 0 && takes_w80t_ln(p))) return MOCA_E_BADARG;   // ask moca_gemm_ln_ok() first
     if (use_w80) {
         rc = launch_gemm_w80_mode(p, fastp, st);
+    } else if (sq256_mode() && p.a_mode == MOCA_A_LINEAR && p.N % 256 == 0 && p.N >= 2560 && p.M >= 512 && fastp && buffer_addressable(p) &&
+               !(p.flags & (MOCA_EP_OUT_F32 | MOCA_FORCE_SMALL_TILE)) && ((p.M + 255) / 256) * (p.N / 256) * p.splits >= 200 &&
+               (sq256_mode() == 2 || !use_g4)) {
+        // the staggered kernel on 256 x 256 tiles for the wide projections (MOCA_GEMM_SQ256 = 0: never, 1: not where g4 is preferred,
+        // 2: every wide linear -- A/B runs)
+        rc = launch_gemm_w80s<MOCA_A_LINEAR, 2>(p, st);
     } else if (use_big && big_bn == 128 && use_g4) {
         if (p.a_mode == MOCA_A_LINEAR) rc = fastp ? launch_gemm_g4<MOCA_A_LINEAR, true>(p, st) : launch_gemm_g4<MOCA_A_LINEAR, false>(p, st);
         else if (p.a_mode == MOCA_A_CONV3X3) rc = fastp ? launch_gemm_g4<MOCA_A_CONV3X3, true>(p, st) : launch_gemm_g4<MOCA_A_CONV3X3, false>(p, st);

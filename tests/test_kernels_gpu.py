@@ -413,3 +413,28 @@ def test_gemm_gelu_epilogue_and_token_embedding():
     emb = torch.empty(14, 64, dtype=torch.float16, device=DEV)
     ops.embed_tokens(tok, table, pos, emb, n_tokens=14, L=7, Cn=64, vocab=50)
     check(emb, table[tok] + pos.repeat(2, 1), 1e-3, "token embedding")
+
+
+# ---------------------------------------------------------------- GEMM: the 256 x 256 tiling of the wide projections
+@pytest.mark.parametrize("M,K,N,geglu,with_res", [(5000, 640, 2560, True, False), (4500, 1280, 3072, False, True),
+                                                  (5120, 384, 5120, True, False), (4100, 1280, 3072, False, False)])
+def test_gemm_sq256(M, K, N, geglu, with_res, monkeypatch):
+    """MOCA_GEMM_SQ256=2 sends every wide linear (N >= 2560, >= 200 tiles) to the 256 x 256 staggered kernel: M tails, an odd
+    number of 64-deep k-tiles, the GEGLU and the residual store loops."""
+    monkeypatch.setenv("MOCA_GEMM_SQ256", "2")
+    a = rnd(M, K)
+    w = rnd(N, K, scale=K ** -0.5)
+    b = rnd(N, dtype=torch.float32, scale=0.1)
+    y = a.float() @ w.float().t() + b
+    if geglu:
+        pw = ops.pack_geglu(w, b)
+        out = torch.empty(M, N // 2, dtype=torch.float16, device=DEV)
+        ops.gemm(a, pw, out, M=M)
+        ref = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+    else:
+        pw = ops.pack_linear(w, b)
+        res = rnd(M, N) if with_res else None
+        out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        ops.gemm(a, pw, out, M=M, residual=res)
+        ref = y + res.float() if with_res else y
+    check(out, ref, TOL16, f"sq256 {M}x{N}x{K} geglu={geglu}")
