@@ -92,9 +92,9 @@ typedef struct moca_gemm_params {
  * (openaimodel3d.py:228,276; attention.py:217-219,278,373) / GEGLU
  * (attention.py:381-383) folded into the epilogue.                              */
 int moca_gemm_f16(const moca_gemm_params* p, void* stream);
-/* Rows per row tile of the MOCA_EP_COLSUM output for this call (320), or 0 when this call cannot produce column sums
- * (it would not run on the 320-row direct-to-LDS kernel: N % 160, split-K, GEGLU, fp32 output, slow gather ...).
- * The GroupNorm that consumes the sums (moca_groupnorm_colsum_f16) needs H*W % rows == 0.                            */
+/* Rows per row tile of the MOCA_EP_COLSUM output for this call (320 / 160 on the staggered kernel, 256 on the 256-row
+ * direct-to-LDS kernel), or 0 when this call cannot produce column sums (split-K, GEGLU, fp32 output, small tiles ...).
+ * The GroupNorm that consumes the sums (moca_groupnorm_colsum_f16) needs (frames_per_stat * H*W) % rows == 0.        */
 int moca_gemm_colsum_rows(const moca_gemm_params* p);
 /* 1 when this call can also produce the LayerNorm of its output rows (MOCA_EP_LN): a plain linear with N == 320 (a block of
  * the 160 x 320 tiling owns complete rows), fast gather, no split-K, enough rows to fill the chip; else 0.               */
@@ -114,7 +114,8 @@ int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma, const fl
                             float eps, int32_t silu, float* ws, void* stream);
 int64_t moca_groupnorm_ws_bytes(int32_t F, int32_t HW, int32_t C);
 /* The same GroupNorm when the producer of x was a moca_gemm_f16 call with MOCA_EP_COLSUM: the statistics pass over x
- * is replaced by a reduction of colsum [F*HW/tile_rows][C][2] (HW % tile_rows == 0); two launches (finalize, apply)
+ * is replaced by a reduction of colsum [F*HW/tile_rows][C][2] (no row tile may straddle two statistics groups:
+ * (frames_per_stat * HW) % tile_rows == 0); two launches (finalize, apply)
  * instead of three and x is read once.  ws as above.                                                                */
 int moca_groupnorm_colsum_f16(const void* x, void* y, const float* gamma, const float* beta, const float* colsum,
                               int32_t tile_rows, int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,

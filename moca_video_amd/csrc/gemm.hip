@@ -1075,7 +1075,10 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     __syncthreads();
     MOCA_STAMP(4);
 
-    store_fp16_tile<512>(p, smem, pitch, TM, out_bn, m0, on0, tid);
+    // (MOCA_EP_COLSUM is only accepted without GEGLU / split-k: out_bn == BN; 256 x 272 B or 256 x 336 B of staged rows + the
+    //  32 x BN x 2 / 25 x BN x 2 floats of row-subset sums fit inside the 144 / 156 KiB ring)
+    if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * (BN * 2 + 16)), pitch, m0, n0, tile_m, tid);
+    else store_fp16_tile<512>(p, smem, pitch, TM, out_bn, m0, on0, tid);
     MOCA_STAMP(5);
 #ifdef MOCA_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {
@@ -2126,6 +2129,16 @@ static inline int sq256_mode() {
     const char* e = getenv("MOCA_GEMM_SQ256");
     return e ? atoi(e) : 1;
 }
+static inline bool fast_gather(const moca_gemm_params& p);
+static inline bool buffer_addressable(const moca_gemm_params& p);
+// the staggered kernel on 256 x 256 tiles for the wide projections (MOCA_GEMM_SQ256 = 0: never, 1: not where g4 is preferred,
+// 2: every wide linear -- A/B runs); asked after takes_w80()
+static inline bool takes_sq256(const moca_gemm_params& p, bool use_g4) {
+    const int mode = sq256_mode();
+    return mode && p.a_mode == MOCA_A_LINEAR && p.N % 256 == 0 && p.N >= 2560 && p.M >= 512 && fast_gather(p) && buffer_addressable(p) &&
+           !(p.flags & (MOCA_EP_OUT_F32 | MOCA_FORCE_SMALL_TILE)) && ((p.M + 255) / 256) * (p.N / 256) * p.splits >= 200 &&
+           (mode == 2 || !use_g4);
+}
 static inline int w80_variant() {                     // A/B runs: 0 = flat-address w80, 1 = buffer-addressed w80b, 2 (default) = staggered w80s
     const char* e_buf = getenv("MOCA_GEMM_BUF");
     return e_buf ? atoi(e_buf) : 2;
@@ -2244,12 +2257,36 @@ static void normalise_splits(moca_gemm_params& p) {
     }
 }
 
+// does this (validated, split-normalised) call run on the 256-row direct-to-LDS kernel (gemm_glds_kernel), and with which BN?
+// (mirrors the dispatch order of moca_gemm_f16: w80 family first, then sq256, then g4, then glds)
+static int takes_glds_bn(const moca_gemm_params& p) {
+    if (takes_w80(p)) return 0;
+    const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
+    if (!(big_bn != 0 && p.M > 128 && !(p.flags & MOCA_FORCE_SMALL_TILE))) return 0;
+    const char* e_g4 = getenv("MOCA_GEMM_G4");
+    const int g4_mode = e_g4 ? atoi(e_g4) : 1;
+    const bool use_g4 = !(p.flags & MOCA_EP_OUT_F32) && (g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640));
+    if (takes_sq256(p, use_g4)) return 0;
+    if (big_bn == 128 && use_g4) return 0;
+    return big_bn;
+}
+// rows per tile of the column sums a MOCA_EP_COLSUM launch leaves behind (0: this call cannot): 320 / 160 on the staggered kernel,
+// 256 on the 256-row kernel (fp16 output, no GEGLU, no split-k)
+static int colsum_rows(const moca_gemm_params& p) {
+    if (p.splits != 1) return 0;
+    if (takes_w80s(p)) return w80s_wide(p) ? 160 : 320;
+    const char* e = getenv("MOCA_GN_COLSUM_GLDS");       // A/B runs: 0 = only the staggered kernel leaves column sums
+    if (e && atoi(e) == 0) return 0;
+    if (!(p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32)) && takes_glds_bn(p) != 0) return 256;
+    return 0;
+}
+
 extern "C" int moca_gemm_colsum_rows(const moca_gemm_params* pp) {
     if (!pp) return 0;
     moca_gemm_params p = *pp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
     normalise_splits(p);
-    return (p.splits == 1 && takes_w80s(p)) ? (w80s_wide(p) ? 160 : 320) : 0;
+    return colsum_rows(p);
 }
 
 extern "C" int moca_gemm_ln_ok(const moca_gemm_params* pp) {
@@ -2313,15 +2350,11 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     // w80 (320 x 160 tiles, 80 x 80 wave tiles): every non-GEGLU contraction whose N is a multiple of 160 and whose
     // 320-row tiles fill the chip.  MOCA_GEMM_W80=0 disables it (A/B against the 256-row kernel), 2 drops the tile-count rule.
     const bool use_w80 = takes_w80(p);
-    if ((p.flags & MOCA_EP_COLSUM) && !(p.colsum && p.splits == 1 && takes_w80s(p))) return MOCA_E_BADARG;   // ask moca_gemm_colsum_rows() first
+    if ((p.flags & MOCA_EP_COLSUM) && !(p.colsum && colsum_rows(p) != 0)) return MOCA_E_BADARG;   // ask moca_gemm_colsum_rows() first
     if ((p.flags & MOCA_EP_LN) && !(p.ln_gamma && p.ln_beta && p.ln_out && p.ld_ln % 8 == 0 && takes_w80t_ln(p))) return MOCA_E_BADARG;   // ask moca_gemm_ln_ok() first
     if (use_w80) {
         rc = launch_gemm_w80_mode(p, fastp, st);
-    } else if (sq256_mode() && p.a_mode == MOCA_A_LINEAR && p.N % 256 == 0 && p.N >= 2560 && p.M >= 512 && fastp && buffer_addressable(p) &&
-               !(p.flags & (MOCA_EP_OUT_F32 | MOCA_FORCE_SMALL_TILE)) && ((p.M + 255) / 256) * (p.N / 256) * p.splits >= 200 &&
-               (sq256_mode() == 2 || !use_g4)) {
-        // the staggered kernel on 256 x 256 tiles for the wide projections (MOCA_GEMM_SQ256 = 0: never, 1: not where g4 is preferred,
-        // 2: every wide linear -- A/B runs)
+    } else if (takes_sq256(p, use_g4)) {
         rc = launch_gemm_w80s<MOCA_A_LINEAR, 2>(p, st);
     } else if (use_big && big_bn == 128 && use_g4) {
         if (p.a_mode == MOCA_A_LINEAR) rc = fastp ? launch_gemm_g4<MOCA_A_LINEAR, true>(p, st) : launch_gemm_g4<MOCA_A_LINEAR, false>(p, st);

@@ -63,52 +63,67 @@ __global__ void gn_partial_kernel(const half_t* __restrict__ x, float* __restric
 }
 
 // ---- K2: finalize mean / rstd per (stat group, channel group) in fp64 --------
-// one wavefront per (stat group, channel group): grid (stat groups, 32)
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ meanrstd,
-                                                         int frames_per_stat, int nchunk, double inv_count, float eps) {
+// one block of FIN_T threads per (stat group, channel group): grid (stat groups, 32).  Up to 1280 partial pairs per block at
+// the 320-channel level with 16 frames per statistics group: every thread issues all its loads before the first add (a
+// one-wavefront loop of dependent L2 round trips took ~10 us there), fp64 accumulation, fixed combine order (deterministic).
+constexpr int FIN_T = 256;
+
+__device__ __forceinline__ void gn_finalize_store(double a, double b, float* __restrict__ meanrstd, int64_t slot, double inv_count, float eps) {
+    __shared__ double s_a[FIN_T / 64], s_b[FIN_T / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int w = 0; w < FIN_T / 64; ++w) { sa += s_a[w]; sb += s_b[w]; }
+        const double mean = sa * inv_count;
+        double var = sb * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        meanrstd[slot * 2] = (float)mean;
+        meanrstd[slot * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+__global__ __launch_bounds__(FIN_T) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ meanrstd,
+                                                            int frames_per_stat, int nchunk, double inv_count, float eps) {
     const int sg = blockIdx.x, g = blockIdx.y, l = threadIdx.x;
     const int n = frames_per_stat * nchunk;
     const float* base = partial + (int64_t)sg * n * GN_GROUPS * 2;
     double a = 0.0, b = 0.0;
-    for (int i = l; i < n; i += 64) {
-        const float2 v = *reinterpret_cast<const float2*>(base + ((int64_t)i * GN_GROUPS + g) * 2);
-        a += (double)v.x;
-        b += (double)v.y;
-    }
+    for (int i0 = l; i0 < n; i0 += 4 * FIN_T) {
+        float2 v[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-    if (l == 0) {
-        const double mean = a * inv_count;
-        double var = b * inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        meanrstd[((int64_t)sg * GN_GROUPS + g) * 2] = (float)mean;
-        meanrstd[((int64_t)sg * GN_GROUPS + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * FIN_T;
+            v[u] = i < n ? *reinterpret_cast<const float2*>(base + ((int64_t)i * GN_GROUPS + g) * 2) : float2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a += (double)v[u].x; b += (double)v[u].y; }
     }
+    gn_finalize_store(a, b, meanrstd, (int64_t)sg * GN_GROUPS + g, inv_count, eps);
 }
 
 // ---- K2': the same from the column sums a MOCA_EP_COLSUM GEMM left behind: colsum[row tile][C][2], a statistics group
-// (sg, g) = tiles [sg*tps, (sg+1)*tps) x channels [g*cpg, (g+1)*cpg); one wavefront per (sg, g), fp64 accumulation in a
-// fixed order ----
-__global__ __launch_bounds__(64) void gn_finalize_colsum_kernel(const float* __restrict__ colsum, float* __restrict__ meanrstd,
-                                                                int tps, int C, int cpg, double inv_count, float eps) {
+// (sg, g) = tiles [sg*tps, (sg+1)*tps) x channels [g*cpg, (g+1)*cpg) ----
+__global__ __launch_bounds__(FIN_T) void gn_finalize_colsum_kernel(const float* __restrict__ colsum, float* __restrict__ meanrstd,
+                                                                   int tps, int C, int cpg, double inv_count, float eps) {
     const int sg = blockIdx.x, g = blockIdx.y, l = threadIdx.x;
     const int n = tps * cpg;
     double a = 0.0, b = 0.0;
-    for (int i = l; i < n; i += 64) {
-        const int t = i / cpg, c = g * cpg + (i - t * cpg);
-        const float2 v = *reinterpret_cast<const float2*>(colsum + (((int64_t)sg * tps + t) * C + c) * 2);
-        a += (double)v.x;
-        b += (double)v.y;
-    }
+    for (int i0 = l; i0 < n; i0 += 4 * FIN_T) {
+        float2 v[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-    if (l == 0) {
-        const double mean = a * inv_count;
-        double var = b * inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        meanrstd[((int64_t)sg * GN_GROUPS + g) * 2] = (float)mean;
-        meanrstd[((int64_t)sg * GN_GROUPS + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * FIN_T;
+            const int t = i / cpg, c = g * cpg + (i - t * cpg);
+            v[u] = i < n ? *reinterpret_cast<const float2*>(colsum + (((int64_t)sg * tps + t) * C + c) * 2) : float2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a += (double)v[u].x; b += (double)v[u].y; }
     }
+    gn_finalize_store(a, b, meanrstd, (int64_t)sg * GN_GROUPS + g, inv_count, eps);
 }
 
 // ---- K3: apply (x - mean) * rstd * gamma + beta, optional SiLU ----------------
@@ -357,7 +372,7 @@ extern "C" int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamm
     const size_t lds = (size_t)ppb * C * 2 * sizeof(float);
     hipLaunchKernelGGL(gn_partial_kernel, grid, block, lds, st, reinterpret_cast<const half_t*>(x), partial, HW, C, nchunk);
     MOCA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(F / frames_per_stat, GN_GROUPS), dim3(64), 0, st, partial, meanrstd,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(F / frames_per_stat, GN_GROUPS), dim3(FIN_T), 0, st, partial, meanrstd,
                        frames_per_stat, nchunk, inv_count, eps);
     MOCA_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, reinterpret_cast<const half_t*>(x), reinterpret_cast<half_t*>(y),
@@ -371,7 +386,7 @@ extern "C" int moca_groupnorm_colsum_f16(const void* x, void* y, const float* ga
                                          float eps, int32_t silu, float* ws, void* stream) {
     if (!x || !y || !gamma || !beta || !ws || !colsum) return MOCA_E_BADARG;
     if (F <= 0 || HW <= 0 || C <= 0 || C % 8 || C % GN_GROUPS || frames_per_stat <= 0 || F % frames_per_stat) return MOCA_E_BADARG;
-    if (tile_rows <= 0 || HW % tile_rows) return MOCA_E_BADARG;         // a row tile must not straddle two frames
+    if (tile_rows <= 0 || ((int64_t)frames_per_stat * HW) % tile_rows) return MOCA_E_BADARG;   // a row tile must not straddle two statistics groups
     const int nch8 = C / 8;
     if (nch8 > 1024) return MOCA_E_BADARG;
     int ppb = 256 / nch8;
@@ -380,8 +395,8 @@ extern "C" int moca_groupnorm_colsum_f16(const void* x, void* y, const float* ga
     float* meanrstd = ws + (int64_t)F * nchunk * GN_GROUPS * 2;         // same workspace layout as the three-launch path
     hipStream_t st = moca_stream(stream);
     const double inv_count = 1.0 / ((double)frames_per_stat * HW * (C / GN_GROUPS));
-    const int tps = frames_per_stat * (HW / tile_rows);                   // row tiles per statistics group
-    hipLaunchKernelGGL(gn_finalize_colsum_kernel, dim3(F / frames_per_stat, GN_GROUPS), dim3(64), 0, st, colsum, meanrstd,
+    const int tps = (int)(((int64_t)frames_per_stat * HW) / tile_rows);   // row tiles per statistics group
+    hipLaunchKernelGGL(gn_finalize_colsum_kernel, dim3(F / frames_per_stat, GN_GROUPS), dim3(FIN_T), 0, st, colsum, meanrstd,
                        tps, C, C / GN_GROUPS, inv_count, eps);
     MOCA_CHECK_LAUNCH();
     const dim3 grid(F, nchunk), block(nch8, ppb);

@@ -138,7 +138,7 @@ class _PlanBase:
         HW = fm.H * fm.W
         ws = self.pool.get(1, ops.groupnorm_ws_floats(fm.F, HW, fm.C), torch.float32)
         cs = fm.colsum
-        if cs is not None and HW % cs[1] == 0:
+        if cs is not None and (fps * HW) % cs[1] == 0:      # no row tile straddles two statistics groups
             self._emit(ops.groupnorm_colsum, fm.buf, y, gb[0], gb[1], cs[0], tile_rows=cs[1], F=fm.F, HW=HW, Cn=fm.C,
                        frames_per_stat=fps, eps=eps, silu=silu, ws=ws)
         else:

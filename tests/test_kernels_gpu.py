@@ -152,7 +152,10 @@ def test_groupnorm(Fr, HW, C, fps, silu, eps, path, monkeypatch):
 
 
 @pytest.mark.parametrize("mode,Fr,HW,C,N,fps,with_res", [("tconv", 32, 1280, 320, 320, 16, True), ("conv", 8, 2560, 64, 640, 1, False),
-                                                            ("linear", 16, 1280, 320, 640, 8, True)])
+                                                            ("linear", 16, 1280, 320, 640, 8, True),
+                                                            ("tconv", 32, 160, 1280, 1280, 16, True),      # 256-row kernel (BN 128)
+                                                            ("linear", 32, 160, 1280, 1280, 16, False),
+                                                            ("conv", 16, 160, 128, 320, 8, True)])         # 256-row kernel (BN 160)
 def test_gemm_colsum_feeds_groupnorm(mode, Fr, HW, C, N, fps, with_res):
     """MOCA_EP_COLSUM: the 320-row GEMM leaves per-(row tile, column) sums / sums of squares of what it stores; the GroupNorm
     that consumes them (finalize-from-column-sums + apply) must equal GroupNorm of the stored tensor (ref: torch)."""
@@ -164,7 +167,7 @@ def test_gemm_colsum_feeds_groupnorm(mode, Fr, HW, C, N, fps, with_res):
         pw, kw = ops.pack_linear(w, b), {}
         ref = a.float() @ w.float().t() + b
     elif mode == "conv":
-        H, W = 40, HW // 40
+        H, W = (40, HW // 40) if HW % 40 == 0 and HW >= 1600 else (10, HW // 10)
         x = rnd(Fr, C, H, W)
         w = rnd(N, C, 3, 3, scale=(9 * C) ** -0.5)
         pw = ops.pack_conv3x3(w, b)
@@ -182,7 +185,8 @@ def test_gemm_colsum_feeds_groupnorm(mode, Fr, HW, C, N, fps, with_res):
     if res is not None:
         ref = ref + res.float()
     rows = ops.gemm_colsum_rows(a, pw, M=M, residual=res, **kw)
-    assert rows in (160, 320) and M % rows == 0, "this shape is expected on the 320 x 160 / 160 x 320 kernel"
+    assert rows in (160, 256, 320) and M % rows == 0, "this shape is expected on the 320 x 160 / 160 x 320 / 256-row kernel"
+    assert (rows == 256) == (HW == 160)
     out = torch.empty(M, N, dtype=torch.float16, device=DEV)
     cs = torch.full((M // rows, 2 * N), float("nan"), dtype=torch.float32, device=DEV)
     ops.gemm(a, pw, out, M=M, residual=res, colsum=cs, **kw)
