@@ -111,7 +111,8 @@ def pack_geglu(weight, bias, device="cuda"):
 # kernel wrappers
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
-                 residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None):
+                 residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None,
+                 force_small=False):
     p = _l.GemmParams()
     p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), (out.data_ptr() if out is not None else None)
     p.bias = pw.bias.data_ptr() if pw.bias is not None else None
@@ -132,7 +133,8 @@ def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR
     if tconv is not None:
         p.C, p.T, p.HW = tconv
     p.flags = (_l.MOCA_EP_GEGLU if pw.geglu else 0) | (_l.MOCA_EP_OUT_F32 if out_f32 else 0) | \
-              ((_l.MOCA_EP_GELU | _l.MOCA_FORCE_SMALL_TILE) if gelu else 0) | (_l.MOCA_EP_COLSUM if colsum is not None else 0)
+              ((_l.MOCA_EP_GELU | _l.MOCA_FORCE_SMALL_TILE) if gelu else 0) | (_l.MOCA_EP_COLSUM if colsum is not None else 0) | \
+              (_l.MOCA_FORCE_SMALL_TILE if force_small else 0)
     p.colsum = colsum.data_ptr() if colsum is not None else None
     if ln is not None:                       # (gamma f32 [N], beta f32 [N], ln_out fp16 [M][ld] or None when only probing, eps)
         p.flags |= _l.MOCA_EP_LN

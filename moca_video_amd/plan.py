@@ -42,7 +42,16 @@ def gemm_splits(M, pw):
         tiles = ((M + tm - 1) // tm) * (pw.N // bn)
     if tiles >= (N_CU * 3) // 4:
         return 1
-    return max(1, min(N_CU // tiles, nk // 8))
+    cap = N_CU // tiles
+    if tiles >= 40:
+        # measured at M = N = 1280 (50 tiles, tools/bench_l3.py): K = 1280 runs 17.9 us unsplit against 22-25 us with any split
+        # (the slabs and the reduce launch cost more than the idle CUs); K = 2560..5120 is best at 4 splits (one round of 200
+        # blocks, 20 % less slab traffic than 5); only the 3x3 convs (K >= 11520) want every CU
+        if nk <= 24:
+            return 1
+        if nk <= 100:
+            return max(1, min(cap, 4))
+    return max(1, min(cap, nk // 8))
 
 
 class _PlanBase:
