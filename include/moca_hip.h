@@ -49,6 +49,17 @@ extern "C" {
                            /* proj_in / to_out linears): only where moca_gemm_ln_ok() != 0   */
 #define MOCA_EP_GELU    8  /* out = gelu(acc + bias) (exact erf GELU; 128-row kernel only:   */
                            /* M <= 128 or MOCA_FORCE_SMALL_TILE, splits = 1)                  */
+#define MOCA_EP_ROWSUM 64  /* also write per-(column tile, row) sums and sums of squares of   */
+                           /* the stored (fp16-rounded) values to p.rowsum: the LayerNorm     */
+                           /* statistics of the consumer (attention.py:199-201); only where   */
+                           /* moca_gemm_rowsum_cols() > 0                                     */
+#define MOCA_EP_LNFOLD 128 /* the A operand is x, the linear wanted is Linear(LayerNorm(x)):  */
+                           /* W is packed as W' = W * diag(ln weight), bias as b + W.ln_bias, */
+                           /* p.lnf_wsum[n] = sum_k W'[n][k]; the epilogue computes           */
+                           /* rstd[m] * (acc[m][n] - mean[m] * wsum[n]) + bias[n] with the    */
+                           /* row statistics from p.lnf_part (what a MOCA_EP_ROWSUM producer  */
+                           /* left behind): LayerNorm never touches memory                    */
+                           /* (attention.py:216-220); only where moca_gemm_lnfold_ok() != 0   */
 
 typedef struct moca_gemm_params {
     const void* a;         /* fp16 activations (gather source)                              */
@@ -82,7 +93,13 @@ typedef struct moca_gemm_params {
     const float* ln_beta;
     void*       ln_out;    /* MOCA_EP_LN: fp16 [M][ld_ln] second output                                                */
     int32_t     ld_ln;
-    float       ln_eps;
+    float       ln_eps;    /* MOCA_EP_LN / MOCA_EP_LNFOLD: LayerNorm eps                                               */
+    float*      rowsum;    /* MOCA_EP_ROWSUM (out): f32 [N / cols][M][2] = (sum, sum of squares) over the columns of each
+                              column tile (cols = moca_gemm_rowsum_cols()), of the values as stored                     */
+    const float* lnf_part; /* MOCA_EP_LNFOLD (in): f32 [lnf_nparts][M][2] row partial sums of the A operand (K columns) */
+    const float* lnf_wsum; /* MOCA_EP_LNFOLD: f32 [N], sum over k of the packed fp16 W'[n][k]                           */
+    int32_t     lnf_nparts;
+    int32_t     reserved2_;
 } moca_gemm_params;
 
 /* Replaces F.conv2d 3x3 (openaimodel3d.py:152,177,66-70,96-106,376,531),
@@ -99,6 +116,12 @@ int moca_gemm_colsum_rows(const moca_gemm_params* p);
 /* 1 when this call can also produce the LayerNorm of its output rows (MOCA_EP_LN): a plain linear with N == 320 (a block of
  * the 160 x 320 tiling owns complete rows), fast gather, no split-K, enough rows to fill the chip; else 0.               */
 int moca_gemm_ln_ok(const moca_gemm_params* p);
+/* Columns per column tile of the MOCA_EP_ROWSUM output of this call (320 / 160 on the staggered kernel, 128 / 160 on the
+ * 256-row kernel; N / cols partial sums per row), or 0 when this call cannot leave row sums behind.                     */
+int moca_gemm_rowsum_cols(const moca_gemm_params* p);
+/* 1 when this call's kernel has the MOCA_EP_LNFOLD epilogue (a plain or GEGLU linear on the staggered, 256-row or
+ * two-blocks-per-CU kernel, fp16 output, no split-K); else 0 (the caller then runs moca_layernorm_f16 first).           */
+int moca_gemm_lnfold_ok(const moca_gemm_params* p);
 /* bytes of split-K workspace moca_gemm_f16 needs for (M,N,splits) */
 int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits);
 

@@ -793,6 +793,115 @@ __device__ __forceinline__ void store_fp16_tile_ln(const moca_gemm_params& p, co
     }
 }
 
+// ---- store loop with LayerNorm statistics of the consumer (MOCA_EP_ROWSUM): as store_fp16_tile, but LPR lanes share a row
+//      (lane l -> 16-byte chunks l, l + LPR, ...), so the sum and the sum of squares of the stored (fp16-rounded) values of a
+//      row's BNC columns are reduced with shuffles and written to rowsum[column tile][m][2].  The consumer
+//      (MOCA_EP_LNFOLD) combines the N / BNC partials of a row. ----
+template <int NTHREADS, int BNC, int LPR>
+__device__ __forceinline__ void store_fp16_tile_rowsum(const moca_gemm_params& p, const char* stage, int pitch, int rows,
+                                                       int m0, int n0, int tid) {
+    constexpr int CPL = BNC / 8 / LPR;
+    static_assert(CPL * LPR * 8 == BNC, "column tile = LPR lanes x CPL chunks of 8");
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    const int l = tid % LPR, rsub = tid / LPR;
+    float* dst = p.rowsum + (int64_t)(n0 / BNC) * p.M * 2;
+    for (int row = rsub; row < rows; row += NTHREADS / LPR) {
+        const int m = m0 + row;
+        const bool ok = m < p.M;                         // (all lanes of a row agree; the shuffles below need every lane)
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int col = (l + LPR * c) * 8;
+            half8v h = *reinterpret_cast<const half8v*>(stage + row * pitch + col * 2);
+            if ((rowadd || resid) && ok) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+                if (rowadd) {
+                    const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + n0 + col);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+                }
+                if (resid) {
+                    const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + n0 + col);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float a = (float)h[j]; s += a; q += a * a; }
+            if (ok) *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + n0 + col) = h;
+        }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (l == 0 && ok) *reinterpret_cast<float2*>(dst + (int64_t)m * 2) = float2{s, q};
+    }
+}
+
+// ---- MOCA_EP_LNFOLD, step 1: thread t < TM owns the LayerNorm statistics of A row m0 + t, thread t < BN the wsum / bias of
+//      column n0 + t.  lnfold_issue() goes BEFORE the prologue's DMA instructions (loads return in order: by the time the first
+//      k-tiles have landed these have too, so their latency costs nothing; measured 7-14 us per launch when they were issued
+//      behind the DMAs) and keeps the raw values of the first two row partials in registers; lnfold_finish() (after the
+//      prologue DMAs are out) adds any further partials and turns the sums into (rstd, -mean * rstd).  Four registers are carried
+//      through the main loop; lnfold_publish() puts them into LDS behind the staged tile for the accumulator -> fp16 staging
+//      pass (rows past M repeat the last row; their stores are skipped anyway). ----
+struct LnFoldRegs { float rs, rb, ws, b; };
+struct LnFoldRaw { float2 p0, p1; float ws, b; };
+template <int TM, int BN>
+__device__ __forceinline__ LnFoldRaw lnfold_issue(const moca_gemm_params& p, int m0, int n0, int tid) {
+    LnFoldRaw r = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
+    if (p.reserved2_ & 1) return r;
+    if (tid < BN) {
+        r.ws = p.lnf_wsum[n0 + tid];
+        r.b = p.bias ? p.bias[n0 + tid] : 0.f;
+    }
+    if (tid < TM) {
+        const int m = min(m0 + tid, p.M - 1);
+        r.p0 = *reinterpret_cast<const float2*>(p.lnf_part + (int64_t)m * 2);
+        if (p.lnf_nparts > 1) r.p1 = *reinterpret_cast<const float2*>(p.lnf_part + ((int64_t)p.M + m) * 2);
+    }
+    return r;
+}
+template <int TM, int BN>
+__device__ __forceinline__ LnFoldRegs lnfold_finish(const moca_gemm_params& p, const LnFoldRaw& raw, int m0, int tid) {
+    LnFoldRegs r = {0.f, 0.f, raw.ws, raw.b};
+    if (tid < TM) {
+        const int m = min(m0 + tid, p.M - 1);
+        float s = raw.p0.x + raw.p1.x, q = raw.p0.y + raw.p1.y;
+        for (int i = 2; i < ((p.reserved2_ & 1) ? 0 : p.lnf_nparts); ++i) {
+            const float2 v = *reinterpret_cast<const float2*>(p.lnf_part + ((int64_t)i * p.M + m) * 2);
+            s += v.x; q += v.y;
+        }
+        const float inv_k = 1.0f / (float)p.K;
+        const float mean = s * inv_k;
+        const float var = fmaxf(q * inv_k - mean * mean, 0.f);
+        r.rs = rsqrtf(var + p.ln_eps);
+        r.rb = -mean * r.rs;
+    }
+    return r;
+}
+// lds: [TM] float2 (rstd, -mean * rstd), then [BN] wsum, then [BN] bias
+template <int TM, int BN>
+__device__ __forceinline__ void lnfold_publish(const LnFoldRegs& r, float* lds, int tid) {
+    if (tid < TM) *reinterpret_cast<float2*>(lds + 2 * tid) = float2{r.rs, r.rb};
+    if (tid < BN) { lds[2 * TM + tid] = r.ws; lds[2 * TM + BN + tid] = r.b; }
+    __syncthreads();
+}
+// step 2, per accumulator tile: v = rstd * acc + (-mean * rstd) * wsum + bias
+__device__ __forceinline__ f32x4 lnfold_apply(const f32x4 acc, const float2 st, const f32x4 ws, const f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = st.x * acc[j] + (st.y * ws[j] + b[j]);
+    return r;
+}
+__device__ __forceinline__ f32x4 ld4_or_zero(const float* ptr, int i) {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return ptr ? *reinterpret_cast<const f32x4*>(ptr + i) : z;
+}
+
 typedef __attribute__((address_space(3))) char* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
 
@@ -918,8 +1027,12 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     constexpr int NMMA = 4 * NT;     // MFMAs per half k-tile
     constexpr int NRD = 4 + NT;      // fragment reads per half k-tile
 
+    LnFoldRaw lraw = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
+    if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, m0, n0, tid);
     if (nk > 0) issue(kt_begin, 0);
     if (nk > 1) issue(kt_begin + 1, 1);
+    LnFoldRegs lf = {0.f, 0.f, 0.f, 0.f};
+    if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, m0, tid);
     MOCA_STAMP(1);
     if (nk > 0) {
         wait_tile(nk > 1);
@@ -1057,27 +1170,32 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
             }
         }
     } else {
+        const bool fold = (p.flags & MOCA_EP_LNFOLD) != 0;     // Linear(LayerNorm(x)) from x (no GEGLU / split-k on this kernel)
+        float* rst = reinterpret_cast<float*>(smem + TM * (BN * 2 + 16));
+        if (fold) lnfold_publish<TM, BN>(lf, rst, tid);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = wave_n * (BN / 2) + nt * 16 + 4 * fg;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
+            f32x4 bv, ws4 = {0.f, 0.f, 0.f, 0.f};
+            if (fold) { ws4 = *reinterpret_cast<const f32x4*>(rst + 2 * TM + col); bv = *reinterpret_cast<const f32x4*>(rst + 2 * TM + BN + col); }
+            else bv = ld4_or_zero(p.bias, n0 + col);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int row = wave_m * 64 + mt * 16 + fr;
-                half4v h;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[mt][nt][r] + bv[r]);
-                *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = h;
+                f32x4 v;
+                if (fold) v = lnfold_apply(acc[mt][nt], *reinterpret_cast<const float2*>(rst + 2 * row), ws4, bv);
+                else v = acc[mt][nt] + bv;
+                *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = __builtin_convertvector(v, half4v);
             }
         }
     }
     __syncthreads();
     MOCA_STAMP(4);
 
-    // (MOCA_EP_COLSUM is only accepted without GEGLU / split-k: out_bn == BN; 256 x 272 B or 256 x 336 B of staged rows + the
-    //  32 x BN x 2 / 25 x BN x 2 floats of row-subset sums fit inside the 144 / 156 KiB ring)
+    // (MOCA_EP_COLSUM / MOCA_EP_ROWSUM are only accepted without GEGLU / split-k: out_bn == BN; 256 x 272 B or 256 x 336 B of
+    //  staged rows + the 32 x BN x 2 / 25 x BN x 2 floats of row-subset sums fit inside the 144 / 156 KiB ring)
     if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * (BN * 2 + 16)), pitch, m0, n0, tile_m, tid);
+    else if (p.flags & MOCA_EP_ROWSUM) store_fp16_tile_rowsum<512, BN, 4>(p, smem, pitch, TM, m0, n0, tid);
     else store_fp16_tile<512>(p, smem, pitch, TM, out_bn, m0, on0, tid);
     MOCA_STAMP(5);
 #ifdef MOCA_STAMPS
@@ -1241,7 +1359,11 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     };
 
     // ---- prologue: pair (0, 1) ----
+    LnFoldRaw lraw = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
+    if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, m0, n0, tid);
     issue_pair(kt_begin, 0, 1);
+    LnFoldRegs lf = {0.f, 0.f, 0.f, 0.f};
+    if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, m0, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int i = 0; i < nk; i += 2) {
@@ -1275,16 +1397,30 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     const int out_bn = geglu ? BN / 2 : BN;
     const int on0 = geglu ? n0 / 2 : n0;
     const int pitch = out_bn * 2 + 16;
+    const bool fold = (p.flags & MOCA_EP_LNFOLD) != 0 && !(p.reserved2_ & 2);         // Linear(LayerNorm(x)) from x: row statistics -> LDS behind the staged tile
+    float* rst = reinterpret_cast<float*>(smem + TM * (BN * 2 + 16));
+    if (fold) lnfold_publish<TM, BN>(lf, rst, tid);
     if (geglu) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int ncol = n0 + wave_n * 64 + nt * 16 + 4 * fg;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) { bv = *reinterpret_cast<const f32x4*>(p.bias + ncol); bg = *reinterpret_cast<const f32x4*>(p.bias + ncol + 32); }
+            const int lcol = wave_n * 64 + nt * 16 + 4 * fg, ncol = n0 + lcol;
+            f32x4 bv, bg, wv = {0.f, 0.f, 0.f, 0.f}, wg = wv;
+            if (fold) {
+                wv = *reinterpret_cast<const f32x4*>(rst + 2 * TM + lcol); wg = *reinterpret_cast<const f32x4*>(rst + 2 * TM + lcol + 32);
+                bv = *reinterpret_cast<const f32x4*>(rst + 2 * TM + BN + lcol); bg = *reinterpret_cast<const f32x4*>(rst + 2 * TM + BN + lcol + 32);
+            } else {
+                bv = ld4_or_zero(p.bias, ncol); bg = ld4_or_zero(p.bias, ncol + 32);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int row = wave_m * 128 + mt * 16 + fr;
-                const f32x4 va = acc[mt][nt] + bv, ga = acc[mt][nt + 2] + bg;
+                f32x4 va, ga;
+                if (fold) {
+                    const float2 st = *reinterpret_cast<const float2*>(rst + 2 * row);
+                    va = lnfold_apply(acc[mt][nt], st, wv, bv); ga = lnfold_apply(acc[mt][nt + 2], st, wg, bg);
+                } else {
+                    va = acc[mt][nt] + bv; ga = acc[mt][nt + 2] + bg;
+                }
                 const f32x2 lo = moca_geglu2(f32x2{va[0], va[1]}, f32x2{ga[0], ga[1]});
                 const f32x2 hi = moca_geglu2(f32x2{va[2], va[3]}, f32x2{ga[2], ga[3]});
                 half4v h;
@@ -1296,15 +1432,16 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = wave_n * 64 + nt * 16 + 4 * fg;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
+            f32x4 bv, ws4 = {0.f, 0.f, 0.f, 0.f};
+            if (fold) { ws4 = *reinterpret_cast<const f32x4*>(rst + 2 * TM + col); bv = *reinterpret_cast<const f32x4*>(rst + 2 * TM + BN + col); }
+            else bv = ld4_or_zero(p.bias, n0 + col);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int row = wave_m * 128 + mt * 16 + fr;
-                half4v h;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[mt][nt][r] + bv[r]);
-                *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = h;
+                f32x4 v;
+                if (fold) v = lnfold_apply(acc[mt][nt], *reinterpret_cast<const float2*>(rst + 2 * row), ws4, bv);
+                else v = acc[mt][nt] + bv;
+                *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = __builtin_convertvector(v, half4v);
             }
         }
     }
@@ -1923,7 +2060,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && p.splits == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + wave_n * WTN + nt * 16 + 4 * fg);
+        if (p.bias && p.splits == 1 && !(p.flags & MOCA_EP_LNFOLD)) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + wave_n * WTN + nt * 16 + 4 * fg);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
     }
@@ -1953,10 +2090,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     };
 
     // ---- prologue: pairs (0,1) and (2,3) in flight, pair (0,1) landed everywhere ----
+    LnFoldRaw lraw = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
+    if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, m0, n0, tid);
     ga.seek(kt_begin);
     issue_pair(0, 1);
     ga.advance();
     issue_pair(2, 3);
+    LnFoldRegs lf = {0.f, 0.f, 0.f, 0.f};
+    if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, m0, tid);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
     __builtin_amdgcn_s_barrier();
     if (late) __builtin_amdgcn_s_barrier();            // from here on waves 4..7 run one barrier behind waves 0..3
@@ -2036,36 +2177,67 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         }
         return;
     }
+    const bool fold = (p.flags & MOCA_EP_LNFOLD) != 0 && !(p.reserved2_ & 2);
     if constexpr (SQ) {
         if (p.flags & MOCA_EP_GEGLU) {                   // per 64-column group: value tiles +0, +1 and their gate tiles +2, +3 (bias is in the accumulators)
             constexpr int gpitch = (BN / 2) * 2 + 16;
+            float* rst = reinterpret_cast<float*>(smem + TM * gpitch);
+            if (fold) lnfold_publish<TM, BN>(lf, rst, tid);
 #pragma unroll
             for (int grp = 0; grp < 2; ++grp)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int lcol = wave_n * WTN + grp * 64 + nt * 16 + 4 * fg;
+                    f32x4 wv = {0.f, 0.f, 0.f, 0.f}, wg = wv, bv = wv, bg = wv;
+                    if (fold) {
+                        wv = *reinterpret_cast<const f32x4*>(rst + 2 * TM + lcol); wg = *reinterpret_cast<const f32x4*>(rst + 2 * TM + lcol + 32);
+                        bv = *reinterpret_cast<const f32x4*>(rst + 2 * TM + BN + lcol); bg = *reinterpret_cast<const f32x4*>(rst + 2 * TM + BN + lcol + 32);
+                    }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const int row = wave_m * WTM + mt * 16 + fr;
-                        const f32x4 va = acc[mt][4 * grp + nt], gt = acc[mt][4 * grp + nt + 2];
+                        f32x4 va = acc[mt][4 * grp + nt], gt = acc[mt][4 * grp + nt + 2];
+                        if (fold) {
+                            const float2 st = *reinterpret_cast<const float2*>(rst + 2 * row);
+                            va = lnfold_apply(va, st, wv, bv); gt = lnfold_apply(gt, st, wg, bg);
+                        }
                         const f32x2 lo = moca_geglu2(f32x2{va[0], va[1]}, f32x2{gt[0], gt[1]});
                         const f32x2 hi = moca_geglu2(f32x2{va[2], va[3]}, f32x2{gt[2], gt[3]});
                         half4v h;
                         h[0] = (half_t)lo[0]; h[1] = (half_t)lo[1]; h[2] = (half_t)hi[0]; h[3] = (half_t)hi[1];
                         *reinterpret_cast<half4v*>(smem + row * gpitch + (wave_n * 64 + grp * 32 + nt * 16 + 4 * fg) * 2) = h;
                     }
+                }
             __syncthreads();
             store_fp16_tile<512>(p, smem, gpitch, TM, BN / 2, m0, n0 / 2, tid);
             return;
         }
     }
     constexpr int pitch = BN * 2 + 16;
+    if (fold) {                                          // Linear(LayerNorm(x)) from x: row statistics -> LDS behind the staged tile
+        float* rst = reinterpret_cast<float*>(smem + TM * pitch);
+        lnfold_publish<TM, BN>(lf, rst, tid);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = wave_n * WTN + nt * 16 + 4 * fg;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = wave_n * WTN + nt * 16 + 4 * fg;
+            const f32x4 ws4 = *reinterpret_cast<const f32x4*>(rst + 2 * TM + col);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(rst + 2 * TM + BN + col);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int row = wave_m * WTM + mt * 16 + fr;
-            *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = __builtin_convertvector(acc[mt][nt], half4v);
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = wave_m * WTM + mt * 16 + fr;
+                const float2 st = *reinterpret_cast<const float2*>(rst + 2 * row);
+                *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = __builtin_convertvector(lnfold_apply(acc[mt][nt], st, ws4, b4), half4v);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = wave_n * WTN + nt * 16 + 4 * fg;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = wave_m * WTM + mt * 16 + fr;
+                *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = __builtin_convertvector(acc[mt][nt], half4v);
+            }
         }
     }
     __syncthreads();
@@ -2074,9 +2246,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     } else if constexpr (WIDE) {
         if (p.flags & MOCA_EP_LN) store_fp16_tile_ln(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, tid);
         else if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
+        else if (p.flags & MOCA_EP_ROWSUM) store_fp16_tile_rowsum<512, BN, 8>(p, smem, pitch, TM, m0, n0, tid);
         else store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
     } else {
         if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
+        else if (p.flags & MOCA_EP_ROWSUM) store_fp16_tile_rowsum<512, BN, 4>(p, smem, pitch, TM, m0, n0, tid);
         else store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
     }
 #endif
@@ -2281,6 +2455,43 @@ static int colsum_rows(const moca_gemm_params& p) {
     return 0;
 }
 
+// columns per column tile of the row sums a MOCA_EP_ROWSUM launch leaves behind (0: this call cannot)
+static int rowsum_cols(const moca_gemm_params& p) {
+    if (p.splits != 1 || (p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_LN | MOCA_EP_GELU | MOCA_FORCE_SMALL_TILE))) return 0;
+    if (takes_w80s(p)) return w80s_wide(p) ? 320 : 160;
+    return takes_glds_bn(p);
+}
+// does the kernel this call runs on have the MOCA_EP_LNFOLD epilogue?
+static bool lnfold_ok(const moca_gemm_params& p) {
+    if (p.a_mode != MOCA_A_LINEAR || p.splits != 1) return false;
+    if (p.flags & (MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_LN | MOCA_EP_ROWSUM | MOCA_EP_GELU | MOCA_FORCE_SMALL_TILE)) return false;
+    if (takes_w80(p)) return !(p.flags & MOCA_EP_GEGLU) && takes_w80s(p);
+    const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
+    if (!(big_bn != 0 && p.M > 128)) return false;
+    const char* e_g4 = getenv("MOCA_GEMM_G4");
+    const int g4_mode = e_g4 ? atoi(e_g4) : 1;
+    const bool use_g4 = g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640);
+    if (takes_sq256(p, use_g4)) return true;
+    if (big_bn == 128 && use_g4) return true;
+    return !(p.flags & MOCA_EP_GEGLU);                  // the 256-row kernel: plain epilogue only
+}
+
+extern "C" int moca_gemm_rowsum_cols(const moca_gemm_params* pp) {
+    if (!pp) return 0;
+    moca_gemm_params p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
+    normalise_splits(p);
+    return rowsum_cols(p);
+}
+
+extern "C" int moca_gemm_lnfold_ok(const moca_gemm_params* pp) {
+    if (!pp) return 0;
+    moca_gemm_params p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
+    normalise_splits(p);
+    return lnfold_ok(p) ? 1 : 0;
+}
+
 extern "C" int moca_gemm_colsum_rows(const moca_gemm_params* pp) {
     if (!pp) return 0;
     moca_gemm_params p = *pp;
@@ -2352,6 +2563,8 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     const bool use_w80 = takes_w80(p);
     if ((p.flags & MOCA_EP_COLSUM) && !(p.colsum && colsum_rows(p) != 0)) return MOCA_E_BADARG;   // ask moca_gemm_colsum_rows() first
     if ((p.flags & MOCA_EP_LN) && !(p.ln_gamma && p.ln_beta && p.ln_out && p.ld_ln % 8 == 0 && takes_w80t_ln(p))) return MOCA_E_BADARG;   // ask moca_gemm_ln_ok() first
+    if ((p.flags & MOCA_EP_ROWSUM) && !(p.rowsum && rowsum_cols(p) != 0)) return MOCA_E_BADARG;             // ask moca_gemm_rowsum_cols() first
+    if ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1 && lnfold_ok(p))) return MOCA_E_BADARG;   // ask moca_gemm_lnfold_ok() first
     if (use_w80) {
         rc = launch_gemm_w80_mode(p, fastp, st);
     } else if (takes_sq256(p, use_g4)) {

@@ -9,6 +9,7 @@ through torch kernels: torch only allocates the buffers.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import torch
 
 from . import lib as _l
@@ -41,10 +42,11 @@ def _round_up(x, m):
 # --------------------------------------------------------------------------------------
 class PackedWeight:
     """fp16 [Npad][Kpad] K-contiguous weight + fp32 bias, as moca_gemm_f16 wants them."""
-    __slots__ = ("w", "bias", "N", "K", "n_out", "geglu")
+    __slots__ = ("w", "bias", "N", "K", "n_out", "geglu", "wsum")
 
     def __init__(self, w, bias, N, K, n_out, geglu=False):
         self.w, self.bias, self.N, self.K, self.n_out, self.geglu = w, bias, N, K, n_out, geglu
+        self.wsum = None         # LayerNorm-folded weights only (fold_layernorm): f32 [N], row sums of the packed fp16 W'
 
 
 def _finish(w2d: torch.Tensor, bias, device, n_out=None, geglu=False) -> PackedWeight:
@@ -107,12 +109,30 @@ def pack_geglu(weight, bias, device="cuda"):
     return p
 
 
+def fold_layernorm(weight, bias, gamma, beta):
+    """Linear(LayerNorm(x)) as a linear on x plus per-row statistics (MOCA_EP_LNFOLD):
+    W' = W * diag(gamma), b' = b + W @ beta.  Returns (W' f32, b' f32); pack them with pack_linear / pack_geglu and call
+    finish_lnfold() on the result."""
+    w = weight.reshape(weight.shape[0], -1).float()
+    g, be = gamma.to(w.device).float(), beta.to(w.device).float()
+    b = w @ be
+    if bias is not None:
+        b = b + bias.to(w.device).float()
+    return w * g[None, :], b
+
+
+def finish_lnfold(pw: PackedWeight) -> PackedWeight:
+    """wsum[n] = sum_k of the PACKED fp16 W'[n][k] (what the MFMAs multiply with), so that acc - mean * wsum is exact algebra"""
+    pw.wsum = pw.w.float().sum(dim=1).contiguous()
+    return pw
+
+
 # --------------------------------------------------------------------------------------
 # kernel wrappers
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
                  residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None,
-                 force_small=False):
+                 force_small=False, rowsum=None, lnfold=None):
     p = _l.GemmParams()
     p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), (out.data_ptr() if out is not None else None)
     p.bias = pw.bias.data_ptr() if pw.bias is not None else None
@@ -142,7 +162,17 @@ def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR
         p.ln_out = ln[2].data_ptr() if ln[2] is not None else None
         p.ld_ln = ln[2].stride(-2) if ln[2] is not None else pw.N
         p.ln_eps = ln[3]
+    if rowsum is not None:                   # f32 [N / cols][M][2] (cols = gemm_rowsum_cols), or True when only probing
+        p.flags |= _l.MOCA_EP_ROWSUM
+        p.rowsum = rowsum.data_ptr() if torch.is_tensor(rowsum) else None
+    if lnfold is not None:                   # (row partials f32 [nparts][M][2] or None when only probing, nparts, eps); pw.wsum required
+        p.flags |= _l.MOCA_EP_LNFOLD
+        p.lnf_part = lnfold[0].data_ptr() if lnfold[0] is not None else None
+        p.lnf_nparts = lnfold[1]
+        p.ln_eps = lnfold[2]
+        p.lnf_wsum = pw.wsum.data_ptr() if pw.wsum is not None else None
     p.splits = splits
+    p.reserved2_ = int(os.environ.get('MOCA_LNFOLD_DBG', '0'))
     return p
 
 
@@ -159,6 +189,18 @@ def gemm_ln_ok(a, pw: PackedWeight, **kw):
     """can this call also write the LayerNorm of its output rows (MOCA_EP_LN)?"""
     p = _gemm_params(a, pw, None, **kw)
     return bool(_l.load().moca_gemm_ln_ok(C.byref(p)))
+
+
+def gemm_rowsum_cols(a, pw: PackedWeight, **kw):
+    """columns per column tile of the MOCA_EP_ROWSUM output of this call (N / cols partial sums per row), 0 if it cannot"""
+    p = _gemm_params(a, pw, None, **kw)
+    return int(_l.load().moca_gemm_rowsum_cols(C.byref(p)))
+
+
+def gemm_lnfold_ok(a, pw: PackedWeight, **kw):
+    """does the kernel this call runs on have the MOCA_EP_LNFOLD epilogue?"""
+    p = _gemm_params(a, pw, None, **kw)
+    return bool(_l.load().moca_gemm_lnfold_ok(C.byref(p)))
 
 
 def gemm_colsum_rows(a, pw: PackedWeight, **kw):

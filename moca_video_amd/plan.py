@@ -54,6 +54,15 @@ def gemm_splits(M, pw):
     return max(1, min(cap, nk // 8))
 
 
+class _LNRef:
+    """a LayerNorm that exists only as statistics: x (fp16 [M][C]) + the row partial sums its producer left behind
+    (f32 [nparts][M][2]); consumed by a MOCA_EP_LNFOLD GEMM"""
+    __slots__ = ("x", "part", "nparts")
+
+    def __init__(self, x, part, nparts):
+        self.x, self.part, self.nparts = x, part, nparts
+
+
 class _PlanBase:
     """pool + recorded launch list + hipGraph capture/replay, shared by the UNet plan and the VAE-decoder plan"""
 
@@ -251,9 +260,47 @@ class _Plan(_PlanBase):
         self._release(h2.buf)
         return cur
 
-    def _attn_self(self, att, l, M, Cn, heads, spatial, F, HW):
+    # ---- LayerNorm folded into the linear that consumes it ------------------------------------------------------------
+    def _folded(self, key, build):
+        """LayerNorm-folded packed weights of one consumer (built on first use, kept beside the plain ones)"""
+        k = ("lnfold", key)
+        if k not in self.P:
+            self.P[k] = build()
+        return self.P[k]
+
+    def _fold_pw(self, kind, mod, norm):
+        """W' = W diag(gamma), b' = b + W beta for the linear `mod` that reads LayerNorm `norm` (ops.fold_layernorm)"""
+        g, b = self.P[id(norm)]
+        dev = self.device
+
+        def build():
+            if kind == "qkv":                                    # fused to_q | to_k | to_v (no biases, attention.py:54-56)
+                w = torch.cat([mod.to_q.weight.detach(), mod.to_k.weight.detach(), mod.to_v.weight.detach()], dim=0).to(dev)
+                wf, bf = ops.fold_layernorm(w, None, g, b)
+                return ops.finish_lnfold(ops.pack_linear(wf, bf, device=dev))
+            if kind == "q":
+                wf, bf = ops.fold_layernorm(mod.to_q.weight.detach().to(dev), None, g, b)
+                return ops.finish_lnfold(ops.pack_linear(wf, bf, device=dev))
+            wf, bf = ops.fold_layernorm(mod.weight.detach().to(dev), mod.bias.detach().to(dev), g, b)      # GEGLU.proj
+            return ops.finish_lnfold(ops.pack_geglu(wf, bf, device=dev))
+        return self._folded(id(mod), build)
+
+    def linear_of_ln(self, l, M, pw, fold_pw):
+        """linear(LayerNorm(x)): `l` is either the LayerNorm output (a tensor) or an _LNRef (x + row partial sums left by its
+        producer): then the fold runs in this GEMM's epilogue on the folded weights and no LayerNorm pass exists"""
+        if isinstance(l, _LNRef):
+            pwf = fold_pw()
+            out = self.pool.get(M, pwf.n_out if pwf.geglu else pwf.N)
+            self._emit(ops.gemm, l.x, pwf, out, M=M, lda=l.x.stride(-2), splits=1, lnfold=(l.part, l.nparts, 1e-5))
+            return out
+        return self.linear(l, M, pw)
+
+    def _release_ln(self, l):
+        self._release(l.part if isinstance(l, _LNRef) else l)
+
+    def _attn_self(self, att, l, M, Cn, heads, spatial, F, HW, norm=None):
         P = self.P
-        qkv = self.linear(l, M, P[id(att)])                     # [M][3C] fused to_q|to_k|to_v
+        qkv = self.linear_of_ln(l, M, P[id(att)], lambda: self._fold_pw("qkv", att, norm))   # [M][3C] fused to_q|to_k|to_v
         o = self.pool.get(M, Cn)
         q, k, v = qkv[:, :Cn], qkv[:, Cn:2 * Cn], qkv[:, 2 * Cn:]
         scale = att.dim_head ** -0.5
@@ -266,8 +313,8 @@ class _Plan(_PlanBase):
         self._release(qkv)
         return o
 
-    def _attn_cross(self, att, l, M, Cn, heads, F, HW):
-        q = self.linear(l, M, self.P[id(att)])
+    def _attn_cross(self, att, l, M, Cn, heads, F, HW, norm=None):
+        q = self.linear_of_ln(l, M, self.P[id(att)], lambda: self._fold_pw("q", att, norm))
         off, inner = self.model._kv_cols[id(att)]                # one K/V per video (context.repeat_interleave, :547),
         ld = self.kv_all.shape[1]                                # all layers' K|V projected by one GEMM up front
         o = self.pool.get(M, Cn)
@@ -276,52 +323,86 @@ class _Plan(_PlanBase):
         self._release(q)
         return o
 
-    def linear_ln(self, a, M, pw, gb, residual=None):
-        """`out = linear(a) (+ residual)` and `l = LayerNorm(out)` (eps 1e-5, attention.py:199-201).  ONE launch where the
-        160 x 320 tiling applies (N = 320: a block owns whole rows and normalises them in its store loop, MOCA_EP_LN);
-        otherwise the linear followed by the LayerNorm kernel."""
+    def linear_ln(self, a, M, pw, gb, residual=None, consumer=None):
+        """`out = linear(a) (+ residual)` and `l = LayerNorm(out)` (eps 1e-5, attention.py:199-201).
+        (1) `consumer` = a callable returning the LayerNorm-folded weights of the ONE linear that reads l: when this launch can
+        leave row sums behind (MOCA_EP_ROWSUM) and the consumer's kernel has the fold epilogue (MOCA_EP_LNFOLD), l is an
+        _LNRef and LayerNorm never touches memory; (2) ONE launch writing out and LayerNorm(out) where the 160 x 320 tiling
+        applies (N = 320: a block owns whole rows and normalises them in its store loop, MOCA_EP_LN); (3) otherwise the linear
+        followed by the LayerNorm kernel."""
         lda = a.stride(-2)
         splits = self._splits(M, pw)
-        if os.environ.get("MOCA_GEMM_LN", "1") != "0" and \
-                ops.gemm_ln_ok(a, pw, M=M, lda=lda, residual=residual, splits=splits, ln=(gb[0], gb[1], None, 1e-5)):
+        ln_epilogue = os.environ.get("MOCA_GEMM_LN", "1") != "0" and \
+            ops.gemm_ln_ok(a, pw, M=M, lda=lda, residual=residual, splits=splits, ln=(gb[0], gb[1], None, 1e-5))
+        # Measured (same device, whole CFG step, tools/ab_run7.sh): fold wherever possible 36.9 ms, fold only where neither the
+        # LayerNorm store loop (N = 320) nor more than two row partials apply 37.3, never 37.6.  In isolation the consumers pay
+        # 3-12 % for the two FMAs per accumulator and the statistics loads (tools/bench_lnfold.py; worst at K = 320 and with the
+        # 10 partials of the 1280-channel level), less than the LayerNorm pass and the second output they replace cost in the
+        # graph.  MOCA_LN_FOLD: 0 = never, 1 = only where there is no LayerNorm store loop and <= 2 partials, 2 (default) = wherever
+        # producer and consumer kernels allow.
+        fold_mode = int(os.environ.get("MOCA_LN_FOLD", "2"))
+        fold_set = os.environ.get("MOCA_LN_FOLD_SET")            # (A/B runs: the channel counts the fold may run at)
+        if fold_set is not None:
+            fold_mode = 2 if str(pw.N) in fold_set.split(",") else 0
+        if consumer is not None and fold_mode != 0 and splits == 1 and (fold_mode == 2 or not ln_epilogue):
+            cols = ops.gemm_rowsum_cols(a, pw, M=M, lda=lda, residual=residual, splits=1, rowsum=True)
+            nparts = pw.N // cols if cols > 0 else 0
+            if cols > 0 and (fold_mode == 2 or nparts <= 2):
+                pwf = consumer()
+                if ops.gemm_lnfold_ok(a, pwf, M=M, lda=pw.N, splits=self._splits(M, pwf), lnfold=(None, nparts, 1e-5)) and \
+                        self._splits(M, pwf) == 1:
+                    out = self.pool.get(M, pw.N)
+                    part = self.pool.get(nparts * M, 2, torch.float32)
+                    self._emit(ops.gemm, a, pw, out, M=M, lda=lda, residual=residual, splits=1, rowsum=part)
+                    return out, _LNRef(out, part, nparts)
+        if ln_epilogue:
             out, l = self.pool.get(M, pw.N), self.pool.get(M, pw.N)
             self._emit(ops.gemm, a, pw, out, M=M, lda=lda, residual=residual, splits=1, ln=(gb[0], gb[1], l, 1e-5))
             return out, l
         out = self.linear(a, M, pw, residual=residual)
         return out, self.ln(out, M, pw.N, gb)
 
-    def tblock(self, blk, h, l, M, Cn, heads, spatial, F, HW, next_gb=None):
+    def tblock(self, blk, h, l, M, Cn, heads, spatial, F, HW, next_gb=None, next_consumer=None):
         """BasicTransformerBlock._forward, attention.py:216-220.  `l` = norm1(h), already computed by the producer of h;
         returns (h_out, norm1 of the NEXT block applied to it, or None)."""
         P = self.P
-        for att, nxt in ((blk.attn1, blk.norm2), (blk.attn2, blk.norm3)):
+        geglu = blk.ff.net[0].proj
+        consumers = (self._ln_consumer(blk.attn2, blk.norm2), lambda: self._fold_pw("geglu", geglu, blk.norm3))
+        for (att, cur, nxt), cons in zip(((blk.attn1, blk.norm1, blk.norm2), (blk.attn2, blk.norm2, blk.norm3)), consumers):
             if att.is_self:
-                o = self._attn_self(att, l, M, Cn, heads, spatial, F, HW)
+                o = self._attn_self(att, l, M, Cn, heads, spatial, F, HW, norm=cur)
             else:
-                o = self._attn_cross(att, l, M, Cn, heads, F, HW)
-            self._release(l)
-            nh, l = self.linear_ln(o, M, P[id(att.to_out[0])], P[id(nxt)], residual=h)
+                o = self._attn_cross(att, l, M, Cn, heads, F, HW, norm=cur)
+            self._release_ln(l)
+            nh, l = self.linear_ln(o, M, P[id(att.to_out[0])], P[id(nxt)], residual=h, consumer=cons)
             self._release(o, h)
             h = nh
-        ff = self.linear(l, M, P[id(blk.ff.net[0].proj)])        # GEGLU fused into the epilogue
-        self._release(l)
+        ff = self.linear_of_ln(l, M, P[id(geglu)], consumers[1])  # GEGLU fused into the epilogue
+        self._release_ln(l)
         if next_gb is not None:
-            nh, l = self.linear_ln(ff, M, P[id(blk.ff.net[2])], next_gb, residual=h)
+            nh, l = self.linear_ln(ff, M, P[id(blk.ff.net[2])], next_gb, residual=h, consumer=next_consumer)
         else:
             nh, l = self.linear(ff, M, P[id(blk.ff.net[2])], residual=h), None
         self._release(ff, h)
         return nh, l
+
+    def _ln_consumer(self, att, norm):
+        """the folded weights of the projection that reads `norm` in front of attention `att`"""
+        return lambda: self._fold_pw("qkv" if att.is_self else "q", att, norm)
 
     def transformer(self, mod, x, spatial):
         """SpatialTransformer.forward attention.py:262-278 / TemporalTransformer.forward :331-373"""
         P = self.P
         n = self.gn(x, P[id(mod.norm)], fps=1 if spatial else self.T, eps=1e-6, silu=False)
         blocks = list(mod.transformer_blocks)
-        h, l = self.linear_ln(n, x.M, P[id(mod.proj_in)], P[id(blocks[0].norm1)])
+        h, l = self.linear_ln(n, x.M, P[id(mod.proj_in)], P[id(blocks[0].norm1)],
+                              consumer=self._ln_consumer(blocks[0].attn1, blocks[0].norm1))
         self._release(n)
         for i, blk in enumerate(blocks):
-            nxt = P[id(blocks[i + 1].norm1)] if i + 1 < len(blocks) else None
-            h, l = self.tblock(blk, h, l, x.M, mod.inner, mod.heads, spatial, x.F, x.H * x.W, next_gb=nxt)
+            last = i + 1 >= len(blocks)
+            nxt = None if last else P[id(blocks[i + 1].norm1)]
+            ncons = None if last else self._ln_consumer(blocks[i + 1].attn1, blocks[i + 1].norm1)
+            h, l = self.tblock(blk, h, l, x.M, mod.inner, mod.heads, spatial, x.F, x.H * x.W, next_gb=nxt, next_consumer=ncons)
         out, cs = self.linear(h, x.M, P[id(mod.proj_out)], residual=x.buf, want_colsum=True)
         self._release(h)
         return _FMap(out, x.F, x.H, x.W, x.C, cs)

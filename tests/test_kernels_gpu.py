@@ -442,3 +442,56 @@ def test_gemm_sq256(M, K, N, geglu, with_res, monkeypatch):
         ops.gemm(a, pw, out, M=M, residual=res)
         ref = y + res.float() if with_res else y
     check(out, ref, TOL16, f"sq256 {M}x{N}x{K} geglu={geglu}")
+
+
+# ---------------------------------------------------------------- LayerNorm folded into the consuming linear
+@pytest.mark.parametrize("M,C,Kp,with_res,consumers", [
+    (40000, 320, 320, True, [("lin", 960), ("geglu", 1280)]),            # 160 x 320 producer (1 partial); staggered / g4 consumers
+    (20480, 640, 640, True, [("lin", 1920), ("geglu", 2560)]),           # 2 partials
+    (5120, 1280, 1280, False, [("lin", 3840), ("lin", 1280), ("geglu", 5120)]),   # 256-row producer (10 partials); staggered, 256-row, sq256
+    (33000, 320, 320, True, [("lin", 960)]),                             # M tail
+    (33000, -320, 320, True, [("lin", 960)]),                            # (C < 0: MOCA_GEMM_WIDE=0) 320 x 160 producer, 2 partials
+    (4000, 512, 320, False, [("lin", 1536), ("geglu", 2048)])])          # init_attn widths: 256-row producer (4 partials)
+def test_gemm_rowsum_feeds_lnfold(M, C, Kp, with_res, consumers, monkeypatch):
+    """MOCA_EP_ROWSUM + MOCA_EP_LNFOLD: the producer linear leaves per-(column tile, row) sums of what it stores; the consumer
+    runs on x with W' = W diag(gamma), b' = b + W beta and finishes Linear(LayerNorm(x)) in its epilogue (ref: torch)."""
+    if C < 0:
+        C = -C
+        monkeypatch.setenv("MOCA_GEMM_WIDE", "0")
+    a, w, b = rnd(M, Kp), rnd(C, Kp, scale=Kp ** -0.5), rnd(C, dtype=torch.float32)
+    res = rnd(M, C) * 2 + 0.5 if with_res else None          # (a non-zero row mean: the fold subtracts mean * wsum)
+    pw = ops.pack_linear(w, b)
+    cols = ops.gemm_rowsum_cols(a, pw, M=M, residual=res, rowsum=True)
+    assert cols > 0 and C % cols == 0
+    nparts = C // cols
+    x = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    part = torch.full((nparts * M, 2), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm(a, pw, x, M=M, residual=res, rowsum=part)
+    xr = a.float() @ w.float().t() + b
+    if with_res:
+        xr = xr + res.float()
+    check(x, xr, TOL16, "producer")
+    pr = part.view(nparts, M, 2).sum(0)
+    xf = x.float()
+    assert relerr(pr[:, 0], xf.sum(1)) < 1e-4 and relerr(pr[:, 1], (xf * xf).sum(1)) < 1e-4
+    g = rnd(C, dtype=torch.float32) * 0.3 + 1.0
+    be = rnd(C, dtype=torch.float32) * 0.3
+    ln = F.layer_norm(xf, (C,), g, be, 1e-5)
+    for kind, n in consumers:
+        if kind == "lin":
+            wc, bc = rnd(n, C, scale=C ** -0.5), rnd(n, dtype=torch.float32)
+            wf, bf = ops.fold_layernorm(wc, bc, g, be)
+            pwf = ops.finish_lnfold(ops.pack_linear(wf, bf))
+            ref = ln @ wc.float().t() + bc
+            n_out = n
+        else:
+            wc, bc = rnd(2 * n, C, scale=C ** -0.5), rnd(2 * n, dtype=torch.float32, scale=0.1)
+            wf, bf = ops.fold_layernorm(wc, bc, g, be)
+            pwf = ops.finish_lnfold(ops.pack_geglu(wf, bf))
+            y = ln @ wc.float().t() + bc
+            ref = y[:, :n] * F.gelu(y[:, n:])
+            n_out = n
+        assert ops.gemm_lnfold_ok(x, pwf, M=M, lnfold=(None, nparts, 1e-5)), f"{kind} N={n}: expected a kernel with the fold epilogue"
+        out = torch.empty(M, n_out, dtype=torch.float16, device=DEV)
+        ops.gemm(x, pwf, out, M=M, lnfold=(part, nparts, 1e-5))
+        check(out, ref, TOL16, f"lnfold consumer {kind} N={n} (C={C}, {nparts} partials)")

@@ -252,8 +252,8 @@ def test_reloading_weights_releases_the_old_graphs(reduced_model):
     t = torch.from_numpy(g["uniform__t"]).cuda()
     for _ in range(3):
         y0 = reduced_model(x, t, context=ctx, fps=16)
-    old = list(reduced_model._plans.values())
-    assert old and all(p.graph is not None for p in old)
+    old = list(reduced_model._plans.values())      # (the fixture is shared: plans other tests ran only once have no graph yet)
+    assert any(p.graph is not None for p in old) and reduced_model._plan_for(x, ctx.shape[1]).graph is not None
     reduced_model.load_state_dict(state_dict_for(reduced_model, 11), strict=True)
     assert not reduced_model._plans and all(p.graph is None for p in old), "old plans must have released their graphs"
     for _ in range(3):

@@ -40,7 +40,8 @@ with torch.cuda.stream(st):
             key = f"gemm {mode:5s} M={kw['M']:6d} N={pw.N:5d} K={pw.K:5d}" + (" geglu" if pw.geglu else "") + \
                   (" +res" if kw.get("residual") is not None else "") + (" +rowadd" if kw.get("rowadd") is not None else "") + \
                   (f" splits={kw['splits']}" if kw.get("splits", 1) > 1 else "") + (" f32" if kw.get("out_f32") else "") + \
-                  (" +colsum" if kw.get("colsum") is not None else "") + (" +LN" if kw.get("ln") is not None else "")
+                  (" +colsum" if kw.get("colsum") is not None else "") + (" +LN" if kw.get("ln") is not None else "") + \
+                  (" +rowsum" if kw.get("rowsum") is not None else "") + (" lnfold" if kw.get("lnfold") is not None else "")
             flop = 2.0 * kw["M"] * pw.N * pw.w.shape[1]
             if kw.get("conv") is not None and kw["conv"][6]:
                 pass
