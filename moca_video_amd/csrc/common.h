@@ -21,7 +21,11 @@ typedef float    f32x16 __attribute__((ext_vector_type(16)));
 
 static inline hipStream_t moca_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-__device__ __forceinline__ float moca_silu(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with v_exp + v_rcp (1 ulp each, far below the fp16 output resolution) instead of an IEEE division: the
+// GroupNorm apply pass runs it on every activation and the division's ~10 instructions were a third of its VALU work
+__device__ __forceinline__ float moca_silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 // erf GELU, as F.gelu default (attention.py:383).  erf by Abramowitz-Stegun 7.1.26
 // (|abs err| <= 1.5e-7 + 1 ulp of v_rcp_f32, far below the fp16 output resolution): 1 v_rcp + 1 v_exp
 // + 6 FMA instead of libm erff's ~40-instruction branchy polynomial.  The GEGLU epilogue runs it

@@ -127,6 +127,9 @@ __global__ __launch_bounds__(FIN_T) void gn_finalize_colsum_kernel(const float* 
 }
 
 // ---- K3: apply (x - mean) * rstd * gamma + beta, optional SiLU ----------------
+// Two batches of four 16-byte loads per thread in flight: the first batch is issued BEFORE the statistics / affine parameters
+// are fetched (their latency used to precede the first x load of every block), the next batch before the current one is
+// normalised and stored.  Rows past the end of the chunk are fetched from the last valid row (cache hits) and not stored.
 __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const float* __restrict__ meanrstd, int HW, int C, int nchunk,
@@ -135,8 +138,17 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
     const int cx = threadIdx.x, py = threadIdx.y, ppb = blockDim.y;
     const int pc = (HW + nchunk - 1) / nchunk;
     const int p_begin = chunk * pc, p_end = min(p_begin + pc, HW);
+    if (p_begin >= p_end) return;
     const int cpg = C / GN_GROUPS;
     const int sg = f / frames_per_stat;
+    const int64_t off = ((int64_t)f * HW) * C + cx * 8;
+    auto load4 = [&](half8v (&v)[4], int pp) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8v*>(x + off + (int64_t)min(pp + u * ppb, p_end - 1) * C);
+    };
+    int pp = p_begin + py;
+    half8v cur[4], nxt[4];
+    load4(cur, pp);
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -147,7 +159,6 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
         sc[j] = rstd * gamma[c];
         sh[j] = beta[c] - mean * sc[j];
     }
-    const int64_t off = ((int64_t)f * HW) * C + cx * 8;
     auto norm8 = [&](const half8v& v) {
         half8v o;
 #pragma unroll
@@ -158,16 +169,17 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
         }
         return o;
     };
-    int pp = p_begin + py;
-    for (; pp + 3 * ppb < p_end; pp += 4 * ppb) {         // four loads in flight per thread, as in the statistics pass
-        half8v v[4];
+    for (; pp < p_end; pp += 4 * ppb) {
+        const bool more = pp + 4 * ppb < p_end;
+        if (more) load4(nxt, pp + 4 * ppb);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8v*>(x + off + (int64_t)(pp + u * ppb) * C);
+        for (int u = 0; u < 4; ++u)
+            if (pp + u * ppb < p_end) *reinterpret_cast<half8v*>(y + off + (int64_t)(pp + u * ppb) * C) = norm8(cur[u]);
+        if (more) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<half8v*>(y + off + (int64_t)(pp + u * ppb) * C) = norm8(v[u]);
+            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+        }
     }
-    for (; pp < p_end; pp += ppb)
-        *reinterpret_cast<half8v*>(y + off + (int64_t)pp * C) = norm8(*reinterpret_cast<const half8v*>(x + off + (int64_t)pp * C));
 }
 
 // ---- single-launch GroupNorm for small tensors ------------------------------------
