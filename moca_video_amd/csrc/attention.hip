@@ -41,6 +41,22 @@ __device__ __forceinline__ half4v tr_read(const char* addr) {
     return __builtin_bit_cast(half4v, v);
 }
 
+// XCD-aware block order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2).  With
+// the natural order the 20 query blocks of one (frame, head) land on all 8 XCDs and every L2 fetches that head's K and V from
+// the fabric (rocprofv3 FETCH_SIZE: 2 GB per 2560-token launch, ~6 TB/s during the kernel).  Here all query blocks of a
+// (frame, head) pair go to XCD (pair % 8), consecutive in time, so K/V cross the fabric once.
+__device__ __forceinline__ void attn_block_coords(int& bx, int& by) {
+    const int nx = gridDim.x, ny = gridDim.y;
+    if (ny % 8 == 0) {
+        const int b = blockIdx.y * nx + blockIdx.x;       // dispatch order
+        const int xcd = b & 7, slot = b >> 3;
+        by = (slot / nx) * 8 + xcd;
+        bx = slot % nx;
+    } else {
+        bx = blockIdx.x; by = blockIdx.y;
+    }
+}
+
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attention_kernel(
     const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, half_t* __restrict__ out,
@@ -51,9 +67,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     __shared__ __attribute__((aligned(16))) char sV[2][KT * ROWB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bq = blockIdx.y / heads, head = blockIdx.y % heads;
+    int bx, by;
+    attn_block_coords(bx, by);
+    const int bq = by / heads, head = by % heads;
     const int bkv = bq / kv_div;
-    const int q0 = blockIdx.x * QB + wave * 32;
+    const int q0 = bx * QB + wave * 32;
     const int fr = lane & 31, fh = lane >> 5;
 
     const half_t* qb = q + (int64_t)bq * Nq * ldq + head * D;
@@ -244,9 +262,11 @@ __global__ __launch_bounds__(256, 2) void attention_v4_kernel(
     char* const sV = smem + 2 * TILE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bq = blockIdx.y / heads, head = blockIdx.y % heads;
+    int bx, by;
+    attn_block_coords(bx, by);
+    const int bq = by / heads, head = by % heads;
     const int bkv = bq / kv_div;
-    const int q0 = blockIdx.x * QB + wave * 32;
+    const int q0 = bx * QB + wave * 32;
     const int fr = lane & 31, fh = lane >> 5;
 
     const half_t* qb = q + (int64_t)bq * Nq * ldq + head * D;
