@@ -53,6 +53,12 @@ extern "C" {
                            /* the stored (fp16-rounded) values to p.rowsum: the LayerNorm     */
                            /* statistics of the consumer (attention.py:199-201); only where   */
                            /* moca_gemm_rowsum_cols() > 0                                     */
+#define MOCA_EP_GSTAT  256 /* GroupNorm statistics of the consumer, finished: every block adds */
+                           /* the sums / sums of squares of what it stores, per (statistics    */
+                           /* group, channel group), to p.gstat (f64 atomics; zero before the  */
+                           /* launch); moca_groupnorm_gstat_f16 then needs no finalize launch. */
+                           /* Same kernels as MOCA_EP_COLSUM (moca_gemm_colsum_rows() > 0) and */
+                           /* p.gstat_rows % that == 0                                         */
 #define MOCA_EP_LNFOLD 128 /* the A operand is x, the linear wanted is Linear(LayerNorm(x)):  */
                            /* W is packed as W' = W * diag(ln weight), bias as b + W.ln_bias, */
                            /* p.lnf_wsum[n] = sum_k W'[n][k]; the epilogue computes           */
@@ -100,6 +106,10 @@ typedef struct moca_gemm_params {
     const float* lnf_wsum; /* MOCA_EP_LNFOLD: f32 [N], sum over k of the packed fp16 W'[n][k]                           */
     int32_t     lnf_nparts;
     int32_t     reserved2_;
+    double*     gstat;     /* MOCA_EP_GSTAT: f64 [M / gstat_rows][32][2] accumulators (sum, sum of squares) per
+                              (statistics group, GroupNorm channel group of N / 32 columns)                             */
+    int32_t     gstat_rows;/* rows per statistics group (frames_per_stat * H*W of the consumer's GroupNorm)             */
+    int32_t     reserved3_;
 } moca_gemm_params;
 
 /* Replaces F.conv2d 3x3 (openaimodel3d.py:152,177,66-70,96-106,376,531),
@@ -143,6 +153,14 @@ int64_t moca_groupnorm_ws_bytes(int32_t F, int32_t HW, int32_t C);
 int moca_groupnorm_colsum_f16(const void* x, void* y, const float* gamma, const float* beta, const float* colsum,
                               int32_t tile_rows, int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
                               float eps, int32_t silu, float* ws, void* stream);
+
+/* The same GroupNorm when the producer of x was a moca_gemm_f16 call with MOCA_EP_GSTAT: gstat f64 [F / frames_per_stat][32][2]
+ * holds the finished sums, so this is ONE launch (apply) and x is read once.                                          */
+int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gamma, const float* beta, const double* gstat,
+                             int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
+                             float eps, int32_t silu, void* stream);
+/* hipMemsetAsync(ptr, 0, bytes) on the stream (the MOCA_EP_GSTAT accumulators of a forward are zeroed by one call) */
+int moca_memset_zero(void* ptr, int64_t bytes, void* stream);
 
 /* LayerNorm over the last dim of fp16 x[M][C] (eps 1e-5): attention.py:199-201 */
 int moca_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta,

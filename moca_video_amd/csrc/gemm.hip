@@ -719,6 +719,38 @@ __device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p
         for (int j = 0; j < 8; ++j) { red[(rs * BNC + ch * 8 + j) * 2] = s[j]; red[(rs * BNC + ch * 8 + j) * 2 + 1] = q[j]; }
     }
     __syncthreads();
+    if (p.flags & MOCA_EP_GSTAT) {
+        // finished statistics: column totals -> LDS, then one thread per (GroupNorm channel group touched by this tile, sum or sum
+        // of squares) adds its columns and issues ONE f64 atomic on gstat[statistics group][channel group] (a row tile lies
+        // inside one statistics group).  Sums of <= 320 x 40 values per atomic in fp32; the cross-tile accumulation is f64.
+        float a[2] = {0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = tid + h * 512;
+            if (i < 2 * BNC) {
+#pragma unroll 4
+                for (int r = 0; r < RS; ++r) a[h] += red[r * BNC * 2 + i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = tid + h * 512;
+            if (i < 2 * BNC) red[i] = a[h];
+        }
+        __syncthreads();
+        const int cpg = p.N / 32;
+        const int g0 = n0 / cpg, g1 = (n0 + BNC - 1) / cpg;
+        if (tid < 2 * (g1 - g0 + 1)) {
+            const int g = g0 + (tid >> 1), comp = tid & 1;
+            const int c0 = max(g * cpg, n0) - n0, c1 = min((g + 1) * cpg, n0 + BNC) - n0;
+            float t = 0.f;
+            for (int c = c0; c < c1; ++c) t += red[c * 2 + comp];
+            const int sg = m0 / p.gstat_rows;
+            atomicAdd(p.gstat + ((int64_t)sg * 32 + g) * 2 + comp, (double)t);
+        }
+        return;
+    }
     for (int i = tid; i < 2 * BNC; i += 512) {
         float a = 0.f;
 #pragma unroll 4
@@ -1194,7 +1226,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
 
     // (MOCA_EP_COLSUM / MOCA_EP_ROWSUM are only accepted without GEGLU / split-k: out_bn == BN; 256 x 272 B or 256 x 336 B of
     //  staged rows + the 32 x BN x 2 / 25 x BN x 2 floats of row-subset sums fit inside the 144 / 156 KiB ring)
-    if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * (BN * 2 + 16)), pitch, m0, n0, tile_m, tid);
+    if (p.flags & (MOCA_EP_COLSUM | MOCA_EP_GSTAT)) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * (BN * 2 + 16)), pitch, m0, n0, tile_m, tid);
     else if (p.flags & MOCA_EP_ROWSUM) store_fp16_tile_rowsum<512, BN, 4>(p, smem, pitch, TM, m0, n0, tid);
     else store_fp16_tile<512>(p, smem, pitch, TM, out_bn, m0, on0, tid);
     MOCA_STAMP(5);
@@ -2245,11 +2277,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
     } else if constexpr (WIDE) {
         if (p.flags & MOCA_EP_LN) store_fp16_tile_ln(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, tid);
-        else if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
+        else if (p.flags & (MOCA_EP_COLSUM | MOCA_EP_GSTAT)) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
         else if (p.flags & MOCA_EP_ROWSUM) store_fp16_tile_rowsum<512, BN, 8>(p, smem, pitch, TM, m0, n0, tid);
         else store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
     } else {
-        if (p.flags & MOCA_EP_COLSUM) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
+        if (p.flags & (MOCA_EP_COLSUM | MOCA_EP_GSTAT)) store_fp16_tile_colsum<TM, BN>(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, n0, tile_m, tid);
         else if (p.flags & MOCA_EP_ROWSUM) store_fp16_tile_rowsum<512, BN, 4>(p, smem, pitch, TM, m0, n0, tid);
         else store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
     }
@@ -2344,7 +2376,7 @@ static inline bool w80s_wide(const moca_gemm_params& p) {
     return p.a_mode == MOCA_A_LINEAR || mode == 2;
 }
 static inline bool takes_w80t_ln(const moca_gemm_params& p) {     // the 160 x 320 tiling with the LayerNorm store loop
-    return p.a_mode == MOCA_A_LINEAR && p.N == 320 && p.splits == 1 && takes_w80s(p) && !(p.flags & MOCA_EP_COLSUM);
+    return p.a_mode == MOCA_A_LINEAR && p.N == 320 && p.splits == 1 && takes_w80s(p) && !(p.flags & (MOCA_EP_COLSUM | MOCA_EP_GSTAT));
 }
 
 int launch_gemm_w80_mode(const moca_gemm_params& p, bool fastp, hipStream_t st) {
@@ -2457,14 +2489,14 @@ static int colsum_rows(const moca_gemm_params& p) {
 
 // columns per column tile of the row sums a MOCA_EP_ROWSUM launch leaves behind (0: this call cannot)
 static int rowsum_cols(const moca_gemm_params& p) {
-    if (p.splits != 1 || (p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_LN | MOCA_EP_GELU | MOCA_FORCE_SMALL_TILE))) return 0;
+    if (p.splits != 1 || (p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_GSTAT | MOCA_EP_LN | MOCA_EP_GELU | MOCA_FORCE_SMALL_TILE))) return 0;
     if (takes_w80s(p)) return w80s_wide(p) ? 320 : 160;
     return takes_glds_bn(p);
 }
 // does the kernel this call runs on have the MOCA_EP_LNFOLD epilogue?
 static bool lnfold_ok(const moca_gemm_params& p) {
     if (p.a_mode != MOCA_A_LINEAR || p.splits != 1) return false;
-    if (p.flags & (MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_LN | MOCA_EP_ROWSUM | MOCA_EP_GELU | MOCA_FORCE_SMALL_TILE)) return false;
+    if (p.flags & (MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_GSTAT | MOCA_EP_LN | MOCA_EP_ROWSUM | MOCA_EP_GELU | MOCA_FORCE_SMALL_TILE)) return false;
     if (takes_w80(p)) return !(p.flags & MOCA_EP_GEGLU) && takes_w80s(p);
     const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
     if (!(big_bn != 0 && p.M > 128)) return false;
@@ -2563,6 +2595,11 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     const bool use_w80 = takes_w80(p);
     if ((p.flags & MOCA_EP_COLSUM) && !(p.colsum && colsum_rows(p) != 0)) return MOCA_E_BADARG;   // ask moca_gemm_colsum_rows() first
     if ((p.flags & MOCA_EP_LN) && !(p.ln_gamma && p.ln_beta && p.ln_out && p.ld_ln % 8 == 0 && takes_w80t_ln(p))) return MOCA_E_BADARG;   // ask moca_gemm_ln_ok() first
+    if (p.flags & MOCA_EP_GSTAT) {                    // same kernels as MOCA_EP_COLSUM; a row tile must lie inside one statistics group
+        const int rows = colsum_rows(p);
+        if (!(p.gstat && rows != 0 && !(p.flags & MOCA_EP_COLSUM) && p.gstat_rows > 0 && p.gstat_rows % rows == 0 && p.M % p.gstat_rows == 0 &&
+              p.N % 32 == 0)) return MOCA_E_BADARG;
+    }
     if ((p.flags & MOCA_EP_ROWSUM) && !(p.rowsum && rowsum_cols(p) != 0)) return MOCA_E_BADARG;             // ask moca_gemm_rowsum_cols() first
     if ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1 && lnfold_ok(p))) return MOCA_E_BADARG;   // ask moca_gemm_lnfold_ok() first
     if (use_w80) {

@@ -182,6 +182,70 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
     }
 }
 
+// ---- K3': apply with the statistics a MOCA_EP_GSTAT producer accumulated: gstat f64 [statistics group][32][2] = (sum, sum of
+// squares), finished.  The first 32 threads of a block turn its statistics group's 32 pairs into (mean, rstd) in fp64 while the
+// block's first batch of x loads is in flight; no finalize launch exists.
+__global__ void gn_apply_gstat_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const double* __restrict__ gstat, int HW, int C, int nchunk,
+                                      int frames_per_stat, double inv_count, float eps, int silu) {
+    __shared__ float s_mr[2 * GN_GROUPS];
+    const int f = blockIdx.x, chunk = blockIdx.y;
+    const int cx = threadIdx.x, py = threadIdx.y, ppb = blockDim.y;
+    const int tid = py * blockDim.x + cx;
+    const int pc = (HW + nchunk - 1) / nchunk;
+    const int p_begin = chunk * pc, p_end = min(p_begin + pc, HW);
+    if (p_begin >= p_end) return;
+    const int cpg = C / GN_GROUPS;
+    const int sg = f / frames_per_stat;
+    const int64_t off = ((int64_t)f * HW) * C + cx * 8;
+    auto load4 = [&](half8v (&v)[4], int pp) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8v*>(x + off + (int64_t)min(pp + u * ppb, p_end - 1) * C);
+    };
+    int pp = p_begin + py;
+    half8v cur[4], nxt[4];
+    load4(cur, pp);
+    if (tid < GN_GROUPS) {
+        const double a = gstat[((int64_t)sg * GN_GROUPS + tid) * 2], b = gstat[((int64_t)sg * GN_GROUPS + tid) * 2 + 1];
+        const double mean = a * inv_count;
+        double var = b * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mr[2 * tid] = (float)mean;
+        s_mr[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cx * 8 + j;
+        const int g = c / cpg;
+        sc[j] = s_mr[2 * g + 1] * gamma[c];
+        sh[j] = beta[c] - s_mr[2 * g] * sc[j];
+    }
+    auto norm8 = [&](const half8v& v) {
+        half8v o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = (float)v[j] * sc[j] + sh[j];
+            if (silu) a = moca_silu(a);
+            o[j] = (half_t)a;
+        }
+        return o;
+    };
+    for (; pp < p_end; pp += 4 * ppb) {
+        const bool more = pp + 4 * ppb < p_end;
+        if (more) load4(nxt, pp + 4 * ppb);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (pp + u * ppb < p_end) *reinterpret_cast<half8v*>(y + off + (int64_t)(pp + u * ppb) * C) = norm8(cur[u]);
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+        }
+    }
+}
+
 // ---- single-launch GroupNorm for small tensors ------------------------------------
 // A statistics slab = (statistics group sg, channel group g): R = frames_per_stat*HW consecutive rows x cpg channels.
 // S blocks share one slab: each of them reduces the WHOLE slab (redundantly -- a slab is at most a few hundred KB and
@@ -414,6 +478,25 @@ extern "C" int moca_groupnorm_colsum_f16(const void* x, void* y, const float* ga
     const dim3 grid(F, nchunk), block(nch8, ppb);
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, reinterpret_cast<const half_t*>(x), reinterpret_cast<half_t*>(y),
                        gamma, beta, meanrstd, HW, C, nchunk, frames_per_stat, silu);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gamma, const float* beta, const double* gstat,
+                                        int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
+                                        float eps, int32_t silu, void* stream) {
+    if (!x || !y || !gamma || !beta || !gstat) return MOCA_E_BADARG;
+    if (F <= 0 || HW <= 0 || C <= 0 || C % 8 || C % GN_GROUPS || frames_per_stat <= 0 || F % frames_per_stat) return MOCA_E_BADARG;
+    const int nch8 = C / 8;
+    if (nch8 > 1024) return MOCA_E_BADARG;
+    int ppb = 256 / nch8;
+    if (ppb < 1) ppb = 1;
+    if (nch8 * ppb < GN_GROUPS) return MOCA_E_BADARG;                     // (the first 32 threads of a block finish the statistics)
+    const int nchunk = gn_nchunk(F, HW);
+    const double inv_count = 1.0 / ((double)frames_per_stat * HW * (C / GN_GROUPS));
+    const dim3 grid(F, nchunk), block(nch8, ppb);
+    hipLaunchKernelGGL(gn_apply_gstat_kernel, grid, block, 0, moca_stream(stream), reinterpret_cast<const half_t*>(x),
+                       reinterpret_cast<half_t*>(y), gamma, beta, gstat, HW, C, nchunk, frames_per_stat, inv_count, eps, silu);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

@@ -82,4 +82,10 @@ extern "C" int moca_device_info(char* name, int32_t len, int32_t* cu_count) {
     return MOCA_OK;
 }
 
+extern "C" int moca_memset_zero(void* ptr, int64_t bytes, void* stream) {
+    if (!ptr || bytes < 0) return MOCA_E_BADARG;
+    if (bytes == 0) return MOCA_OK;
+    return hipMemsetAsync(ptr, 0, (size_t)bytes, moca_stream(stream)) == hipSuccess ? MOCA_OK : MOCA_E_LAUNCH;
+}
+
 extern "C" const char* moca_version(void) { return "moca_hip 0.1 (gfx950)"; }

@@ -132,7 +132,7 @@ def finish_lnfold(pw: PackedWeight) -> PackedWeight:
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
                  residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None,
-                 force_small=False, rowsum=None, lnfold=None):
+                 force_small=False, rowsum=None, lnfold=None, gstat=None):
     p = _l.GemmParams()
     p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), (out.data_ptr() if out is not None else None)
     p.bias = pw.bias.data_ptr() if pw.bias is not None else None
@@ -165,6 +165,10 @@ def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR
     if rowsum is not None:                   # f32 [N / cols][M][2] (cols = gemm_rowsum_cols), or True when only probing
         p.flags |= _l.MOCA_EP_ROWSUM
         p.rowsum = rowsum.data_ptr() if torch.is_tensor(rowsum) else None
+    if gstat is not None:                    # (f64 [M / rows][32][2] accumulators, zeroed before the launch; rows per statistics group)
+        p.flags |= _l.MOCA_EP_GSTAT
+        p.gstat = gstat[0].data_ptr()
+        p.gstat_rows = gstat[1]
     if lnfold is not None:                   # (row partials f32 [nparts][M][2] or None when only probing, nparts, eps); pw.wsum required
         p.flags |= _l.MOCA_EP_LNFOLD
         p.lnf_part = lnfold[0].data_ptr() if lnfold[0] is not None else None
@@ -221,6 +225,18 @@ def groupnorm_colsum(x, y, gamma, beta, colsum, *, tile_rows, F, HW, Cn, frames_
                                                  frames_per_stat, eps, 1 if silu else 0, _l.ptr(ws), _st()),
              "moca_groupnorm_colsum_f16")
     return y
+
+
+def groupnorm_gstat(x, y, gamma, beta, gstat, *, F, HW, Cn, frames_per_stat, eps, silu):
+    """GroupNorm whose statistics the producing GEMM accumulated (MOCA_EP_GSTAT): one launch"""
+    _l.check(_l.load().moca_groupnorm_gstat_f16(_l.ptr(x), _l.ptr(y), _l.ptr(gamma), _l.ptr(beta), _l.ptr(gstat), F, HW, Cn,
+                                                frames_per_stat, eps, 1 if silu else 0, _st()), "moca_groupnorm_gstat_f16")
+    return y
+
+
+def memset_zero(t):
+    _l.check(_l.load().moca_memset_zero(_l.ptr(t), t.numel() * t.element_size(), _st()), "moca_memset_zero")
+    return t
 
 
 def groupnorm_ws_floats(F, HW, Cn):

@@ -77,6 +77,7 @@ class _PlanBase:
         self.graph = None
         self.graph_failed = False
         self.n_runs = 0
+        self._gstat_buf, self._gstat_used, self._last_gemm_step = None, 0, None
 
     def close(self):
         """release the instantiated hipGraph (moca_graph_destroy); the plan falls back to eager launches if used again"""
@@ -123,6 +124,7 @@ class _PlanBase:
             rows = ops.gemm_colsum_rows(a, pw, M=M, splits=splits, **kw)
             if rows > 0:
                 cs = (self.pool.get((M + rows - 1) // rows, 2 * pw.N, torch.float32), rows)
+        self._last_gemm_step = len(self.steps)
         self._emit(ops.gemm, a, pw, out, M=M, splits=splits, splitk_ws=ws, colsum=None if cs is None else cs[0], **kw)
         if ws is not None:
             self.pool.put(ws)
@@ -142,12 +144,12 @@ class _PlanBase:
         M = fm.F * oH * oW
         out, cs = self._gemm(fm.buf, pw, M, mode=_l.MOCA_A_CONV3X3, conv=(fm.C, fm.H, fm.W, oH, oW, stride, up),
                              rowadd=rowadd, rowadd_div=rowadd_div, residual=residual, want_colsum=True)
-        return _FMap(out, fm.F, oH, oW, pw.N, cs)
+        return _FMap(out, fm.F, oH, oW, pw.N, cs, src=self._last_gemm_step if cs is not None else None)
 
     def tconv(self, fm, pw, residual=None):
         out, cs = self._gemm(fm.buf, pw, fm.M, mode=_l.MOCA_A_TCONV3, tconv=(fm.C, self.T, fm.H * fm.W), residual=residual,
                              want_colsum=True)
-        return _FMap(out, fm.F, fm.H, fm.W, pw.N, cs)
+        return _FMap(out, fm.F, fm.H, fm.W, pw.N, cs, src=self._last_gemm_step if cs is not None else None)
 
     def gn(self, fm, gb, *, fps, eps, silu):
         """GroupNorm(32) (+SiLU).  With `fm.colsum` (left by the producing GEMM) and row tiles that do not straddle frames the
@@ -156,7 +158,20 @@ class _PlanBase:
         HW = fm.H * fm.W
         ws = self.pool.get(1, ops.groupnorm_ws_floats(fm.F, HW, fm.C), torch.float32)
         cs = fm.colsum
-        if cs is not None and (fps * HW) % cs[1] == 0:      # no row tile straddles two statistics groups
+        if cs is not None and (fps * HW) % cs[1] == 0 and fm.src is not None and os.environ.get("MOCA_GN_GSTAT", "1") != "0":
+            # the producer is re-targeted: instead of per-tile column sums it accumulates the FINISHED statistics of this
+            # GroupNorm (f64 atomics per (statistics group, channel group), MOCA_EP_GSTAT) -- no finalize launch
+            prod = self.steps[fm.src]
+            slot = self._gstat_slot((fm.F // fps) * 64)
+            kw = dict(prod.keywords)
+            kw["colsum"] = None
+            kw["gstat"] = (slot, fps * HW)
+            self.steps[fm.src] = functools.partial(prod.func, *prod.args, **kw)
+            self.pool.put(cs[0])
+            fm.colsum = None
+            self._emit(ops.groupnorm_gstat, fm.buf, y, gb[0], gb[1], slot, F=fm.F, HW=HW, Cn=fm.C, frames_per_stat=fps,
+                       eps=eps, silu=silu)
+        elif cs is not None and (fps * HW) % cs[1] == 0:      # no row tile straddles two statistics groups
             self._emit(ops.groupnorm_colsum, fm.buf, y, gb[0], gb[1], cs[0], tile_rows=cs[1], F=fm.F, HW=HW, Cn=fm.C,
                        frames_per_stat=fps, eps=eps, silu=silu, ws=ws)
         else:
@@ -164,6 +179,17 @@ class _PlanBase:
                        eps=eps, silu=silu, ws=ws)
         self.pool.put(ws)
         return y
+
+    def _gstat_slot(self, n_doubles):
+        """f64 accumulators of one GEMM -> GroupNorm pair, carved from ONE buffer that a single memset zeroes at the start of
+        every run (_run_steps)"""
+        if self._gstat_buf is None:
+            self._gstat_buf = torch.zeros(1 << 21, dtype=torch.float64, device=self.device)      # 16 MiB
+        if self._gstat_used + n_doubles > self._gstat_buf.numel():
+            raise RuntimeError("moca_video_amd: GroupNorm statistics buffer exhausted")
+        s = self._gstat_buf[self._gstat_used:self._gstat_used + n_doubles]
+        self._gstat_used += n_doubles
+        return s
 
     def _drop_colsum(self, fm):
         """the statistics buffer of a feature map goes back to the pool once its GroupNorm consumer has been recorded"""
@@ -177,6 +203,8 @@ class _PlanBase:
         return y
 
     def _run_steps(self):
+        if self._gstat_used:
+            ops.memset_zero(self._gstat_buf[:self._gstat_used])
         for s in self.steps:
             s()
 
@@ -405,7 +433,7 @@ class _Plan(_PlanBase):
             h, l = self.tblock(blk, h, l, x.M, mod.inner, mod.heads, spatial, x.F, x.H * x.W, next_gb=nxt, next_consumer=ncons)
         out, cs = self.linear(h, x.M, P[id(mod.proj_out)], residual=x.buf, want_colsum=True)
         self._release(h)
-        return _FMap(out, x.F, x.H, x.W, x.C, cs)
+        return _FMap(out, x.F, x.H, x.W, x.C, cs, src=self._last_gemm_step if cs is not None else None)
 
     def run_seq(self, seq, h):
         """TimestepEmbedSequential.forward, openaimodel3d.py:36-48"""

@@ -180,10 +180,11 @@ class _Pool:
 class _FMap:
     """channels-last feature map: buf [F*H*W][C] fp16; `colsum` = (f32 [row tiles][C][2] buffer, rows per tile) when the
     GEMM that produced it also left per-(row tile, channel) sums and sums of squares behind (GroupNorm statistics)"""
-    __slots__ = ("buf", "F", "H", "W", "C", "colsum")
+    __slots__ = ("buf", "F", "H", "W", "C", "colsum", "src")
 
-    def __init__(self, buf, F, H, W, C, colsum=None):
+    def __init__(self, buf, F, H, W, C, colsum=None, src=None):
         self.buf, self.F, self.H, self.W, self.C, self.colsum = buf, F, H, W, C, colsum
+        self.src = src          # index of the recorded GEMM launch that produced buf (with colsum): plan.gn() may re-target it
 
     @property
     def M(self):

@@ -202,6 +202,19 @@ def test_gemm_colsum_feeds_groupnorm(mode, Fr, HW, C, N, fps, with_res):
     xr = out.float().view(Fr // fps, fps * HW, N).permute(0, 2, 1)
     gref = F.silu(F.group_norm(xr, 32, g, be, 1e-5)).permute(0, 2, 1).reshape(Fr * HW, N)
     check(y, gref, TOL16, f"groupnorm from column sums ({mode})")
+    # MOCA_EP_GSTAT: the same launch accumulating the FINISHED statistics (f64 atomics per (statistics group, channel group));
+    # the GroupNorm is then a single apply launch
+    n_sg = Fr // fps
+    gst = torch.zeros(n_sg * 64, dtype=torch.float64, device=DEV)
+    out2 = torch.empty_like(out)
+    ops.gemm(a, pw, out2, M=M, residual=res, gstat=(gst, fps * HW), **kw)
+    assert torch.equal(out2, out)
+    xg = out.float().view(n_sg, fps * HW, 32, N // 32)
+    gs = gst.view(n_sg, 32, 2).float()
+    assert relerr(gs[..., 0], xg.sum(dim=(1, 3))) < 1e-3 and relerr(gs[..., 1], (xg * xg).sum(dim=(1, 3))) < 1e-3
+    y3 = torch.full_like(y, float("nan"))
+    ops.groupnorm_gstat(out, y3, g, be, gst, F=Fr, HW=HW, Cn=N, frames_per_stat=fps, eps=1e-5, silu=True)
+    check(y3, gref, TOL16, f"groupnorm from accumulated statistics ({mode})")
     # a shape the 320-row kernel does not take reports 0 (the plan then keeps the three-launch GroupNorm)
     assert ops.gemm_colsum_rows(rnd(100, 64), ops.pack_linear(rnd(128, 64), None), M=100) == 0
 
