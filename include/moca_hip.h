@@ -159,6 +159,11 @@ int moca_groupnorm_colsum_f16(const void* x, void* y, const float* gamma, const 
 int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gamma, const float* beta, const double* gstat,
                              int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
                              float eps, int32_t silu, void* stream);
+/* torch.cat([a, b], dim=channels) (openaimodel3d.py:571) of a [F*HW][C1] and b [F*HW][C2] that also ADDS the GroupNorm
+ * statistics of its output to gstat (as MOCA_EP_GSTAT; zero before the launch): the ResBlock.in_layers GroupNorm that
+ * follows (openaimodel3d.py:149) is then one moca_groupnorm_gstat_f16 launch.                                        */
+int moca_concat_channels_gstat_f16(const void* a, const void* b, void* out, int32_t F, int32_t HW, int32_t C1, int32_t C2,
+                                   int32_t frames_per_stat, double* gstat, void* stream);
 /* hipMemsetAsync(ptr, 0, bytes) on the stream (the MOCA_EP_GSTAT accumulators of a forward are zeroed by one call) */
 int moca_memset_zero(void* ptr, int64_t bytes, void* stream);
 

@@ -246,6 +246,61 @@ __global__ void gn_apply_gstat_kernel(const half_t* __restrict__ x, half_t* __re
     }
 }
 
+// ---- torch.cat(dim=channels) that also leaves the GroupNorm statistics of its output behind (openaimodel3d.py:571 followed by
+// ResBlock.in_layers[0], :149): the copy is a streaming pass over both inputs anyway; every thread owns 8 fixed channels of
+// the concatenated row, accumulates their sums / sums of squares over its pixels, the block combines them per channel group
+// through LDS and adds them to gstat (f64 atomics, as MOCA_EP_GSTAT) -- the consumer GroupNorm is then one apply launch instead
+// of partial + finalize + apply.  blockDim = (C/8, ppb), grid (F, nchunk) as the GroupNorm passes. ----
+__global__ void concat_gstat_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, half_t* __restrict__ out,
+                                    double* __restrict__ gstat, int HW, int C1, int C2, int nchunk, int frames_per_stat) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int C = C1 + C2;
+    float* s_sum = reinterpret_cast<float*>(smem_raw);   // [ppb][C]
+    float* s_sq = s_sum + blockDim.y * C;                 // [ppb][C]
+    const int f = blockIdx.x, chunk = blockIdx.y;
+    const int cx = threadIdx.x, py = threadIdx.y, ppb = blockDim.y;
+    const int pc = (HW + nchunk - 1) / nchunk;
+    const int p_begin = chunk * pc, p_end = min(p_begin + pc, HW);
+    const bool from_a = cx * 8 < C1;
+    const half_t* src = from_a ? a + ((int64_t)f * HW) * C1 + cx * 8 : b + ((int64_t)f * HW) * C2 + (cx * 8 - C1);
+    const int ld = from_a ? C1 : C2;
+    half_t* dst = out + ((int64_t)f * HW) * C + cx * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    int pp = p_begin + py;
+    for (; pp + 3 * ppb < p_end; pp += 4 * ppb) {
+        half8v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8v*>(src + (int64_t)(pp + u * ppb) * ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            *reinterpret_cast<half8v*>(dst + (int64_t)(pp + u * ppb) * C) = v[u];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float t = (float)v[u][j]; s[j] += t; q[j] += t * t; }
+        }
+    }
+    for (; pp < p_end; pp += ppb) {
+        const half8v v = *reinterpret_cast<const half8v*>(src + (int64_t)pp * ld);
+        *reinterpret_cast<half8v*>(dst + (int64_t)pp * C) = v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = (float)v[j]; s[j] += t; q[j] += t * t; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s_sum[py * C + cx * 8 + j] = s[j]; s_sq[py * C + cx * 8 + j] = q[j]; }
+    __syncthreads();
+    const int tid = py * blockDim.x + cx;
+    if (tid < 2 * GN_GROUPS) {
+        const int g = tid >> 1, comp = tid & 1;
+        const int cpg = C / GN_GROUPS;
+        const float* base = comp ? s_sq : s_sum;
+        float t = 0.f;
+        for (int y = 0; y < ppb; ++y)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) t += base[y * C + c];
+        atomicAdd(gstat + ((int64_t)(f / frames_per_stat) * GN_GROUPS + g) * 2 + comp, (double)t);
+    }
+}
+
 // ---- single-launch GroupNorm for small tensors ------------------------------------
 // A statistics slab = (statistics group sg, channel group g): R = frames_per_stat*HW consecutive rows x cpg channels.
 // S blocks share one slab: each of them reduces the WHOLE slab (redundantly -- a slab is at most a few hundred KB and
@@ -497,6 +552,25 @@ extern "C" int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gam
     const dim3 grid(F, nchunk), block(nch8, ppb);
     hipLaunchKernelGGL(gn_apply_gstat_kernel, grid, block, 0, moca_stream(stream), reinterpret_cast<const half_t*>(x),
                        reinterpret_cast<half_t*>(y), gamma, beta, gstat, HW, C, nchunk, frames_per_stat, inv_count, eps, silu);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_concat_channels_gstat_f16(const void* a, const void* b, void* out, int32_t F, int32_t HW, int32_t C1, int32_t C2,
+                                              int32_t frames_per_stat, double* gstat, void* stream) {
+    if (!a || !b || !out || !gstat || F <= 0 || HW <= 0 || C1 <= 0 || C2 <= 0 || C1 % 8 || C2 % 8) return MOCA_E_BADARG;
+    const int C = C1 + C2;
+    if (C % GN_GROUPS || frames_per_stat <= 0 || F % frames_per_stat) return MOCA_E_BADARG;
+    const int nch8 = C / 8;
+    if (nch8 > 1024) return MOCA_E_BADARG;
+    int ppb = 256 / nch8;
+    if (ppb < 1) ppb = 1;
+    if (nch8 * ppb < 2 * GN_GROUPS) return MOCA_E_BADARG;
+    const int nchunk = gn_nchunk(F, HW);
+    const size_t lds = (size_t)ppb * C * 2 * sizeof(float);
+    if (lds > 64 * 1024) return MOCA_E_BADARG;
+    hipLaunchKernelGGL(concat_gstat_kernel, dim3(F, nchunk), dim3(nch8, ppb), lds, moca_stream(stream), reinterpret_cast<const half_t*>(a),
+                       reinterpret_cast<const half_t*>(b), reinterpret_cast<half_t*>(out), gstat, HW, C1, C2, nchunk, frames_per_stat);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

@@ -59,6 +59,7 @@ SIGNATURES = {
     "moca_groupnorm_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "moca_groupnorm_gstat_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "moca_memset_zero": (C.c_int, [_vp, _i64, _vp]),
+    "moca_concat_channels_gstat_f16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "moca_layernorm_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "moca_attention_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "moca_attention_causal_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),

@@ -234,6 +234,13 @@ def groupnorm_gstat(x, y, gamma, beta, gstat, *, F, HW, Cn, frames_per_stat, eps
     return y
 
 
+def concat_channels_gstat(a, b, out, gstat, *, F, HW, C1, C2, frames_per_stat):
+    """torch.cat(dim=channels) + the GroupNorm statistics of the result added to gstat (f64 [F / frames_per_stat][32][2])"""
+    _l.check(_l.load().moca_concat_channels_gstat_f16(_l.ptr(a), _l.ptr(b), _l.ptr(out), F, HW, C1, C2, frames_per_stat,
+                                                      _l.ptr(gstat), _st()), "moca_concat_channels_gstat_f16")
+    return out
+
+
 def memset_zero(t):
     _l.check(_l.load().moca_memset_zero(_l.ptr(t), t.numel() * t.element_size(), _st()), "moca_memset_zero")
     return t

@@ -158,7 +158,10 @@ class _PlanBase:
         HW = fm.H * fm.W
         ws = self.pool.get(1, ops.groupnorm_ws_floats(fm.F, HW, fm.C), torch.float32)
         cs = fm.colsum
-        if cs is not None and (fps * HW) % cs[1] == 0 and fm.src is not None and os.environ.get("MOCA_GN_GSTAT", "1") != "0":
+        if fm.gstat is not None and fm.gstat[1] == fps:       # (the concat that produced fm accumulated the statistics)
+            self._emit(ops.groupnorm_gstat, fm.buf, y, gb[0], gb[1], fm.gstat[0], F=fm.F, HW=HW, Cn=fm.C, frames_per_stat=fps,
+                       eps=eps, silu=silu)
+        elif cs is not None and (fps * HW) % cs[1] == 0 and fm.src is not None and os.environ.get("MOCA_GN_GSTAT", "1") != "0":
             # the producer is re-targeted: instead of per-tile column sums it accumulates the FINISHED statistics of this
             # GroupNorm (f64 atomics per (statistics group, channel group), MOCA_EP_GSTAT) -- no finalize launch
             prod = self.steps[fm.src]
@@ -504,10 +507,20 @@ class _Plan(_PlanBase):
         for module in m.output_blocks:
             skip = hs.pop()
             cat = self.pool.get(h.M, h.C + skip.C)
-            self._emit(ops.concat_channels, h.buf, skip.buf, cat, rows=h.M, C1=h.C, C2=skip.C)   # torch.cat(dim=1), :571
+            gst = None
+            Cc = h.C + skip.C
+            if os.environ.get("MOCA_GN_GSTAT", "1") != "0" and os.environ.get("MOCA_CAT_GSTAT", "1") != "0" and \
+                    isinstance(module[0], _ResBlock) and Cc % 32 == 0 and \
+                    64 <= (Cc // 8) * max(1, 256 // (Cc // 8)) and Cc // 8 <= 1024:
+                # torch.cat(dim=1), :571, leaving the statistics of ResBlock.in_layers[0] (per-frame GroupNorm) behind
+                gst = (self._gstat_slot(h.F * 64), 1)
+                self._emit(ops.concat_channels_gstat, h.buf, skip.buf, cat, gst[0], F=h.F, HW=h.H * h.W, C1=h.C, C2=skip.C,
+                           frames_per_stat=1)
+            else:
+                self._emit(ops.concat_channels, h.buf, skip.buf, cat, rows=h.M, C1=h.C, C2=skip.C)   # torch.cat(dim=1), :571
             self._pinned.discard(skip.buf.data_ptr())
             self._release(h.buf, skip.buf)
-            h = self.run_seq(module, _FMap(cat, h.F, h.H, h.W, h.C + skip.C))
+            h = self.run_seq(module, _FMap(cat, h.F, h.H, h.W, Cc, gstat=gst))
         g = self.gn(h, P[id(m.out[0])], fps=1, eps=1e-5, silu=True)
         self._release(h.buf)
         self._drop_colsum(h)

@@ -508,3 +508,23 @@ def test_gemm_rowsum_feeds_lnfold(M, C, Kp, with_res, consumers, monkeypatch):
         out = torch.empty(M, n_out, dtype=torch.float16, device=DEV)
         ops.gemm(x, pwf, out, M=M, lnfold=(part, nparts, 1e-5))
         check(out, ref, TOL16, f"lnfold consumer {kind} N={n} (C={C}, {nparts} partials)")
+
+
+@pytest.mark.parametrize("Fr,HW,C1,C2", [(4, 100, 320, 320), (2, 2560, 640, 320), (3, 37, 1280, 1280), (2, 160, 1280, 640)])
+def test_concat_with_groupnorm_statistics(Fr, HW, C1, C2):
+    """torch.cat(dim=channels) that also accumulates the statistics of the GroupNorm that follows (openaimodel3d.py:571,149)"""
+    a, b = rnd(Fr * HW, C1) * 1.3 + 0.2, rnd(Fr * HW, C2) * 0.7 - 0.4
+    C = C1 + C2
+    out = torch.empty(Fr * HW, C, dtype=torch.float16, device=DEV)
+    gst = torch.zeros(Fr * 64, dtype=torch.float64, device=DEV)
+    ops.concat_channels_gstat(a, b, out, gst, F=Fr, HW=HW, C1=C1, C2=C2, frames_per_stat=1)
+    ref = torch.cat([a, b], dim=1)
+    assert torch.equal(out, ref)
+    xg = ref.float().view(Fr, HW, 32, C // 32)
+    gs = gst.view(Fr, 32, 2).float()
+    assert relerr(gs[..., 0], xg.sum(dim=(1, 3))) < 1e-3 and relerr(gs[..., 1], (xg * xg).sum(dim=(1, 3))) < 1e-3
+    g, be = rnd(C, dtype=torch.float32) * 0.2 + 1.0, rnd(C, dtype=torch.float32) * 0.2
+    y = torch.empty_like(out)
+    ops.groupnorm_gstat(out, y, g, be, gst, F=Fr, HW=HW, Cn=C, frames_per_stat=1, eps=1e-5, silu=True)
+    gref = F.silu(F.group_norm(ref.float().view(Fr, HW, C).permute(0, 2, 1), 32, g, be, 1e-5)).permute(0, 2, 1).reshape(Fr * HW, C)
+    check(y, gref, TOL16, "groupnorm of the concatenation")
