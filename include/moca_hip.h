@@ -59,6 +59,13 @@ extern "C" {
                            /* launch); moca_groupnorm_gstat_f16 then needs no finalize launch. */
                            /* Same kernels as MOCA_EP_COLSUM (moca_gemm_colsum_rows() > 0) and */
                            /* p.gstat_rows % that == 0                                         */
+#define MOCA_EP_TATTN  512 /* the fused to_q|to_k|to_v projection of a TemporalTransformer's    */
+                           /* self-attention FOLLOWED BY the attention over the frame axis      */
+                           /* (attention.py:92-114 inside :331-352): W rows are packed per head  */
+                           /* (64 q, 64 k, 64 v rows), an M tile = the 16 frames of 20 pixels,   */
+                           /* the block finishes softmax(q k^T * tattn_scale) v per pixel and    */
+                           /* writes only the attention output out[M][ldo >= N/3].  T == 16,     */
+                           /* HW % 20 == 0 (moca_gemm_tattn_ok()); may carry MOCA_EP_LNFOLD      */
 #define MOCA_EP_LNFOLD 128 /* the A operand is x, the linear wanted is Linear(LayerNorm(x)):  */
                            /* W is packed as W' = W * diag(ln weight), bias as b + W.ln_bias, */
                            /* p.lnf_wsum[n] = sum_k W'[n][k]; the epilogue computes           */
@@ -109,7 +116,7 @@ typedef struct moca_gemm_params {
     double*     gstat;     /* MOCA_EP_GSTAT: f64 [M / gstat_rows][32][2] accumulators (sum, sum of squares) per
                               (statistics group, GroupNorm channel group of N / 32 columns)                             */
     int32_t     gstat_rows;/* rows per statistics group (frames_per_stat * H*W of the consumer's GroupNorm)             */
-    int32_t     reserved3_;
+    float       tattn_scale;/* MOCA_EP_TATTN: softmax scale (dim_head ** -0.5); frames / pixels per frame in T / HW     */
 } moca_gemm_params;
 
 /* Replaces F.conv2d 3x3 (openaimodel3d.py:152,177,66-70,96-106,376,531),
@@ -132,6 +139,9 @@ int moca_gemm_rowsum_cols(const moca_gemm_params* p);
 /* 1 when this call's kernel has the MOCA_EP_LNFOLD epilogue (a plain or GEGLU linear on the staggered, 256-row or
  * two-blocks-per-CU kernel, fp16 output, no split-K); else 0 (the caller then runs moca_layernorm_f16 first).           */
 int moca_gemm_lnfold_ok(const moca_gemm_params* p);
+/* 1 when this call can run as MOCA_EP_TATTN (linear, K % 64 == 0, N % 192 == 0, T == 16, HW % 20 == 0, M % (16 HW) == 0,
+ * no split-K / residual / row add); else 0 (the caller then runs the projection and moca_temporal_attention_f16).       */
+int moca_gemm_tattn_ok(const moca_gemm_params* p);
 /* bytes of split-K workspace moca_gemm_f16 needs for (M,N,splits) */
 int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits);
 

@@ -882,8 +882,9 @@ __device__ __forceinline__ void store_fp16_tile_rowsum(const moca_gemm_params& p
 //      pass (rows past M repeat the last row; their stores are skipped anyway). ----
 struct LnFoldRegs { float rs, rb, ws, b; };
 struct LnFoldRaw { float2 p0, p1; float ws, b; };
+// (`row` = the global A row of this thread's tile row: m0 + tid, or the gathered row of the temporal-attention tiling)
 template <int TM, int BN>
-__device__ __forceinline__ LnFoldRaw lnfold_issue(const moca_gemm_params& p, int m0, int n0, int tid) {
+__device__ __forceinline__ LnFoldRaw lnfold_issue(const moca_gemm_params& p, int row, int n0, int tid) {
     LnFoldRaw r = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
     if (p.reserved2_ & 1) return r;
     if (tid < BN) {
@@ -891,17 +892,17 @@ __device__ __forceinline__ LnFoldRaw lnfold_issue(const moca_gemm_params& p, int
         r.b = p.bias ? p.bias[n0 + tid] : 0.f;
     }
     if (tid < TM) {
-        const int m = min(m0 + tid, p.M - 1);
+        const int m = min(row, p.M - 1);
         r.p0 = *reinterpret_cast<const float2*>(p.lnf_part + (int64_t)m * 2);
         if (p.lnf_nparts > 1) r.p1 = *reinterpret_cast<const float2*>(p.lnf_part + ((int64_t)p.M + m) * 2);
     }
     return r;
 }
 template <int TM, int BN>
-__device__ __forceinline__ LnFoldRegs lnfold_finish(const moca_gemm_params& p, const LnFoldRaw& raw, int m0, int tid) {
+__device__ __forceinline__ LnFoldRegs lnfold_finish(const moca_gemm_params& p, const LnFoldRaw& raw, int row, int tid) {
     LnFoldRegs r = {0.f, 0.f, raw.ws, raw.b};
     if (tid < TM) {
-        const int m = min(m0 + tid, p.M - 1);
+        const int m = min(row, p.M - 1);
         float s = raw.p0.x + raw.p1.x, q = raw.p0.y + raw.p1.y;
         for (int i = 2; i < ((p.reserved2_ & 1) ? 0 : p.lnf_nparts); ++i) {
             const float2 v = *reinterpret_cast<const float2*>(p.lnf_part + ((int64_t)i * p.M + m) * 2);
@@ -1060,11 +1061,11 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     constexpr int NRD = 4 + NT;      // fragment reads per half k-tile
 
     LnFoldRaw lraw = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
-    if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, m0, n0, tid);
+    if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, m0 + tid, n0, tid);
     if (nk > 0) issue(kt_begin, 0);
     if (nk > 1) issue(kt_begin + 1, 1);
     LnFoldRegs lf = {0.f, 0.f, 0.f, 0.f};
-    if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, m0, tid);
+    if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, m0 + tid, tid);
     MOCA_STAMP(1);
     if (nk > 0) {
         wait_tile(nk > 1);
@@ -1392,10 +1393,10 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
 
     // ---- prologue: pair (0, 1) ----
     LnFoldRaw lraw = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
-    if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, m0, n0, tid);
+    if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, m0 + tid, n0, tid);
     issue_pair(kt_begin, 0, 1);
     LnFoldRegs lf = {0.f, 0.f, 0.f, 0.f};
-    if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, m0, tid);
+    if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, m0 + tid, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int i = 0; i < nk; i += 2) {
@@ -1987,11 +1988,11 @@ int launch_gemm_w80(const moca_gemm_params& p, hipStream_t st) {
 template <int AMODE, int SHAPE>
 __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_params p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the launch stub; __amdgpu_buffer_rsrc_t is a device-only type)
-    constexpr bool WIDE = SHAPE == 1, SQ = SHAPE == 2;
-    constexpr int MT = SQ ? 4 : 5, NT = SQ ? 8 : 5, KS = 32, RB = 64;
-    constexpr int WTM = 16 * MT, WTN = 16 * NT;          // wave tile: 80 x 80, or 64 x 128
-    constexpr int TM = SQ ? 256 : (WIDE ? 160 : 320), BN = SQ ? 256 : (WIDE ? 320 : 160);
-    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB;     // 30 KiB per k-tile (32 KiB for 256 x 256)
+    constexpr bool WIDE = SHAPE == 1, SQ = SHAPE == 2, TQ = SHAPE == 3;
+    constexpr int MT = SQ ? 4 : 5, NT = SQ ? 8 : (TQ ? 6 : 5), KS = 32, RB = 64;
+    constexpr int WTM = 16 * MT, WTN = 16 * NT;          // wave tile: 80 x 80, 64 x 128, or 80 x 96
+    constexpr int TM = SQ ? 256 : (WIDE ? 160 : 320), BN = SQ ? 256 : (WIDE ? 320 : (TQ ? 192 : 160));
+    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB;     // 30 KiB per k-tile (32 KiB for 256 x 256 and 320 x 192)
     constexpr int NS = 5;
     constexpr int PPW = 4;                               // DMA instructions per wave per k-tile (30 pieces + 2 repeats; 32 pieces)
     constexpr int NAP = SQ ? 2 : (WIDE ? 2 : 3);
@@ -2027,7 +2028,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     const bool flex_is_big = wave < 4;
     const int kt_last_pair = kt_begin + nk - 2;
     BGather<AMODE, NAP, KS> ga(p, lch, kt_begin, kt_last_pair);
-    const int small1 = wave < 6 ? 4 + wave : 2 + wave;    // j = 3
+    const int small1 = TQ ? 4 + wave : (wave < 6 ? 4 + wave : 2 + wave);    // j = 3 (320 x 192: 12 W pieces, no repeats)
+    // SHAPE 3 ("tq", MOCA_EP_TATTN): the rows of an M tile are the 16 frames of 20 neighbouring pixels of one video, gathered by
+    // row index -- tile row r = 16 * (pixel - pix0) + frame -- so that the block holds q, k, v of one head for whole temporal
+    // sequences and finishes the temporal attention (attention.py:331-352) in its epilogue.  A DMA piece (16 tile rows) = the 16
+    // frames of one pixel.
+    const int tq_tpv = TQ ? p.HW / 20 : 1;                                   // row tiles per video
+    const int tq_b = tile_m / tq_tpv, tq_pb = tile_m - tq_b * tq_tpv;
+    auto grow = [&](int tr) -> int { return TQ ? (tq_b * 16 + (tr & 15)) * p.HW + tq_pb * 20 + (tr >> 4) : m0 + tr; };
     unsigned w_off[3];
     if constexpr (SQ) {                                  // A pieces w and 8 + w, W pieces w and 8 + w
         ga.init_row(0, m0 + wave * 16 + lrow);
@@ -2037,7 +2045,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         w_off[2] = 0;
     } else if constexpr (!WIDE) {
 #pragma unroll
-        for (int g = 0; g < NAP; ++g) ga.init_row(g, m0 + (g < 2 ? g * 8 + wave : 16 + (wave & 3)) * 16 + lrow);
+        for (int g = 0; g < NAP; ++g) ga.init_row(g, grow((g < 2 ? g * 8 + wave : 16 + (wave & 3)) * 16 + lrow));
         w_off[0] = (unsigned)(((int64_t)(n0 + (wave & 3) * 16 + lrow) * p.ldw + lch * 8) * 2);      // j = 2 (waves 4..7)
         w_off[1] = (unsigned)(((int64_t)(n0 + small1 * 16 + lrow) * p.ldw + lch * 8) * 2);           // j = 3
         w_off[2] = 0;
@@ -2123,13 +2131,13 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
 
     // ---- prologue: pairs (0,1) and (2,3) in flight, pair (0,1) landed everywhere ----
     LnFoldRaw lraw = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
-    if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, m0, n0, tid);
+    if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, grow(tid), n0, tid);
     ga.seek(kt_begin);
     issue_pair(0, 1);
     ga.advance();
     issue_pair(2, 3);
     LnFoldRegs lf = {0.f, 0.f, 0.f, 0.f};
-    if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, m0, tid);
+    if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, grow(tid), tid);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
     __builtin_amdgcn_s_barrier();
     if (late) __builtin_amdgcn_s_barrier();            // from here on waves 4..7 run one barrier behind waves 0..3
@@ -2273,7 +2281,53 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         }
     }
     __syncthreads();
-    if constexpr (SQ) {
+    if constexpr (TQ) {
+        // temporal attention of the 20 pixels of this tile for head tile_n: q | k | v = columns [0,64) | [64,128) | [128,192) of the
+        // staged fp16 rows, 16 frames per pixel.  One wavefront per pixel (pixels w, w + 8, w + 16); the arithmetic is that of
+        // temporal_attention_kernel (attention.hip): S^T = K.Q^T by v_mfma_f32_16x16x32_f16, softmax over the 16 keys in-lane
+        // + two cross-lane steps, O^T = V^T.P^T by v_mfma_f32_16x16x16_f16.  Only O (64 of the 192 columns) goes to memory.
+        const float sl2e = p.tattn_scale * 1.4426950408889634f;
+        half_t* outp = reinterpret_cast<half_t*>(p.out);
+        for (int pix = wave; pix < 20; pix += 8) {
+            const char* base = smem + (pix * 16) * pitch;
+            half8v kf[2], qf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                qf[ks] = *reinterpret_cast<const half8v*>(base + fr * pitch + (ks * 32 + fg * 8) * 2);
+                kf[ks] = *reinterpret_cast<const half8v*>(base + fr * pitch + (64 + ks * 32 + fg * 8) * 2);
+            }
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[0], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[1], sc, 0, 0, 0);
+            float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));          // lane: S^T[key = 4 fg + r][query = fr]
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+            half4v pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = exp2f((sc[r] - mx) * sl2e);
+                sum += pv;
+                pf[r] = (half_t)pv;
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+            half_t* ob = outp + (int64_t)grow(pix * 16 + fr) * p.ldo + tile_n * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                half4v vf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vf[j] = *reinterpret_cast<const half_t*>(base + (4 * fg + j) * pitch + (128 + dt * 16 + fr) * 2);
+                f32x4 o4 = {0.f, 0.f, 0.f, 0.f};
+                o4 = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, o4, 0, 0, 0);     // lane: O^T[d = 16 dt + 4 fg + r][query = fr]
+                half4v h4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h4[r] = (half_t)(o4[r] * inv);
+                *reinterpret_cast<half4v*>(ob + dt * 16 + 4 * fg) = h4;
+            }
+        }
+    } else if constexpr (SQ) {
         store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
     } else if constexpr (WIDE) {
         if (p.flags & MOCA_EP_LN) store_fp16_tile_ln(p, smem, reinterpret_cast<float*>(smem + TM * pitch), pitch, m0, tid);
@@ -2290,7 +2344,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
 
 template <int AMODE, int SHAPE>
 int launch_gemm_w80s(const moca_gemm_params& p, hipStream_t st) {
-    constexpr int TM = SHAPE == 2 ? 256 : (SHAPE == 1 ? 160 : 320), BN = SHAPE == 2 ? 256 : (SHAPE == 1 ? 320 : 160);
+    constexpr int TM = SHAPE == 2 ? 256 : (SHAPE == 1 ? 160 : 320), BN = SHAPE == 2 ? 256 : (SHAPE == 1 ? 320 : (SHAPE == 3 ? 192 : 160));
     const int tiles_m = (p.M + TM - 1) / TM, tiles_n = p.N / BN;
     const int nblk = tiles_m * tiles_n * p.splits;
     constexpr int lds = 5 * (TM + BN) * 64;              // 150 KiB (160 KiB for 256 x 256); the fp16 epilogue tile fits inside the ring
@@ -2508,6 +2562,26 @@ static bool lnfold_ok(const moca_gemm_params& p) {
     return !(p.flags & MOCA_EP_GEGLU);                  // the 256-row kernel: plain epilogue only
 }
 
+// MOCA_EP_TATTN: the q|k|v projection of a temporal self-attention with the attention finished in the epilogue (SHAPE 3 of the
+// staggered kernel: 320 x 192 tiles, rows = 16 frames x 20 pixels, columns = one head)
+static bool tattn_ok(const moca_gemm_params& p) {
+    if (p.a_mode != MOCA_A_LINEAR || p.splits != 1 || !fast_gather(p) || !buffer_addressable(p)) return false;
+    if (p.flags & ~(MOCA_EP_TATTN | MOCA_EP_LNFOLD)) return false;
+    if (p.residual || p.rowadd) return false;
+    if (p.N % 192 || p.T != 16 || p.HW <= 0 || p.HW % 20 || p.M % (16 * p.HW)) return false;
+    if (p.ldo % 4 || p.ldo < p.N / 3) return false;
+    return true;
+}
+
+extern "C" int moca_gemm_tattn_ok(const moca_gemm_params* pp) {
+    if (!pp) return 0;
+    moca_gemm_params p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
+    if (p.splits < 1) p.splits = 1;
+    p.flags |= MOCA_EP_TATTN;
+    return tattn_ok(p) ? 1 : 0;
+}
+
 extern "C" int moca_gemm_rowsum_cols(const moca_gemm_params* pp) {
     if (!pp) return 0;
     moca_gemm_params p = *pp;
@@ -2601,6 +2675,10 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
               p.N % 32 == 0)) return MOCA_E_BADARG;
     }
     if ((p.flags & MOCA_EP_ROWSUM) && !(p.rowsum && rowsum_cols(p) != 0)) return MOCA_E_BADARG;             // ask moca_gemm_rowsum_cols() first
+    if (p.flags & MOCA_EP_TATTN) {                    // ask moca_gemm_tattn_ok() first
+        if (!tattn_ok(p) || ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1))) return MOCA_E_BADARG;
+        return launch_gemm_w80s<MOCA_A_LINEAR, 3>(p, st);
+    }
     if ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1 && lnfold_ok(p))) return MOCA_E_BADARG;   // ask moca_gemm_lnfold_ok() first
     if (use_w80) {
         rc = launch_gemm_w80_mode(p, fastp, st);

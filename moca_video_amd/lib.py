@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MOCA_HIP_LIB") or os.path.join(_HERE, "libmoca_hip.so
 
 MOCA_A_LINEAR, MOCA_A_CONV3X3, MOCA_A_TCONV3 = 0, 1, 2
 MOCA_EP_GEGLU, MOCA_EP_OUT_F32, MOCA_FORCE_SMALL_TILE, MOCA_EP_GELU, MOCA_EP_COLSUM, MOCA_EP_LN = 1, 2, 4, 8, 16, 32
-MOCA_EP_ROWSUM, MOCA_EP_LNFOLD, MOCA_EP_GSTAT = 64, 128, 256
+MOCA_EP_ROWSUM, MOCA_EP_LNFOLD, MOCA_EP_GSTAT, MOCA_EP_TATTN = 64, 128, 256, 512
 
 _ERR = {0: "ok", -1: "bad argument (shape/alignment contract)", -2: "HIP launch/runtime error",
         -3: "no gfx950 device", -4: "graph capture/replay failed"}
@@ -41,7 +41,7 @@ class GemmParams(C.Structure):
         ("ld_ln", C.c_int32), ("ln_eps", C.c_float),
         ("rowsum", C.c_void_p), ("lnf_part", C.c_void_p), ("lnf_wsum", C.c_void_p),
         ("lnf_nparts", C.c_int32), ("reserved2_", C.c_int32),
-        ("gstat", C.c_void_p), ("gstat_rows", C.c_int32), ("reserved3_", C.c_int32),
+        ("gstat", C.c_void_p), ("gstat_rows", C.c_int32), ("tattn_scale", C.c_float),
     ]
 
 
@@ -54,6 +54,7 @@ SIGNATURES = {
     "moca_gemm_ln_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_rowsum_cols": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_lnfold_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "moca_gemm_tattn_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_groupnorm_colsum_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "moca_groupnorm_nhwc_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "moca_groupnorm_ws_bytes": (_i64, [_i32, _i32, _i32]),

@@ -132,7 +132,7 @@ def finish_lnfold(pw: PackedWeight) -> PackedWeight:
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
                  residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None,
-                 force_small=False, rowsum=None, lnfold=None, gstat=None):
+                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None):
     p = _l.GemmParams()
     p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), (out.data_ptr() if out is not None else None)
     p.bias = pw.bias.data_ptr() if pw.bias is not None else None
@@ -165,6 +165,9 @@ def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR
     if rowsum is not None:                   # f32 [N / cols][M][2] (cols = gemm_rowsum_cols), or True when only probing
         p.flags |= _l.MOCA_EP_ROWSUM
         p.rowsum = rowsum.data_ptr() if torch.is_tensor(rowsum) else None
+    if tattn is not None:                    # (T, HW, softmax scale): projection + temporal attention in one launch (MOCA_EP_TATTN)
+        p.flags |= _l.MOCA_EP_TATTN
+        p.T, p.HW, p.tattn_scale = tattn
     if gstat is not None:                    # (f64 [M / rows][32][2] accumulators, zeroed before the launch; rows per statistics group)
         p.flags |= _l.MOCA_EP_GSTAT
         p.gstat = gstat[0].data_ptr()
@@ -205,6 +208,24 @@ def gemm_lnfold_ok(a, pw: PackedWeight, **kw):
     """does the kernel this call runs on have the MOCA_EP_LNFOLD epilogue?"""
     p = _gemm_params(a, pw, None, **kw)
     return bool(_l.load().moca_gemm_lnfold_ok(C.byref(p)))
+
+
+def gemm_tattn_ok(a, pw: PackedWeight, **kw):
+    """can this call run as MOCA_EP_TATTN (fused q|k|v projection + temporal attention)?"""
+    p = _gemm_params(a, pw, None, **kw)
+    return bool(_l.load().moca_gemm_tattn_ok(C.byref(p)))
+
+
+def pack_qkv_per_head(wq, wk, wv, heads, bias=None, device="cuda"):
+    """to_q | to_k | to_v of a self-attention re-ordered per head for MOCA_EP_TATTN: rows [64 q_h, 64 k_h, 64 v_h] for h = 0..heads-1
+    (weights [heads*64][K] each, or already LayerNorm-folded; `bias` = the folded bias in the plain q|k|v order or None)"""
+    C_ = wq.shape[0]
+    assert C_ == heads * 64 and wk.shape[0] == C_ and wv.shape[0] == C_
+    w = torch.stack([wq.reshape(heads, 64, -1), wk.reshape(heads, 64, -1), wv.reshape(heads, 64, -1)], dim=1).reshape(3 * C_, -1)
+    b = None
+    if bias is not None:
+        b = torch.stack([bias[:C_].reshape(heads, 64), bias[C_:2 * C_].reshape(heads, 64), bias[2 * C_:].reshape(heads, 64)], dim=1).reshape(-1)
+    return _finish(w, b, device)
 
 
 def gemm_colsum_rows(a, pw: PackedWeight, **kw):

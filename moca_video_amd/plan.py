@@ -329,8 +329,52 @@ class _Plan(_PlanBase):
     def _release_ln(self, l):
         self._release(l.part if isinstance(l, _LNRef) else l)
 
+    def _tattn_pw(self, att, norm, heads, folded):
+        """to_q|to_k|to_v packed per head for MOCA_EP_TATTN (LayerNorm-folded when the input arrives as an _LNRef)"""
+        dev = self.device
+
+        def build():
+            wq, wk, wv = (m.weight.detach().to(dev) for m in (att.to_q, att.to_k, att.to_v))
+            if not folded:
+                return ops.pack_qkv_per_head(wq, wk, wv, heads, device=dev)
+            g, b = self.P[id(norm)]
+            wf, bf = ops.fold_layernorm(torch.cat([wq, wk, wv], dim=0), None, g, b)
+            c = wq.shape[0]
+            return ops.finish_lnfold(ops.pack_qkv_per_head(wf[:c], wf[c:2 * c], wf[2 * c:], heads, bias=bf, device=dev))
+        k = ("tqkv_fold" if folded else "tqkv", id(att))
+        if k not in self.P:
+            self.P[k] = build()
+        return self.P[k]
+
+    def _attn_temporal_fused(self, att, l, M, Cn, heads, HW, norm):
+        """q|k|v projection + attention over the frame axis in ONE launch (MOCA_EP_TATTN) where its 320-row tiles (16 frames x 20
+        pixels, one head) come in whole rounds of the chip; None -> the caller runs projection + temporal_attention.
+        MOCA_TATTN: 0 = never, 1 = only where the tile count is a multiple of 256 or >= 1024, 2 (default) = wherever the kernel applies
+        (same-device A/B of the whole CFG step: 37.2 / 36.4 / 36.0 ms -- the launch and the q|k|v round trip it removes outweigh the
+        partial last round of tiles at the 640- and 1280-channel levels)."""
+        mode = int(os.environ.get("MOCA_TATTN", "2"))
+        if mode == 0 or self.T != 16 or HW % 20:
+            return None
+        tiles = (M // 320) * heads
+        if mode == 1 and not (tiles % 256 == 0 or tiles >= 1024):
+            return None
+        folded = isinstance(l, _LNRef)
+        x = l.x if folded else l
+        pw = self._tattn_pw(att, norm, heads, folded)
+        scale = att.dim_head ** -0.5
+        kw = dict(M=M, lda=x.stride(-2), splits=1, tattn=(self.T, HW, scale))
+        if not ops.gemm_tattn_ok(x, pw, lnfold=(None, l.nparts, 1e-5) if folded else None, **kw):
+            return None
+        o = self.pool.get(M, Cn)
+        self._emit(ops.gemm, x, pw, o, lnfold=(l.part, l.nparts, 1e-5) if folded else None, **kw)
+        return o
+
     def _attn_self(self, att, l, M, Cn, heads, spatial, F, HW, norm=None):
         P = self.P
+        if not spatial:
+            o = self._attn_temporal_fused(att, l, M, Cn, heads, HW, norm)
+            if o is not None:
+                return o
         qkv = self.linear_of_ln(l, M, P[id(att)], lambda: self._fold_pw("qkv", att, norm))   # [M][3C] fused to_q|to_k|to_v
         o = self.pool.get(M, Cn)
         q, k, v = qkv[:, :Cn], qkv[:, Cn:2 * Cn], qkv[:, 2 * Cn:]

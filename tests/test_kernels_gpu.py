@@ -528,3 +528,35 @@ def test_concat_with_groupnorm_statistics(Fr, HW, C1, C2):
     ops.groupnorm_gstat(out, y, g, be, gst, F=Fr, HW=HW, Cn=C, frames_per_stat=1, eps=1e-5, silu=True)
     gref = F.silu(F.group_norm(ref.float().view(Fr, HW, C).permute(0, 2, 1), 32, g, be, 1e-5)).permute(0, 2, 1).reshape(Fr * HW, C)
     check(y, gref, TOL16, "groupnorm of the concatenation")
+
+
+# ---------------------------------------------------------------- q|k|v projection + temporal attention in one launch
+@pytest.mark.parametrize("B,HW,heads,K,fold", [(2, 640, 5, 320, False), (1, 1280, 5, 320, True), (2, 100, 8, 512, True), (1, 40, 20, 1280, False)])
+def test_gemm_temporal_attention_fused(B, HW, heads, K, fold):
+    """MOCA_EP_TATTN: to_q|to_k|to_v (packed per head) on tiles of 16 frames x 20 pixels with the attention over the frame axis
+    finished in the epilogue -- against the projection (fp16-rounded, as the two-launch path stores it) + temporal attention in
+    torch; with MOCA_EP_LNFOLD the input is x and the projection is Linear(LayerNorm(x))."""
+    T, C = 16, heads * 64
+    M = B * T * HW
+    x = rnd(M, K) * 1.5 + (0.3 if fold else 0.0)
+    wq, wk, wv = (rnd(C, K, scale=K ** -0.5) for _ in range(3))
+    scale = 0.125
+    if fold:
+        g, be = rnd(K, dtype=torch.float32) * 0.3 + 1.0, rnd(K, dtype=torch.float32) * 0.3
+        wf, bf = ops.fold_layernorm(torch.cat([wq, wk, wv]), None, g, be)
+        pw = ops.finish_lnfold(ops.pack_qkv_per_head(wf[:C], wf[C:2 * C], wf[2 * C:], heads, bias=bf))
+        xf = x.float()
+        part = torch.stack([xf.sum(1), (xf * xf).sum(1)], dim=1).contiguous()
+        a_in = F.layer_norm(xf, (K,), g, be, 1e-5)
+        kw = dict(lnfold=(part, 1, 1e-5))
+    else:
+        pw = ops.pack_qkv_per_head(wq, wk, wv, heads)
+        a_in = x.float()
+        kw = {}
+    assert ops.gemm_tattn_ok(x, pw, M=M, tattn=(T, HW, scale), **({"lnfold": (None, 1, 1e-5)} if fold else {}))
+    out = torch.full((M, C), float("nan"), dtype=torch.float16, device=DEV)
+    ops.gemm(x, pw, out, M=M, tattn=(T, HW, scale), **kw)
+    q, k, v = ((a_in @ w.float().t()).half().float().view(B, T, HW, heads, 64).permute(0, 2, 3, 1, 4) for w in (wq, wk, wv))   # [B,HW,h,T,64]
+    att = torch.softmax(torch.einsum("bphid,bphjd->bphij", q, k) * scale, dim=-1)
+    ref = torch.einsum("bphij,bphjd->bphid", att, v).permute(0, 3, 1, 2, 4).reshape(M, C)
+    check(out, ref, TOL16, f"fused qkv + temporal attention (heads={heads}, K={K}, fold={fold})")
