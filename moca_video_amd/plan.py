@@ -175,6 +175,7 @@ class _PlanBase:
             self._emit(ops.groupnorm_gstat, fm.buf, y, gb[0], gb[1], slot, F=fm.F, HW=HW, Cn=fm.C, frames_per_stat=fps,
                        eps=eps, silu=silu)
         elif cs is not None and (fps * HW) % cs[1] == 0:      # no row tile straddles two statistics groups
+            fm.cs_used = True
             self._emit(ops.groupnorm_colsum, fm.buf, y, gb[0], gb[1], cs[0], tile_rows=cs[1], F=fm.F, HW=HW, Cn=fm.C,
                        frames_per_stat=fps, eps=eps, silu=silu, ws=ws)
         else:
@@ -197,6 +198,11 @@ class _PlanBase:
     def _drop_colsum(self, fm):
         """the statistics buffer of a feature map goes back to the pool once its GroupNorm consumer has been recorded"""
         if fm.colsum is not None:
+            if not fm.cs_used and fm.src is not None:          # nobody read the column sums (the consumer was a conv / a concat /
+                prod = self.steps[fm.src]                      # a GroupNorm whose statistics groups the row tiles straddle):
+                kw = dict(prod.keywords)                       # the producer goes back to the plain store loop
+                kw["colsum"] = None
+                self.steps[fm.src] = functools.partial(prod.func, *prod.args, **kw)
             self.pool.put(fm.colsum[0])
             fm.colsum = None
 

@@ -180,12 +180,13 @@ class _Pool:
 class _FMap:
     """channels-last feature map: buf [F*H*W][C] fp16; `colsum` = (f32 [row tiles][C][2] buffer, rows per tile) when the
     GEMM that produced it also left per-(row tile, channel) sums and sums of squares behind (GroupNorm statistics)"""
-    __slots__ = ("buf", "F", "H", "W", "C", "colsum", "src", "gstat")
+    __slots__ = ("buf", "F", "H", "W", "C", "colsum", "src", "gstat", "cs_used")
 
     def __init__(self, buf, F, H, W, C, colsum=None, src=None, gstat=None):
         self.buf, self.F, self.H, self.W, self.C, self.colsum = buf, F, H, W, C, colsum
         self.src = src          # index of the recorded GEMM launch that produced buf (with colsum): plan.gn() may re-target it
         self.gstat = gstat      # (f64 accumulators, frames_per_stat) when the producer already accumulated finished statistics
+        self.cs_used = False    # a GroupNorm consumed the column sums (else the producer is re-recorded without them)
 
     @property
     def M(self):

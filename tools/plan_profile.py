@@ -41,12 +41,16 @@ with torch.cuda.stream(st):
                   (" +res" if kw.get("residual") is not None else "") + (" +rowadd" if kw.get("rowadd") is not None else "") + \
                   (f" splits={kw['splits']}" if kw.get("splits", 1) > 1 else "") + (" f32" if kw.get("out_f32") else "") + \
                   (" +colsum" if kw.get("colsum") is not None else "") + (" +LN" if kw.get("ln") is not None else "") + \
-                  (" +rowsum" if kw.get("rowsum") is not None else "") + (" lnfold" if kw.get("lnfold") is not None else "")
+                  (" +rowsum" if kw.get("rowsum") is not None else "") + (" lnfold" if kw.get("lnfold") is not None else "") + \
+                  (" +gstat" if kw.get("gstat") is not None else "") + (" +tattn" if kw.get("tattn") is not None else "")
             flop = 2.0 * kw["M"] * pw.N * pw.w.shape[1]
             if kw.get("conv") is not None and kw["conv"][6]:
                 pass
         elif fn == "groupnorm_colsum":
             key = f"groupnorm(colsum) F={kw['F']} HW={kw['HW']} C={kw['Cn']} fps={kw['frames_per_stat']}"
+            flop = 0
+        elif fn == "groupnorm_gstat":
+            key = f"groupnorm(gstat) F={kw['F']} HW={kw['HW']} C={kw['Cn']} fps={kw['frames_per_stat']}"
             flop = 0
         elif fn == "groupnorm":
             key = f"groupnorm F={kw['F']} HW={kw['HW']} C={kw['Cn']} fps={kw['frames_per_stat']}"
