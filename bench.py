@@ -373,6 +373,7 @@ def main():
         achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
     name, cus = mlib.device_info()
     traffic_bytes, traffic_src = traffic_from_profile()
+    n_launches = max([len(pl.steps) for pl in getattr(unet, "_plans", {}).values()] or [0])
     res = {
         "metric": "denoising UNet-steps/sec @16x320x512 fp16",
         "value": round(value, 3),
@@ -394,8 +395,10 @@ def main():
         "achieved_tflops": round(value / world * FLOP_PER_UNET_STEP / 1e12, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic_bytes if not concurrent else None, "traffic_source": traffic_src if not concurrent else None,
-                     "kernel": "UNet forward launch sequence (hipGraph of ~0.75k launches; the implicit-GEMM conv/linear kernels "
-                               "gemm_w80s/gemm_glds/gemm_g4 are 78% of it)" + (", two B=1 graphs on two streams" if concurrent else ", batch 2"),
+                     "kernel": "UNet forward launch sequence (hipGraph of %d launches; the implicit-GEMM conv/linear kernels "
+                               "gemm_w80s/gemm_glds/gemm_g4 are 80%% of its kernel time, "
+                               "profiles/r02_bench_kernel_stats_summary.txt)" % n_launches +
+                               (", two B=1 graphs on two streams" if concurrent else ", batch 2"),
                      "flop_per_launch": flop_per_launch, "avg_launch_ms": round(avg_launch_ms, 3), "launches": len(unet_ms)},
     }
     if world == 1 and not args.no_fifo:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-category summary of a rocprofv3 --kernel-trace --stats CSV of bench.py (forwards = warmup + steps)."""
-import csv, glob, sys
+import csv, glob, re, sys
 f = sys.argv[1]
 nfwd = float(sys.argv[2]) if len(sys.argv) > 2 else 6
 rows = list(csv.DictReader(open(f)))
@@ -9,8 +9,10 @@ for r in rows:
     n = r['Name']
     if any(x in n for x in ('distribution_elementwise', 'rocclr', 'FillFunctor', 'direct_copy', 'float16_copy', 'CatArray', 'index_', 'arange', 'gather_kernel', 'reduce_kernel', 'AbsFunctor', 'CompareEq', 'MulFunctor', 'CUDAFunctorOnSelf')):
         k = 'torch(init/host glue)'
-    elif 'gemm_w80s' in n and 'ELb1E' in n: k = 'gemm_w80s wide (160x320, +LN)'
-    elif 'gemm_w80s' in n: k = 'gemm_w80s (320x160, staggered)'
+    elif 'gemm_w80s' in n and re.search(r'<\d, 3>|ELi3EEE', n): k = 'gemm_w80s 320x192 (q|k|v + temporal attention)'
+    elif 'gemm_w80s' in n and re.search(r'<\d, 2>|ELi2EEE', n): k = 'gemm_w80s 256x256 (wide GEGLU)'
+    elif 'gemm_w80s' in n and re.search(r'<\d, 1>|ELi1EEE', n): k = 'gemm_w80s 160x320'
+    elif 'gemm_w80s' in n: k = 'gemm_w80s 320x160'
     elif 'gemm_w80' in n: k = 'gemm_w80/w80b (320x160)'
     elif 'gemm_g4' in n: k = 'gemm_g4 (GEGLU K<=640)'
     elif 'gemm_glds' in n: k = 'gemm_glds (256xBN)'
@@ -21,7 +23,9 @@ for r in rows:
     elif 'attention_kernel' in n: k = 'attention (short keys / causal)'
     elif 'gn_slab' in n: k = 'gn_slab (single launch)'
     elif 'gn_partial' in n: k = 'gn_partial'
+    elif 'gn_apply_gstat' in n: k = 'gn_apply (statistics from the producer)'
     elif 'gn_apply' in n: k = 'gn_apply'
+    elif 'concat_gstat' in n: k = 'concat + statistics'
     elif 'gn_finalize_colsum' in n: k = 'gn_finalize (from GEMM column sums)'
     elif 'gn_final' in n: k = 'gn_finalize'
     elif 'layernorm' in n: k = 'layernorm'
