@@ -117,6 +117,12 @@ typedef struct moca_gemm_params {
                               (statistics group, GroupNorm channel group of N / 32 columns)                             */
     int32_t     gstat_rows;/* rows per statistics group (frames_per_stat * H*W of the consumer's GroupNorm)             */
     float       tattn_scale;/* MOCA_EP_TATTN: softmax scale (dim_head ** -0.5); frames / pixels per frame in T / HW     */
+    uint32_t*   sk_sync;   /* two-piece split (sk_big > 0): 2 words per output tile, zero before the first launch; the
+                              launch leaves them zero                                                                 */
+    int32_t     sk_big;    /* > 0: every 256-row output tile is computed by TWO blocks, k-tiles [0, sk_big) and [sk_big, end);
+                              the first to finish leaves its fp32 partial sums in splitk_ws, the second adds them and runs
+                              the epilogue -- no reduce launch (what moca_gemm_two_piece() returned, with splits == 1)       */
+    int32_t     reserved4_;
 } moca_gemm_params;
 
 /* Replaces F.conv2d 3x3 (openaimodel3d.py:152,177,66-70,96-106,376,531),
@@ -142,6 +148,11 @@ int moca_gemm_lnfold_ok(const moca_gemm_params* p);
 /* 1 when this call can run as MOCA_EP_TATTN (linear, K % 64 == 0, N % 192 == 0, T == 16, HW % 20 == 0, M % (16 HW) == 0,
  * no split-K / residual / row add); else 0 (the caller then runs the projection and moca_temporal_attention_f16).       */
 int moca_gemm_tattn_ok(const moca_gemm_params* p);
+/* Launches of the 256-row kernel whose tile count leaves more than an eighth of the chip idle for a whole (long) tile time
+ * (e.g. 200 tiles on 256 CUs at M = 5120, N = 1280) can run as 2 x tiles blocks instead: returns sk_big (64-deep k-tiles of the
+ * first piece, chosen so that big and small pieces pack into tiles / CUs of a tile time under dynamic dispatch) or 0 when the
+ * call does not qualify; *ws_bytes = fp32 workspace needed (tiles x 256 x BN x 4), *sync_words = 2 x tiles.                  */
+int moca_gemm_two_piece(const moca_gemm_params* p, int64_t* ws_bytes, int32_t* sync_words);
 /* bytes of split-K workspace moca_gemm_f16 needs for (M,N,splits) */
 int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits);
 

@@ -33,6 +33,13 @@ struct Geo {
     int C, inH, inW, outH, outW, stride, up, T, HW;
 };
 
+// the same remap for an explicit physical index (two-piece mode of the 256-row kernel)
+__device__ __forceinline__ void remap_index(int nblk, int b, int& logical) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, j = b >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
 template <int BN>
 __device__ __forceinline__ void remap_block(int nblk, int& logical) {
     // XCD-aware bijective remap: physical blocks b, b+8, b+16, ... share an XCD (L2);
@@ -956,18 +963,30 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
 
     const int tiles_m = (p.M + TM - 1) / TM;
     const int tiles_n = p.N / BN;
-    const int nblk = tiles_m * tiles_n * p.splits;
-    int logical;
-    remap_block<BN>(nblk, logical);
-    const int split = logical % p.splits;
-    const int tile = logical / p.splits;
+    const int nk_total = (p.K + BK - 1) / BK;      // (W rows are readable and zero beyond K up to the next multiple of 64)
+    int split, tile, kt_begin, kt_end;
+    if (p.sk_big > 0) {
+        // two-piece mode: blocks [0, tiles) compute k-tiles [0, sk_big) of their tile, blocks [tiles, 2 tiles) the rest.  With
+        // sk_big / nk = tiles / CUs the big pieces take tiles / CUs of a tile time on `tiles` CUs while the other CUs work
+        // through the small pieces (dynamic dispatch): the launch ends after ~tiles / CUs of a tile time instead of a whole one.
+        const int ntile = tiles_m * tiles_n;
+        const int piece = (int)blockIdx.x >= ntile ? 1 : 0;
+        remap_index(ntile, (int)blockIdx.x - piece * ntile, tile);
+        split = 0;
+        kt_begin = piece ? p.sk_big : 0;
+        kt_end = piece ? nk_total : p.sk_big;
+    } else {
+        const int nblk = tiles_m * tiles_n * p.splits;
+        int logical;
+        remap_block<BN>(nblk, logical);
+        split = logical % p.splits;
+        tile = logical / p.splits;
+        const int kts = (nk_total + p.splits - 1) / p.splits;
+        kt_begin = split * kts;
+        kt_end = min(kt_begin + kts, nk_total);
+    }
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int m0 = tile_m * TM, n0 = tile_n * BN;
-
-    const int nk_total = (p.K + BK - 1) / BK;      // (W rows are readable and zero beyond K up to the next multiple of 64)
-    const int kts = (nk_total + p.splits - 1) / p.splits;
-    const int kt_begin = split * kts;
-    const int kt_end = min(kt_begin + kts, nk_total);
     const int nk = kt_end - kt_begin;
 
     const half_t* __restrict__ Wptr = reinterpret_cast<const half_t*>(p.w);
@@ -1117,6 +1136,52 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     for (; i < nk; ++i) step(no_t{}, i, i + 1 < nk);       // last two tiles: nothing left to prefetch
     MOCA_STAMP(3);
     __syncthreads();   // all fragment reads done before the ring is reused by the epilogue
+
+    if (p.sk_big > 0) {
+        // two-piece mode: whichever block of the tile finishes first leaves its accumulators (in register order: coalesced 16-byte
+        // stores) in splitk_ws and raises the tile's flag; the second adds them (a + b == b + a: the result does not depend on
+        // who was first) and runs the epilogue.  sk_sync[2 tile] = arrival counter, [2 tile + 1] = "partial sums are visible";
+        // the second block zeroes both.  The only wait is the second block's, for a first block that is already storing.
+        unsigned* __restrict__ sync = p.sk_sync + 2 * tile;
+        unsigned* s_old = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) *s_old = atomicAdd(sync, 1u);
+        __syncthreads();
+        const bool first = *s_old == 0;
+        float* ws = p.splitk_ws + (int64_t)tile * (TM * BN);
+        // The partial sums travel as agent-scope (write-through / cache-bypassing) accesses of their own: an agent-scope FENCE
+        // here writes back and invalidates the whole L2 of the XCD under the other blocks' operand streams (measured: +80-100 us
+        // per launch).  Element e of (mt, nt) of thread t lives at ((mt NT + nt) 4 + e) 512 + t: 256-byte runs per wavefront.
+        if (first) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        __hip_atomic_store(ws + ((mt * NT + nt) * 4 + e) * 512 + tid, acc[mt][nt][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every store acknowledged at the coherence point
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[mt][nt][e] += __hip_atomic_load(ws + ((mt * NT + nt) * 4 + e) * 512 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
 
     // The MFMAs above compute the TRANSPOSED tile (W fragment as A operand), so accumulator element r
     // of tile (mt, nt) is row m = wave_m*64 + mt*16 + fr, column n = wave_n*BN/2 + nt*16 + 4*fg + r:
@@ -2471,7 +2536,7 @@ int launch_gemm_g4(const moca_gemm_params& p, hipStream_t st) {
 template <int BN, int AMODE, bool FAST>
 int launch_gemm_glds(const moca_gemm_params& p, hipStream_t st) {
     const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / BN;
-    const int nblk = tiles_m * tiles_n * p.splits;
+    const int nblk = tiles_m * tiles_n * (p.sk_big > 0 ? 2 : p.splits);
     constexpr int lds_pipe = 3 * (256 + BN) * ROW_BYTES;
     constexpr int lds_epi = 256 * BN * 4;
     constexpr int lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
@@ -2571,6 +2636,46 @@ static bool tattn_ok(const moca_gemm_params& p) {
     if (p.N % 192 || p.T != 16 || p.HW <= 0 || p.HW % 20 || p.M % (16 * p.HW)) return false;
     if (p.ldo % 4 || p.ldo < p.N / 3) return false;
     return true;
+}
+
+// two-piece mode of the 256-row kernel: sk_big for this call, 0 when it does not qualify (measured, tools/bench_quant.py: a
+// 200-tile launch takes exactly as long as a 250-tile one)
+static int two_piece_big(const moca_gemm_params& p) {
+    // OFF unless MOCA_GEMM_TWO_PIECE = n > 1 (n = the smallest k-tile count that qualifies): in the whole CFG step the mode LOSES
+    // 0.8 % (33.75 -> 34.04 ms, same-device A/B) although the long convs gain 7 % in isolation -- kept as a measured experiment.
+    const char* e = getenv("MOCA_GEMM_TWO_PIECE");
+    if (!e || atoi(e) <= 1) return 0;
+    if (p.splits != 1 || (p.flags & (MOCA_EP_OUT_F32 | MOCA_EP_GEGLU | MOCA_FORCE_SMALL_TILE | MOCA_EP_GELU | MOCA_EP_TATTN))) return 0;
+    const int bn = takes_glds_bn(p);
+    if (bn == 0) return 0;
+    const int tiles = ((p.M + 255) / 256) * (p.N / bn);
+    const int nk = (p.K + BK - 1) / BK;
+    // measured (tools/bench_two_piece.py, M = 5120, N = 1280): K = 11520: 168 -> 157 us with the big piece at tiles / CUs + 0.06 of
+    // the k range (the small pieces pay a prologue, the partial-sum exchange and an epilogue each, ~3.6 of them per free CU);
+    // K = 3840 / 5120: +10 us -- the exchange costs more than the idle CUs.  So: only >= 160 k-tiles (K >= 10240).
+    const int min_nk = e ? atoi(e) : 160;                // (MOCA_GEMM_TWO_PIECE = n > 1: the smallest k-tile count that qualifies)
+    if (tiles < 136 || tiles > 232 || nk < (min_nk > 1 ? min_nk : 160)) return 0;
+    int big = (nk * tiles + 128) / 256 + (nk * 6 + 50) / 100;
+    if (big < 1) big = 1;
+    if (big > nk - 1) big = nk - 1;
+    return big;
+}
+
+extern "C" int moca_gemm_two_piece(const moca_gemm_params* pp, int64_t* ws_bytes, int32_t* sync_words) {
+    if (ws_bytes) *ws_bytes = 0;
+    if (sync_words) *sync_words = 0;
+    if (!pp) return 0;
+    moca_gemm_params p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
+    normalise_splits(p);
+    const int big = two_piece_big(p);
+    if (big > 0) {
+        const int bn = takes_glds_bn(p);
+        const int tiles = ((p.M + 255) / 256) * (p.N / bn);
+        if (ws_bytes) *ws_bytes = (int64_t)tiles * 256 * bn * 4;
+        if (sync_words) *sync_words = 2 * tiles;
+    }
+    return big;
 }
 
 extern "C" int moca_gemm_tattn_ok(const moca_gemm_params* pp) {
@@ -2675,6 +2780,11 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
               p.N % 32 == 0)) return MOCA_E_BADARG;
     }
     if ((p.flags & MOCA_EP_ROWSUM) && !(p.rowsum && rowsum_cols(p) != 0)) return MOCA_E_BADARG;             // ask moca_gemm_rowsum_cols() first
+    if (p.sk_big != 0) {                              // ask moca_gemm_two_piece() first
+        const int nk = (p.K + BK - 1) / BK;
+        if (!(p.sk_big > 0 && p.sk_big < nk && p.splitk_ws && p.sk_sync && p.splits == 1 && takes_glds_bn(p) != 0 &&
+              !(p.flags & (MOCA_EP_OUT_F32 | MOCA_EP_GEGLU | MOCA_FORCE_SMALL_TILE | MOCA_EP_GELU | MOCA_EP_TATTN)))) return MOCA_E_BADARG;
+    }
     if (p.flags & MOCA_EP_TATTN) {                    // ask moca_gemm_tattn_ok() first
         if (!tattn_ok(p) || ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1))) return MOCA_E_BADARG;
         return launch_gemm_w80s<MOCA_A_LINEAR, 3>(p, st);

@@ -42,6 +42,7 @@ class GemmParams(C.Structure):
         ("rowsum", C.c_void_p), ("lnf_part", C.c_void_p), ("lnf_wsum", C.c_void_p),
         ("lnf_nparts", C.c_int32), ("reserved2_", C.c_int32),
         ("gstat", C.c_void_p), ("gstat_rows", C.c_int32), ("tattn_scale", C.c_float),
+        ("sk_sync", C.c_void_p), ("sk_big", C.c_int32), ("reserved4_", C.c_int32),
     ]
 
 
@@ -55,6 +56,7 @@ SIGNATURES = {
     "moca_gemm_rowsum_cols": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_lnfold_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_tattn_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "moca_gemm_two_piece": (C.c_int, [C.POINTER(GemmParams), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "moca_groupnorm_colsum_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "moca_groupnorm_nhwc_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "moca_groupnorm_ws_bytes": (_i64, [_i32, _i32, _i32]),

@@ -132,7 +132,7 @@ def finish_lnfold(pw: PackedWeight) -> PackedWeight:
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
                  residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None,
-                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None):
+                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, two_piece=None):
     p = _l.GemmParams()
     p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), (out.data_ptr() if out is not None else None)
     p.bias = pw.bias.data_ptr() if pw.bias is not None else None
@@ -165,6 +165,10 @@ def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR
     if rowsum is not None:                   # f32 [N / cols][M][2] (cols = gemm_rowsum_cols), or True when only probing
         p.flags |= _l.MOCA_EP_ROWSUM
         p.rowsum = rowsum.data_ptr() if torch.is_tensor(rowsum) else None
+    if two_piece is not None:                # (sk_big, fp32 workspace, sync words): two blocks per output tile, no reduce launch
+        p.sk_big = two_piece[0]
+        p.splitk_ws = two_piece[1].data_ptr() if two_piece[1] is not None else None
+        p.sk_sync = two_piece[2].data_ptr() if two_piece[2] is not None else None
     if tattn is not None:                    # (T, HW, softmax scale): projection + temporal attention in one launch (MOCA_EP_TATTN)
         p.flags |= _l.MOCA_EP_TATTN
         p.T, p.HW, p.tattn_scale = tattn
@@ -208,6 +212,14 @@ def gemm_lnfold_ok(a, pw: PackedWeight, **kw):
     """does the kernel this call runs on have the MOCA_EP_LNFOLD epilogue?"""
     p = _gemm_params(a, pw, None, **kw)
     return bool(_l.load().moca_gemm_lnfold_ok(C.byref(p)))
+
+
+def gemm_two_piece(a, pw: PackedWeight, **kw):
+    """(sk_big, workspace bytes, sync words) when this launch should run as two blocks per output tile (see moca_hip.h), else (0, 0, 0)"""
+    p = _gemm_params(a, pw, None, **kw)
+    wsb, sw = C.c_int64(0), C.c_int32(0)
+    big = int(_l.load().moca_gemm_two_piece(C.byref(p), C.byref(wsb), C.byref(sw)))
+    return big, int(wsb.value), int(sw.value)
 
 
 def gemm_tattn_ok(a, pw: PackedWeight, **kw):

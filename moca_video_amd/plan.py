@@ -78,6 +78,7 @@ class _PlanBase:
         self.graph_failed = False
         self.n_runs = 0
         self._gstat_buf, self._gstat_used, self._last_gemm_step = None, 0, None
+        self._sk_sync = None
 
     def close(self):
         """release the instantiated hipGraph (moca_graph_destroy); the plan falls back to eager launches if used again"""
@@ -124,8 +125,21 @@ class _PlanBase:
             rows = ops.gemm_colsum_rows(a, pw, M=M, splits=splits, **kw)
             if rows > 0:
                 cs = (self.pool.get((M + rows - 1) // rows, 2 * pw.N, torch.float32), rows)
+        tp = None
+        if splits == 1:
+            # launches of the 256-row kernel that leave > 1/8 of the chip idle for a whole long tile (200 tiles on 256 CUs at the
+            # 1280-channel level): two blocks per tile with uneven k ranges, partial sums through a workspace, no reduce launch
+            big, ws_bytes, sync_words = ops.gemm_two_piece(a, pw, M=M, **kw)
+            if big > 0:
+                ws = self.pool.get(ws_bytes // 4, 1, torch.float32)
+                if self._sk_sync is None or self._sk_sync.numel() < sync_words:
+                    self._sk_sync = torch.zeros(max(1024, sync_words), dtype=torch.int32, device=self.device)
+                tp = (big, ws, self._sk_sync)
         self._last_gemm_step = len(self.steps)
-        self._emit(ops.gemm, a, pw, out, M=M, splits=splits, splitk_ws=ws, colsum=None if cs is None else cs[0], **kw)
+        if tp is not None:
+            self._emit(ops.gemm, a, pw, out, M=M, splits=1, two_piece=tp, colsum=None if cs is None else cs[0], **kw)
+        else:
+            self._emit(ops.gemm, a, pw, out, M=M, splits=splits, splitk_ws=ws, colsum=None if cs is None else cs[0], **kw)
         if ws is not None:
             self.pool.put(ws)
         return (out, cs) if want_colsum else out

@@ -560,3 +560,50 @@ def test_gemm_temporal_attention_fused(B, HW, heads, K, fold):
     att = torch.softmax(torch.einsum("bphid,bphjd->bphij", q, k) * scale, dim=-1)
     ref = torch.einsum("bphij,bphjd->bphid", att, v).permute(0, 3, 1, 2, 4).reshape(M, C)
     check(out, ref, TOL16, f"fused qkv + temporal attention (heads={heads}, K={K}, fold={fold})")
+
+
+# ---------------------------------------------------------------- two blocks per output tile, no reduce launch
+@pytest.mark.parametrize("mode,M,K,N,with_res", [("lin", 5120, 5120, 1280, True), ("conv", 5120, 11520, 1280, False),
+                                                 ("tconv", 5120, 3840, 1280, True), ("lin", 4900, 3072, 1280, False)])
+def test_gemm_two_piece(mode, M, K, N, with_res, monkeypatch):
+    """sk_big > 0: every 256-row tile is computed by two blocks (uneven k ranges); the first to finish leaves fp32 partial sums,
+    the second adds them and runs the epilogue.  Checked against torch, twice on the same sync words (they re-arm themselves),
+    with bit-identical results (a + b == b + a whichever block came second)."""
+    b = rnd(N, dtype=torch.float32)
+    res = rnd(M, N) if with_res else None
+    if mode == "lin":
+        a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        pw, kw = ops.pack_linear(w, b), {}
+        ref = a.float() @ w.float().t() + b
+    elif mode == "conv":
+        C, Fr, H, W = K // 9, M // 160, 10, 16
+        x = rnd(Fr, C, H, W)
+        w = rnd(N, C, 3, 3, scale=(9 * C) ** -0.5)
+        pw = ops.pack_conv3x3(w, b)
+        a = nhwc(x).reshape(M, C)
+        kw = dict(mode=L.MOCA_A_CONV3X3, conv=(C, H, W, H, W, 1, 0))
+        ref = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    else:
+        C, T, HW = K // 3, 16, 160
+        x = rnd(M // (T * HW), C, T, HW, 1)
+        w = rnd(N, C, 3, 1, 1, scale=(3 * C) ** -0.5)
+        pw = ops.pack_tconv3(w, b)
+        a = x.permute(0, 2, 3, 4, 1).reshape(M, C).contiguous()
+        kw = dict(mode=L.MOCA_A_TCONV3, tconv=(C, T, HW))
+        ref = F.conv3d(x.float(), w.float(), b, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(M, N)
+    if res is not None:
+        ref = ref + res.float()
+    monkeypatch.setenv("MOCA_GEMM_TWO_PIECE", "40")       # (the default only takes >= 160 k-tiles: K >= 10240)
+    big, ws_bytes, sync_words = ops.gemm_two_piece(a, pw, M=M, residual=res, **kw)
+    assert big > 0, "this shape is expected to qualify (about 200 tiles of 256 x 128, >= 40 k-tiles)"
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=DEV)
+    sync = torch.zeros(sync_words, dtype=torch.int32, device=DEV)
+    outs = []
+    for _ in range(3):
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+        ops.gemm(a, pw, out, M=M, residual=res, two_piece=(big, ws, sync), **kw)
+        torch.cuda.synchronize()
+        assert int(sync.abs().sum()) == 0
+        outs.append(out)
+    check(outs[0], ref, TOL16, f"two-piece {mode} M={M} K={K}")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
