@@ -185,7 +185,7 @@ int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gamma, const f
  * follows (openaimodel3d.py:149) is then one moca_groupnorm_gstat_f16 launch.                                        */
 int moca_concat_channels_gstat_f16(const void* a, const void* b, void* out, int32_t F, int32_t HW, int32_t C1, int32_t C2,
                                    int32_t frames_per_stat, double* gstat, void* stream);
-/* hipMemsetAsync(ptr, 0, bytes) on the stream (the MOCA_EP_GSTAT accumulators of a forward are zeroed by one call) */
+/* zero `bytes` bytes at the 16-byte aligned `ptr` on the stream (the MOCA_EP_GSTAT accumulators of a forward are zeroed by one call) */
 int moca_memset_zero(void* ptr, int64_t bytes, void* stream);
 
 /* LayerNorm over the last dim of fp16 x[M][C] (eps 1e-5): attention.py:199-201 */

@@ -4,6 +4,8 @@
 // the graph is just the recorded launch sequence of the C-ABI calls above).
 #include "common.h"
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 extern "C" int moca_graph_begin(void* stream) {
     if (hipStreamBeginCapture(moca_stream(stream), hipStreamCaptureModeThreadLocal) != hipSuccess) return MOCA_E_GRAPH;
@@ -82,10 +84,24 @@ extern "C" int moca_device_info(char* name, int32_t len, int32_t* cu_count) {
     return MOCA_OK;
 }
 
+// (a kernel, not hipMemsetAsync: with the library loaded before torch the process holds two HIP runtime images and the memset
+//  entry of ours reports "no ROCm-capable device" while kernel launches resolve fine -- seen with build() + smoke() in one process)
+__global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, int64_t n16, unsigned char* __restrict__ tail, int ntail) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = uint4{0u, 0u, 0u, 0u};
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
 extern "C" int moca_memset_zero(void* ptr, int64_t bytes, void* stream) {
-    if (!ptr || bytes < 0) return MOCA_E_BADARG;
+    if (!ptr || bytes < 0 || (reinterpret_cast<uintptr_t>(ptr) & 15)) return MOCA_E_BADARG;
     if (bytes == 0) return MOCA_OK;
-    return hipMemsetAsync(ptr, 0, (size_t)bytes, moca_stream(stream)) == hipSuccess ? MOCA_OK : MOCA_E_LAUNCH;
+    const int64_t n16 = bytes / 16;
+    int blocks = (int)((n16 + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, moca_stream(stream), reinterpret_cast<uint4*>(ptr), n16,
+                       reinterpret_cast<unsigned char*>(ptr) + n16 * 16, (int)(bytes - n16 * 16));
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
 }
 
 extern "C" const char* moca_version(void) { return "moca_hip 0.1 (gfx950)"; }

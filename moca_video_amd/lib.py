@@ -10,6 +10,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch FIRST: it bundles its own libamdhip64 and must be the HIP runtime image libmoca_hip.so binds to.  Loaded the other way round
+# (e.g. `import moca_video_amd` before anything imported torch) the process ends up with two runtime images and the first launch
+# from this library fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MOCA_HIP_LIB: diagnostic builds only (e.g. the -DMOCA_STAMPS library used by tools/stamps.py)
 LIB_PATH = os.environ.get("MOCA_HIP_LIB") or os.path.join(_HERE, "libmoca_hip.so")
