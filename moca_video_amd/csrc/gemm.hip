@@ -564,9 +564,21 @@ struct BGather {
     unsigned a_off[NAP];          // per-lane byte offset of row slot g for the current tap
     int tap = -1, tin = 0, tiles_per_tap;
     int kt_next, kt_last;         // even tile of the next pair to issue; last pair of this block's k range
+    // Order in which the k range is walked (the sum does not care).  Tap-major = the packing order of W: all channels of tap 0,
+    // then tap 1, ...: a block sweeps its whole A footprint nine times, and with 32 tiles per XCD that footprint (6-9 MB) does not
+    // stay in the 4 MB L2 -- every sweep comes from the fabric again (GEMM FETCH_SIZE 60 GB per forward for 23 GB of operands).
+    // Channel-major (p.reserved4_ != 0; MOCA_CONV_CMAJOR=1, off by default -- see moca_gemm_f16): the nine taps of one 64-channel slice, then the next slice: the live
+    // footprint is (320 + halo) rows x 128 B per tile = 1.8 MB per XCD, the taps of a slice hit L2.  Costs one set_tap() per k-tile
+    // pair instead of one per C / 64 pairs; the weight k offset follows (tap * C + slice * 64).
+    const int ntap, cmajor;
+    int cp = 0;                   // channel-major: 64-channel slice of the next pair
+    // channel-major changes tap every pair: the per-tap address becomes  centre offset + block-uniform tap delta, selected by a
+    // per-row validity bit mask (3 VALU per row slot and pair instead of ~12); not with the fused x2 upsample (iy >> 1 is not affine)
+    unsigned a_centre[NAP], a_valid[NAP];
 
     __device__ __forceinline__ BGather(const moca_gemm_params& p_, int lch_, int kt_begin, int kt_last_pair)
-        : p(p_), lch(lch_), tiles_per_tap(AMODE == MOCA_A_LINEAR ? (1 << 30) : p_.C / KS), kt_next(kt_begin), kt_last(kt_last_pair) {}
+        : p(p_), lch(lch_), tiles_per_tap(AMODE == MOCA_A_LINEAR ? (1 << 30) : p_.C / KS), kt_next(kt_begin), kt_last(kt_last_pair),
+          ntap(AMODE == MOCA_A_CONV3X3 ? 9 : (AMODE == MOCA_A_TCONV3 ? 3 : 1)), cmajor(AMODE != MOCA_A_LINEAR && p_.reserved4_ != 0) {}
 
     __device__ __forceinline__ void init_row(int g, int m) {
         row_ok[g] = m < p.M;
@@ -601,8 +613,39 @@ struct BGather {
         }
     }
 
+    // (after the init_row() calls) centre offsets and validity masks of the channel-major walk
+    __device__ __forceinline__ void prepare_cmajor() {
+        if (!cmajor || p.up) return;
+#pragma unroll
+        for (int g = 0; g < NAP; ++g) {
+            unsigned m = 0;
+            if (AMODE == MOCA_A_CONV3X3) {
+                a_centre[g] = (unsigned)(((row_off[g] + (int64_t)(row_y[g] + 1) * p.inW + (row_x[g] + 1)) * p.C + lch * 8) * 2);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = row_y[g] + t / 3, ix = row_x[g] + t % 3;
+                    if (row_ok[g] && iy >= 0 && iy < p.inH && ix >= 0 && ix < p.inW) m |= 1u << t;
+                }
+            } else {
+                a_centre[g] = (unsigned)((row_off[g] * p.C + lch * 8) * 2);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int tt = row_y[g] + t - 1;
+                    if (row_ok[g] && tt >= 0 && tt < p.T) m |= 1u << t;
+                }
+            }
+            a_valid[g] = m;
+        }
+    }
+
     __device__ __forceinline__ void set_tap(int t) {
         tap = t;
+        if (AMODE != MOCA_A_LINEAR && cmajor && !p.up) {
+            const int d = AMODE == MOCA_A_CONV3X3 ? ((t / 3 - 1) * p.inW + (t % 3 - 1)) * p.C * 2 : (t - 1) * p.HW * p.C * 2;   // block-uniform
+#pragma unroll
+            for (int g = 0; g < NAP; ++g) a_off[g] = ((a_valid[g] >> t) & 1u) ? a_centre[g] + (unsigned)d : OOB_OFF;
+            return;
+        }
         if (AMODE == MOCA_A_LINEAR) {
 #pragma unroll
             for (int g = 0; g < NAP; ++g) a_off[g] = row_ok[g] ? (unsigned)((row_off[g] + lch * 8) * 2) : OOB_OFF;
@@ -629,6 +672,12 @@ struct BGather {
     // position the stream on the pair whose even tile is kt (one integer division, prologue only)
     __device__ __forceinline__ void seek(int kt) {
         kt_next = kt;
+        if (cmajor) {
+            const int q = kt >> 1;
+            cp = q / ntap;
+            set_tap(q - cp * ntap);
+            return;
+        }
         const int t = kt / tiles_per_tap;
         tin = kt - t * tiles_per_tap;
         set_tap(t);
@@ -637,13 +686,19 @@ struct BGather {
     __device__ __forceinline__ void advance() {
         if (kt_next + 2 <= kt_last) {
             kt_next += 2;
+            if (cmajor) {
+                int t = tap + 1;
+                if (t == ntap) { t = 0; ++cp; }
+                set_tap(t);
+                return;
+            }
             tin += 2;
             if (tin >= tiles_per_tap) { tin = 0; set_tap(tap + 1); }
         }
     }
     // block-uniform byte offsets of the pair's EVEN tile (the odd one is + KS*2 bytes)
-    __device__ __forceinline__ unsigned a_soff() const { return (unsigned)(tin * KS * 2); }
-    __device__ __forceinline__ unsigned w_soff() const { return (unsigned)(kt_next * KS * 2); }
+    __device__ __forceinline__ unsigned a_soff() const { return (unsigned)((cmajor ? 2 * cp : tin) * KS * 2); }
+    __device__ __forceinline__ unsigned w_soff() const { return (unsigned)((cmajor ? tap * tiles_per_tap + 2 * cp : kt_next) * KS * 2); }
 };
 
 // ---- epilogue stage 2 of the direct-to-LDS kernels: the fp16 tile staged in LDS (`rows` x `out_bn`, row pitch `pitch` bytes)
@@ -1937,6 +1992,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80b_kernel(const moca_gemm_param
     // ---- prologue: tiles 0..3 (two pairs) in flight, fragments of tile 0 in set 0 ----
     // The DMA instructions of a pair are issued interleaved (even piece j, odd piece j, ...), so a pair lands as a unit:
     // the waits count whole pairs (8 instructions per wave).
+    ga.prepare_cmajor();
     ga.seek(kt_begin);
     issue_pair(0, 1);
     ga.advance();
@@ -2197,6 +2253,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     // ---- prologue: pairs (0,1) and (2,3) in flight, pair (0,1) landed everywhere ----
     LnFoldRaw lraw = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
     if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, grow(tid), n0, tid);
+    ga.prepare_cmajor();
     ga.seek(kt_begin);
     issue_pair(0, 1);
     ga.advance();
@@ -2780,6 +2837,12 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
               p.N % 32 == 0)) return MOCA_E_BADARG;
     }
     if ((p.flags & MOCA_EP_ROWSUM) && !(p.rowsum && rowsum_cols(p) != 0)) return MOCA_E_BADARG;             // ask moca_gemm_rowsum_cols() first
+    {   // k order of the conv / temporal-conv gathers of the buffer-addressed kernels: tap-major unless MOCA_CONV_CMAJOR=1.
+        // Measured (same device): channel-major is 2-5 % faster on the 640- / 960-channel convs in isolation, cuts the GEMM
+        // FETCH_SIZE of a forward from 59.7 to 54.9 GB -- and the whole CFG step gets 0.4 % SLOWER (34.11 -> 34.25 ms).  Off.
+        const char* e_cm = getenv("MOCA_CONV_CMAJOR");
+        p.reserved4_ = (e_cm && atoi(e_cm) != 0) ? 1 : 0;
+    }
     if (p.sk_big != 0) {                              // ask moca_gemm_two_piece() first
         const int nk = (p.K + BK - 1) / BK;
         if (!(p.sk_big > 0 && p.sk_big < nk && p.splitk_ws && p.sk_sync && p.splits == 1 && takes_glds_bn(p) != 0 &&
