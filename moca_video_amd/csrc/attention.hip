@@ -232,6 +232,150 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     }
 }
 
+// ---- cross-attention against a SHORT context (N_k <= 96: the 77 CLIP tokens): ONE key tile of 96 (three 32-key sub-tiles; the
+// general kernel runs two 64-key tiles of which the second is 80 % padding, with an online-softmax step and a barrier in
+// between), plain softmax (no running maximum), and K / V staged ONCE per block for `q_iters` consecutive 128-query groups
+// (the general kernel re-stages them per 128 queries: 20 times per (frame, head) at 2560 tokens).  Fragment maps and LDS images
+// are those of attention_kernel.
+constexpr int KS96 = 96;
+__global__ __launch_bounds__(256, 2) void attention_short_kernel(
+    const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, half_t* __restrict__ out,
+    int heads, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, int kv_div, float scale_log2e, int q_iters) {
+    __shared__ __attribute__((aligned(16))) char sK[KS96 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sV[KS96 * ROWB];
+    // Q rows in / O rows out pass through a per-wave LDS tile (32 rows x 128 B, chunk ^ ((row >> 1) & 7)): the global accesses are
+    // whole 128-byte rows (8 lanes x 16 B) instead of one 16-byte / 8-byte piece of 32 different rows per instruction.  Each wave
+    // touches only its own 32 rows, so no block barrier is needed inside the query loop.
+    __shared__ __attribute__((aligned(16))) char sQ[QB * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, by;
+    attn_block_coords(bx, by);
+    const int bq = by / heads, head = by % heads;
+    const int bkv = bq / kv_div;
+    const int fr = lane & 31, fh = lane >> 5;
+    const half_t* qb = q + (int64_t)bq * Nq * ldq + head * D;
+    const half_t* kb = k + (int64_t)bkv * Nk * ldk + head * D;
+    const half_t* vb = v + (int64_t)bkv * Nk * ldv + head * D;
+    {   // stage K and V (rows >= Nk are zero; they are masked below)
+        const int cc = tid & 7, r0 = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int row = r0 + 32 * i;
+            half8v a = {0, 0, 0, 0, 0, 0, 0, 0}, b = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (row < Nk) {
+                a = *reinterpret_cast<const half8v*>(kb + (int64_t)row * ldk + cc * 8);
+                b = *reinterpret_cast<const half8v*>(vb + (int64_t)row * ldv + cc * 8);
+            }
+            *reinterpret_cast<half8v*>(sK + row * ROWB + ((cc ^ ((row >> 1) & 7)) << 4)) = a;
+            *reinterpret_cast<half8v*>(sV + row * ROWB + ((cc ^ (((row >> 1) & 1) << 2)) << 4)) = b;
+        }
+    }
+    __syncthreads();
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int tcol16 = (lane >> 4) & 1;
+    const int tkey4 = 4 * fh;
+    char* wq = sQ + wave * 32 * ROWB;
+    half8v nq[4];                                          // the NEXT query group's rows travel while the current one is computed
+    auto load_q = [&](int q0n) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                      // 32 rows x 8 chunks = 256 chunks, 4 per lane, row-contiguous
+            const int c = lane + 64 * i, row = c >> 3, ch = c & 7;
+            half8v t = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (q0n + row < Nq) t = *reinterpret_cast<const half8v*>(qb + (int64_t)(q0n + row) * ldq + ch * 8);
+            nq[i] = t;
+        }
+    };
+    load_q(bx * q_iters * QB + wave * 32);
+    for (int it = 0; it < q_iters; ++it) {
+        const int q0 = (bx * q_iters + it) * QB + wave * 32;
+        if (q0 >= Nq) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i, row = c >> 3, ch = c & 7;
+            *reinterpret_cast<half8v*>(wq + row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4)) = nq[i];
+        }
+        if (it + 1 < q_iters) load_q(q0 + QB);
+        half8v qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[ks] = *reinterpret_cast<const half8v*>(wq + fr * ROWB + (((ks * 2 + fh) ^ ((fr >> 1) & 7)) << 4));
+        f32x16 s[3];
+#pragma unroll
+        for (int sub = 0; sub < 3; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+            const int row = sub * 32 + fr;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int ch = ks * 2 + fh;
+                const half8v kf = *reinterpret_cast<const half8v*>(sK + row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4));
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sub], 0, 0, 0);
+            }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 3; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (key >= Nk) s[sub][r] = -INFINITY;
+                tmax = fmaxf(tmax, s[sub][r]);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mb = tmax * scale_log2e;
+        float psum = 0.f;
+        half8v pf[3][2];
+#pragma unroll
+        for (int sub = 0; sub < 3; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[sub][r] * scale_log2e - mb);
+                psum += pv;
+                pf[sub][r >> 3][r & 7] = (half_t)pv;
+            }
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 3; ++sub)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const int krow0 = sub * 32 + ss * 16 + tkey4 + tq;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int dcol = dt * 32 + tcol16 * 16 + 4 * tp;
+                    const int ch = dcol >> 3, within = (dcol & 7) * 2;
+                    const int ra = krow0, rb = krow0 + 8;
+                    const half4v lo = tr_read(sV + ra * ROWB + ((ch ^ (((ra >> 1) & 1) << 2)) << 4) + within);
+                    const half4v hi = tr_read(sV + rb * ROWB + ((ch ^ (((rb >> 1) & 1) << 2)) << 4) + within);
+                    const half8v vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[sub][ss], o[dt], 0, 0, 0);
+                }
+            }
+        const float inv = 1.0f / (psum + __shfl_xor(psum, 32, 64));
+        // O^T[d = 32 dt + 8 g + 4 fh + j][query fr] -> row fr of the wave's LDS tile (the Q fragments are in registers), then whole rows out
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4v h4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h4[j] = (half_t)(o[dt][g * 4 + j] * inv);
+                const int d0 = dt * 32 + 8 * g + 4 * fh;
+                *reinterpret_cast<half4v*>(wq + fr * ROWB + (((d0 >> 3) ^ ((fr >> 1) & 7)) << 4) + (d0 & 7) * 2) = h4;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i, row = c >> 3, ch = c & 7;
+            if (q0 + row < Nq)
+                *reinterpret_cast<half8v*>(out + ((int64_t)bq * Nq + q0 + row) * ldo + head * D + ch * 8) =
+                    *reinterpret_cast<const half8v*>(wq + row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4));
+        }
+    }
+}
+
 // ---- "v4": the VALU-lean flash attention for long key sequences ---------------------------------------------------------
 // rocprofv3 counters of attention_kernel at N = 2560 (tools/pmc_attn.sh): 222 VALU instructions per wave per 64-key tile,
 // the VALU active in 61 % of all SIMD cycles, the matrix pipe in 30 % -- at head dim 64 the kernel is VALU-bound, so v4 removes
@@ -561,6 +705,22 @@ extern "C" int moca_attention_f16(const void* q, const void* k, const void* v, v
                            reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
                            reinterpret_cast<const half_t*>(v), reinterpret_cast<half_t*>(out),
                            heads, Nq, Nk, ldq, ldk, ldv, ldo, kv_div, scale * 1.4426950408889634f);
+        MOCA_CHECK_LAUNCH();
+        return MOCA_OK;
+    }
+    const char* e_short = getenv("MOCA_ATTN_SHORT");   // A/B runs: 0 = the general kernel for the short context too
+    if ((!e_short || atoi(e_short) != 0) && Nk <= KS96) {
+        // query groups of 128 per block: as many as keep >= ~3 blocks per CU in the launch (K / V are staged once per block)
+        const int qgroups = (Nq + QB - 1) / QB;
+        int q_iters = (int)(((int64_t)qgroups * Bq * heads) / 768);
+        if (q_iters < 1) q_iters = 1;
+        if (q_iters > 8) q_iters = 8;
+        if (q_iters > qgroups) q_iters = qgroups;
+        const dim3 grid_s((qgroups + q_iters - 1) / q_iters, Bq * heads);
+        hipLaunchKernelGGL(attention_short_kernel, grid_s, block, 0, moca_stream(stream),
+                           reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
+                           reinterpret_cast<const half_t*>(v), reinterpret_cast<half_t*>(out),
+                           heads, Nq, Nk, ldq, ldk, ldv, ldo, kv_div, scale * 1.4426950408889634f, q_iters);
         MOCA_CHECK_LAUNCH();
         return MOCA_OK;
     }

@@ -262,7 +262,8 @@ def sdpa_ref(q, k, v, scale):
 
 
 @pytest.mark.parametrize("Bq,heads,Nq,Nk,kv_div", [(4, 5, 300, 300, 1), (2, 5, 2560, 2560, 1), (4, 10, 160, 77, 2),
-                                                   (6, 5, 100, 154, 3), (2, 20, 40, 40, 1), (1, 1, 33, 1, 1)])
+                                                   (6, 5, 100, 154, 3), (2, 20, 40, 40, 1), (1, 1, 33, 1, 1),
+                                                   (32, 5, 2560, 77, 16), (32, 10, 640, 77, 16), (3, 2, 700, 96, 1), (2, 4, 130, 65, 2)])
 def test_attention(Bq, heads, Nq, Nk, kv_div):
     C = heads * 64
     Bk = Bq // kv_div
