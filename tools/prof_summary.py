@@ -20,6 +20,7 @@ for r in rows:
     elif 'splitk' in n: k = 'splitk_reduce'
     elif 'temporal_attention' in n: k = 'temporal_attn'
     elif 'attention_v4' in n: k = 'attention_v4 (long keys)'
+    elif 'attention_short' in n: k = 'attention_short (77-token context)'
     elif 'attention_kernel' in n: k = 'attention (short keys / causal)'
     elif 'gn_slab' in n: k = 'gn_slab (single launch)'
     elif 'gn_partial' in n: k = 'gn_partial'
