@@ -78,6 +78,7 @@ class _PlanBase:
         self.graph_failed = False
         self.n_runs = 0
         self._gstat_buf, self._gstat_used, self._last_gemm_step = None, 0, None
+        self._gstat_full = []
         self._sk_sync = None
 
     def close(self):
@@ -201,10 +202,11 @@ class _PlanBase:
     def _gstat_slot(self, n_doubles):
         """f64 accumulators of one GEMM -> GroupNorm pair, carved from ONE buffer that a single memset zeroes at the start of
         every run (_run_steps)"""
-        if self._gstat_buf is None:
-            self._gstat_buf = torch.zeros(1 << 21, dtype=torch.float64, device=self.device)      # 16 MiB
-        if self._gstat_used + n_doubles > self._gstat_buf.numel():
-            raise RuntimeError("moca_video_amd: GroupNorm statistics buffer exhausted")
+        if self._gstat_buf is None or self._gstat_used + n_doubles > self._gstat_buf.numel():
+            if self._gstat_buf is not None:                # the chunk is full: keep it (its slots are in use), open another one
+                self._gstat_full.append(self._gstat_buf[:self._gstat_used])
+            self._gstat_buf = torch.zeros(max(1 << 20, n_doubles), dtype=torch.float64, device=self.device)      # 8 MiB chunks
+            self._gstat_used = 0
         s = self._gstat_buf[self._gstat_used:self._gstat_used + n_doubles]
         self._gstat_used += n_doubles
         return s
@@ -226,6 +228,8 @@ class _PlanBase:
         return y
 
     def _run_steps(self):
+        for full in self._gstat_full:
+            ops.memset_zero(full)
         if self._gstat_used:
             ops.memset_zero(self._gstat_buf[:self._gstat_used])
         for s in self.steps:
