@@ -584,8 +584,10 @@ __global__ __launch_bounds__(256, 2) void attention_v4_kernel(
 #else
     const float inv = 1.0f / osum[0];
 #endif
-    if (q_ok) {
-        half_t* ob = out + ((int64_t)bq * Nq + qrow) * ldo + head * D;
+    // O rows leave as whole 128-byte rows through the (now free) K/V buffers: wave w owns 4 KiB at smem + 4096 w (the last
+    // barrier of the key loop retired every fragment read; each wave touches only its own 32 rows, so no further barrier)
+    {
+        char* wq = smem + wave * 32 * ROWB;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -593,9 +595,18 @@ __global__ __launch_bounds__(256, 2) void attention_v4_kernel(
                 half4v h4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) h4[j] = (half_t)(o[dt][g * 4 + j] * inv);
-                *reinterpret_cast<half4v*>(ob + dt * 32 + 8 * g + 4 * fh) = h4;
+                const int d0 = dt * 32 + 8 * g + 4 * fh;
+                *reinterpret_cast<half4v*>(wq + fr * ROWB + (((d0 >> 3) ^ ((fr >> 1) & 7)) << 4) + (d0 & 7) * 2) = h4;
             }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i, row = c >> 3, ch = c & 7;
+            if (q0 + row < Nq)
+                *reinterpret_cast<half8v*>(out + ((int64_t)bq * Nq + q0 + row) * ldo + head * D + ch * 8) =
+                    *reinterpret_cast<const half8v*>(wq + row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4));
+        }
     }
+    (void)q_ok;
 #endif
 }
 
