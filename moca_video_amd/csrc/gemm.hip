@@ -33,6 +33,21 @@ struct Geo {
     int C, inH, inW, outH, outW, stride, up, T, HW;
 };
 
+// 2-D XCD partition of the tile grid: XCD (i, j) of an xm x xn arrangement (xm * xn = 8) owns the sub-grid of tiles_m / xm row
+// tiles x tiles_n / xn column tiles and walks it column-fastest.  With the 1-D partition above every XCD streams ALL of W once per
+// M tile it owns: at the 1280-channel level (K = 1280, N = 10240: W = 26 MB against a 4 MB L2) rocprofv3 shows 559 MB of fabric
+// reads per GEGLU launch for 39 MB of operands.  (xm, xn) is chosen on the host to minimise (rows of A + rows of W) per XCD and only
+// when both divide; p.reserved4_ >> 8 carries xn (0 / 1: the 1-D partition).
+__device__ __forceinline__ void remap_tile_2d(int tiles_m, int tiles_n, int xn, int& tile_m, int& tile_n) {
+    const int xm = 8 / xn;
+    const int sm = tiles_m / xm, sn = tiles_n / xn;          // sub-grid of one XCD
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;                        // j-th tile of this XCD
+    const int xi = xcd / xn, xj = xcd - xi * xn;
+    tile_m = xi * sm + j / sn;
+    tile_n = xj * sn + j % sn;
+}
+
 // the same remap for an explicit physical index (two-piece mode of the 256-row kernel)
 __device__ __forceinline__ void remap_index(int nblk, int b, int& logical) {
     const int q = nblk >> 3, r = nblk & 7;
@@ -578,7 +593,7 @@ struct BGather {
 
     __device__ __forceinline__ BGather(const moca_gemm_params& p_, int lch_, int kt_begin, int kt_last_pair)
         : p(p_), lch(lch_), tiles_per_tap(AMODE == MOCA_A_LINEAR ? (1 << 30) : p_.C / KS), kt_next(kt_begin), kt_last(kt_last_pair),
-          ntap(AMODE == MOCA_A_CONV3X3 ? 9 : (AMODE == MOCA_A_TCONV3 ? 3 : 1)), cmajor(AMODE != MOCA_A_LINEAR && p_.reserved4_ != 0) {}
+          ntap(AMODE == MOCA_A_CONV3X3 ? 9 : (AMODE == MOCA_A_TCONV3 ? 3 : 1)), cmajor(AMODE != MOCA_A_LINEAR && (p_.reserved4_ & 0xff) != 0) {}
 
     __device__ __forceinline__ void init_row(int g, int m) {
         row_ok[g] = m < p.M;
@@ -2128,11 +2143,17 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     const int tiles_m = (p.M + TM - 1) / TM;
     const int tiles_n = p.N / BN;
     const int nblk = tiles_m * tiles_n * p.splits;
-    int logical;
-    remap_block<BN>(nblk, logical);
-    const int split = logical % p.splits;
-    const int tile = logical / p.splits;
-    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    int split = 0, tile_m, tile_n;
+    const int xcd_n = p.reserved4_ >> 8;                 // > 1: 2-D XCD partition (host: splits == 1, both tile counts divide)
+    if (xcd_n > 1) {
+        remap_tile_2d(tiles_m, tiles_n, xcd_n, tile_m, tile_n);
+    } else {
+        int logical;
+        remap_block<BN>(nblk, logical);
+        split = logical % p.splits;
+        const int tile = logical / p.splits;
+        tile_m = tile / tiles_n; tile_n = tile % tiles_n;
+    }
     const int m0 = tile_m * TM, n0 = tile_n * BN;
 
     const int nk_total = 2 * ((p.K + 63) / 64);
@@ -2469,6 +2490,21 @@ int launch_gemm_w80s(const moca_gemm_params& p, hipStream_t st) {
     constexpr int TM = SHAPE == 2 ? 256 : (SHAPE == 1 ? 160 : 320), BN = SHAPE == 2 ? 256 : (SHAPE == 1 ? 320 : (SHAPE == 3 ? 192 : 160));
     const int tiles_m = (p.M + TM - 1) / TM, tiles_n = p.N / BN;
     const int nblk = tiles_m * tiles_n * p.splits;
+    moca_gemm_params pl = p;
+    {   // XCD partition of the tile grid: the (xm, xn) with the fewest operand rows per XCD (MOCA_GEMM_XCD2D=0: always 1-D)
+        const char* e2 = getenv("MOCA_GEMM_XCD2D");
+        int best_xn = 1;
+        if (!(e2 && atoi(e2) == 0) && p.splits == 1 && SHAPE != 3 && p.a_mode == MOCA_A_LINEAR) {
+            long best = (long)((tiles_m + 7) / 8) * TM + (long)tiles_n * BN;
+            for (int xn = 2; xn <= 8; xn *= 2) {
+                const int xm = 8 / xn;
+                if (tiles_m % xm || tiles_n % xn) continue;
+                const long cost = (long)(tiles_m / xm) * TM + (long)(tiles_n / xn) * BN;
+                if (cost * 10 < best * 8) { best = cost; best_xn = xn; }      // (only a clear win: >= 20 % fewer rows)
+            }
+        }
+        pl.reserved4_ = (pl.reserved4_ & 0xff) | (best_xn << 8);
+    }
     constexpr int lds = 5 * (TM + BN) * 64;              // 150 KiB (160 KiB for 256 x 256); the fp16 epilogue tile fits inside the ring
     static bool attr_set = false;
     if (!attr_set) {
@@ -2476,7 +2512,7 @@ int launch_gemm_w80s(const moca_gemm_params& p, hipStream_t st) {
             return MOCA_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_w80s_kernel<AMODE, SHAPE>), dim3(nblk), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_w80s_kernel<AMODE, SHAPE>), dim3(nblk), dim3(512), lds, st, pl);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
