@@ -1418,11 +1418,16 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     const int tiles_m = (p.M + TM - 1) / TM;
     const int tiles_n = p.N / BN;
     const int nblk = tiles_m * tiles_n * p.splits;
-    int logical;
-    remap_block<BN>(nblk, logical);
-    const int split = logical % p.splits;
-    const int tile = logical / p.splits;
-    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    int split = 0, tile_m, tile_n;
+    if ((p.reserved4_ >> 8) > 1) {                       // 2-D XCD partition (see remap_tile_2d)
+        remap_tile_2d(tiles_m, tiles_n, p.reserved4_ >> 8, tile_m, tile_n);
+    } else {
+        int logical;
+        remap_block<BN>(nblk, logical);
+        split = logical % p.splits;
+        const int tile = logical / p.splits;
+        tile_m = tile / tiles_n; tile_n = tile % tiles_n;
+    }
     const int m0 = tile_m * TM, n0 = tile_n * BN;
 
     const int nk_total = 2 * ((p.K + 63) / 64);        // 64-deep units -> even
@@ -2485,26 +2490,38 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
 #endif
 }
 
+// XCD partition (xm x xn = 8, xn returned; 1 = the 1-D partition) of a tiles_m x tiles_n grid of TM x BN tiles of a LINEAR
+// launch: estimated fabric bytes = W part + A part.  W: an XCD whose W sub-range ((tiles_n / xn) BN x K) fits its L2 (<= 3 MB)
+// fetches it once -> xm |W| in total; one that does not streams it again for every M tile it owns -> tiles_m |W| whatever
+// the partition.  A is consumed row tile by row tile -> xn |A|.  Only partitions that divide both tile counts; a 2-D partition is
+// taken when it saves >= 20 % (MOCA_GEMM_XCD2D=0: never).
+static int choose_xcd_n(const moca_gemm_params& p, int tiles_m, int tiles_n, int TM, int BN) {
+    const char* e2 = getenv("MOCA_GEMM_XCD2D");
+    if ((e2 && atoi(e2) == 0) || p.splits != 1 || p.a_mode != MOCA_A_LINEAR) return 1;
+    const double Wtot = (double)p.N * p.K * 2, Atot = (double)p.M * p.K * 2;
+    auto cost = [&](int xn) {
+        const int xm = 8 / xn;
+        const double wsub = (double)(tiles_n / xn) * BN * p.K * 2;
+        return (wsub <= 3.0e6 ? xm * Wtot : tiles_m * Wtot) + xn * Atot;
+    };
+    double best = cost(1);
+    int best_xn = 1;
+    for (int xn = 2; xn <= 8; xn *= 2) {
+        if (tiles_m % (8 / xn) || tiles_n % xn) continue;
+        const double c = cost(xn);
+        if (c < 0.8 * best) { best = c; best_xn = xn; }
+    }
+    (void)TM;
+    return best_xn;
+}
+
 template <int AMODE, int SHAPE>
 int launch_gemm_w80s(const moca_gemm_params& p, hipStream_t st) {
     constexpr int TM = SHAPE == 2 ? 256 : (SHAPE == 1 ? 160 : 320), BN = SHAPE == 2 ? 256 : (SHAPE == 1 ? 320 : (SHAPE == 3 ? 192 : 160));
     const int tiles_m = (p.M + TM - 1) / TM, tiles_n = p.N / BN;
     const int nblk = tiles_m * tiles_n * p.splits;
     moca_gemm_params pl = p;
-    {   // XCD partition of the tile grid: the (xm, xn) with the fewest operand rows per XCD (MOCA_GEMM_XCD2D=0: always 1-D)
-        const char* e2 = getenv("MOCA_GEMM_XCD2D");
-        int best_xn = 1;
-        if (!(e2 && atoi(e2) == 0) && p.splits == 1 && SHAPE != 3 && p.a_mode == MOCA_A_LINEAR) {
-            long best = (long)((tiles_m + 7) / 8) * TM + (long)tiles_n * BN;
-            for (int xn = 2; xn <= 8; xn *= 2) {
-                const int xm = 8 / xn;
-                if (tiles_m % xm || tiles_n % xn) continue;
-                const long cost = (long)(tiles_m / xm) * TM + (long)(tiles_n / xn) * BN;
-                if (cost * 10 < best * 8) { best = cost; best_xn = xn; }      // (only a clear win: >= 20 % fewer rows)
-            }
-        }
-        pl.reserved4_ = (pl.reserved4_ & 0xff) | (best_xn << 8);
-    }
+    pl.reserved4_ = (pl.reserved4_ & 0xff) | ((SHAPE == 3 ? 1 : choose_xcd_n(p, tiles_m, tiles_n, TM, BN)) << 8);
     constexpr int lds = 5 * (TM + BN) * 64;              // 150 KiB (160 KiB for 256 x 256); the fp16 epilogue tile fits inside the ring
     static bool attr_set = false;
     if (!attr_set) {
@@ -2621,7 +2638,9 @@ int launch_gemm_g4(const moca_gemm_params& p, hipStream_t st) {
             return MOCA_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_g4_kernel<AMODE, FAST>), dim3(nblk), dim3(256), lds, st, p);
+    moca_gemm_params pl = p;
+    pl.reserved4_ = (pl.reserved4_ & 0xff) | (choose_xcd_n(p, tiles_m, tiles_n, 256, 128) << 8);
+    hipLaunchKernelGGL((gemm_g4_kernel<AMODE, FAST>), dim3(nblk), dim3(256), lds, st, pl);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
