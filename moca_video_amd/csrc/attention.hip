@@ -396,7 +396,10 @@ __global__ __launch_bounds__(256, 2) void attention_short_kernel(
 // What is left per element: 0.5 max3 + exp + 0.5 cvt_pk + 0.5 dot2.  121 VGPRs: four waves per SIMD.  Tiles, LDS images and fragment maps are those of attention_kernel.
 constexpr float LAZY_THR = 8.0f;
 
-__global__ __launch_bounds__(256, 2) void attention_v4_kernel(
+// NW wavefronts (32 queries each) share every K/V tile: 4 (128 queries per block), or 8 (256 queries: half the LDS-DMA and L2 -> LDS
+// traffic per query, one piece of K and one of V per wave and tile; the barrier spans 8 waves)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void attention_v4_kernel(
     const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v, half_t* __restrict__ out,
     int heads, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, int kv_div, float scale_log2e) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (__amdgpu_buffer_rsrc_t is a device-only type; the host pass only needs the launch stub)
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void attention_v4_kernel(
     attn_block_coords(bx, by);
     const int bq = by / heads, head = by % heads;
     const int bkv = bq / kv_div;
-    const int q0 = bx * QB + wave * 32;
+    const int q0 = bx * (32 * NW) + wave * 32;
     const int fr = lane & 31, fh = lane >> 5;
 
     const half_t* qb = q + (int64_t)bq * Nq * ldq + head * D;
@@ -453,13 +456,13 @@ __global__ __launch_bounds__(256, 2) void attention_v4_kernel(
         const lds_c_ptr dk = (lds_c_ptr)sK + buf * TILE + wv * 1024;
         const unsigned ks0 = (unsigned)(kt * KT * ldk * 2);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, dk, 16, k_voff, ks0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, dk + 4096, 16, k_voff, ks0 + (unsigned)(32 * ldk * 2), 0, 0);
+        if constexpr (NW == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, dk + 4096, 16, k_voff, ks0 + (unsigned)(32 * ldk * 2), 0, 0);
     };
     auto dma_v = [&](int kt, int buf) {
         const lds_c_ptr dv = (lds_c_ptr)sV + buf * TILE + wv * 1024;
         const unsigned vs0 = (unsigned)(kt * KT * ldv * 2);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, dv, 16, v_voff, vs0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, dv + 4096, 16, v_voff, vs0 + (unsigned)(32 * ldv * 2), 0, 0);
+        if constexpr (NW == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, dv + 4096, 16, v_voff, vs0 + (unsigned)(32 * ldv * 2), 0, 0);
     };
     // fragment read offsets inside a tile: per-lane constants; (sub, ss, buffer) only add immediates
     int k_off[4];
@@ -712,7 +715,19 @@ extern "C" int moca_attention_f16(const void* q, const void* k, const void* v, v
     const dim3 grid((Nq + QB - 1) / QB, Bq * heads), block(256);
     const char* e_v4 = getenv("MOCA_ATTN_V4");       // A/B runs: 0 = the first-generation kernel everywhere
     if ((!e_v4 || atoi(e_v4) != 0) && Nk >= 2 * KT) {
-        hipLaunchKernelGGL(attention_v4_kernel, grid, block, 0, moca_stream(stream),
+        // 8 waves (256 queries) per block at long sequences: -2.8 % at 2560 tokens (half the K/V staging traffic per query), +6 %
+        // at 640 (too few blocks, the 8-wave barrier) -> from 2048 queries on; MOCA_ATTN_W8 = 0 never / 2 from 512 on (A/B runs)
+        const char* e_w8 = getenv("MOCA_ATTN_W8");
+        const int w8 = e_w8 ? atoi(e_w8) : 1;
+        if (w8 != 0 && Nq >= (w8 == 2 ? 512 : 2048)) {
+            hipLaunchKernelGGL(attention_v4_kernel<8>, dim3((Nq + 255) / 256, Bq * heads), dim3(512), 0, moca_stream(stream),
+                               reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
+                               reinterpret_cast<const half_t*>(v), reinterpret_cast<half_t*>(out),
+                               heads, Nq, Nk, ldq, ldk, ldv, ldo, kv_div, scale * 1.4426950408889634f);
+            MOCA_CHECK_LAUNCH();
+            return MOCA_OK;
+        }
+        hipLaunchKernelGGL(attention_v4_kernel<4>, grid, block, 0, moca_stream(stream),
                            reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
                            reinterpret_cast<const half_t*>(v), reinterpret_cast<half_t*>(out),
                            heads, Nq, Nk, ldq, ldk, ldv, ldo, kv_div, scale * 1.4426950408889634f);
