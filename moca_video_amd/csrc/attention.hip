@@ -715,10 +715,11 @@ extern "C" int moca_attention_f16(const void* q, const void* k, const void* v, v
     const dim3 grid((Nq + QB - 1) / QB, Bq * heads), block(256);
     const char* e_v4 = getenv("MOCA_ATTN_V4");       // A/B runs: 0 = the first-generation kernel everywhere
     if ((!e_v4 || atoi(e_v4) != 0) && Nk >= 2 * KT) {
-        // 8 waves (256 queries) per block at long sequences: -2.8 % at 2560 tokens (half the K/V staging traffic per query), +6 %
-        // at 640 (too few blocks, the 8-wave barrier) -> from 2048 queries on; MOCA_ATTN_W8 = 0 never / 2 from 512 on (A/B runs)
+        // 8 waves (256 queries) per block (MOCA_ATTN_W8 = 1: from 2048 queries on, 2: from 512 on; A/B runs): -2.8 % at 2560 tokens in
+        // isolation on a slow box (half the K/V staging traffic per query), +6 % at 640 (too few blocks, the 8-wave barrier), and
+        // -0.1 % on the whole step on a fast box -> off by default
         const char* e_w8 = getenv("MOCA_ATTN_W8");
-        const int w8 = e_w8 ? atoi(e_w8) : 1;
+        const int w8 = e_w8 ? atoi(e_w8) : 0;
         if (w8 != 0 && Nq >= (w8 == 2 ? 512 : 2048)) {
             hipLaunchKernelGGL(attention_v4_kernel<8>, dim3((Nq + 255) / 256, Bq * heads), dim3(512), 0, moca_stream(stream),
                                reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
