@@ -377,6 +377,70 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const half_t* __restrict__
     }
 }
 
+// ---- single-launch GroupNorm with the slab in REGISTERS: one block per (statistics group, channel group) slab of at most 4096
+// 16-byte chunks (64 KiB: the 1280-channel levels -- 640 rows x 80 B with 16-frame statistics at 5 x 8 latents, 160 rows x 80 B per
+// frame at 10 x 16), every thread keeps its <= 4 chunks, the block reduces (wave shuffles + LDS), normalises from registers and
+// stores: x is read ONCE and nothing is reduced redundantly (gn_slab_kernel: S = 16 blocks each re-reduce the whole slab).
+template <int CPT>
+__global__ __launch_bounds__(1024) void gn_slab_reg_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int R, int C, int cpg, double inv_count, float eps, int silu) {
+    __shared__ float s_red[2][16];
+    __shared__ float s_sc[128], s_sh[128];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int slab = blockIdx.x, sg = slab / GN_GROUPS, g = slab % GN_GROUPS;
+    const int vpr = cpg / 8, nchunks = R * vpr;
+    const int64_t base = (int64_t)sg * R * C + g * cpg;
+    half8v v[CPT];
+    int off[CPT];
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int idx = tid + i * nthr;
+        off[i] = -1;
+        if (idx < nchunks) {
+            const int row = idx / vpr, c = idx - row * vpr;
+            off[i] = row * C + c * 8;
+            v[i] = *reinterpret_cast<const half8v*>(x + base + off[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+        if (off[i] >= 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float a = (float)v[i][j]; s += a; q += a * a; }
+        }
+    s = wave_sum(s); q = wave_sum(q);
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = s; s_red[1][tid >> 6] = q; }
+    __syncthreads();
+    if (tid < cpg) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < (nthr >> 6); ++w) { a += (double)s_red[0][w]; b += (double)s_red[1][w]; }
+        const double mean = a * inv_count;
+        double var = b * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const int c = g * cpg + tid;
+        const float sc = rstd * gamma[c];
+        s_sc[tid] = sc;
+        s_sh[tid] = beta[c] - (float)mean * sc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+        if (off[i] >= 0) {
+            const int c0 = (off[i] % C);                 // = c * 8 (row * C is a multiple of C)
+            half8v r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = (float)v[i][j] * s_sc[c0 + j] + s_sh[c0 + j];
+                if (silu) a = moca_silu(a);
+                r[j] = (half_t)a;
+            }
+            *reinterpret_cast<half8v*>(y + base + off[i]) = r;
+        }
+}
+
 // ---- LayerNorm: one wavefront per row, row kept in registers; every wave keeps LN_ROWS rows in flight ------
 // (one row per wave leaves a CU with ~20 KB of loads in flight -- 3.6 TB/s chip-wide at C = 320; with four rows per
 //  wave the loads of all four are issued before the first reduction)
@@ -481,6 +545,21 @@ extern "C" int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamm
             //  lose to the streaming path's full-row reads as soon as the tensor is more than a few MB)
             const int R = (int)R64;
             const int n_slabs = (F / frames_per_stat) * GN_GROUPS;
+            {   // slab in registers (MOCA_GN_SLAB_REG=0: never): <= 4096 chunks of 16 B, rows of >= 160 B ... or many rows
+                const char* e_reg = getenv("MOCA_GN_SLAB_REG");
+                const int nchunks = R * (cpg / 8);
+                if (!(e_reg && atoi(e_reg) == 0) && cpg % 8 == 0 && nchunks <= 4096 && nchunks >= 256) {
+                    const int cpt = (nchunks + 1023) / 1024;
+                    const int thr = ((nchunks + cpt - 1) / cpt + 63) / 64 * 64;
+                    const half_t* xi = reinterpret_cast<const half_t*>(x);
+                    half_t* yo = reinterpret_cast<half_t*>(y);
+#define MOCA_SLABREG(CPT) hipLaunchKernelGGL(gn_slab_reg_kernel<CPT>, dim3(n_slabs), dim3(thr), 0, st, xi, yo, gamma, beta, R, C, cpg, inv_count, eps, silu)
+                    if (cpt == 1) MOCA_SLABREG(1); else if (cpt == 2) MOCA_SLABREG(2); else if (cpt == 3) MOCA_SLABREG(3); else MOCA_SLABREG(4);
+#undef MOCA_SLABREG
+                    MOCA_CHECK_LAUNCH();
+                    return MOCA_OK;
+                }
+            }
             int S = 1024 / n_slabs;
             if (S > 16) S = 16;
             if (S > R) S = R;
