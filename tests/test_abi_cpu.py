@@ -113,3 +113,35 @@ def test_pack_layouts_on_cpu():
     assert torch.equal(pg.w[64:96, :16], wg[32:64].half()) and torch.equal(pg.bias[32:64], bg[64:96])
     pc = ops.pack_linear_cat([torch.randn(64, 32), torch.randn(64, 32), torch.randn(64, 32)], device="cpu")
     assert pc.w.shape == (192, 64)
+
+
+def test_layernorm_fold_algebra_cpu():
+    """ops.fold_layernorm (host side of MOCA_EP_LNFOLD): Linear(LayerNorm(x)) == rstd * (x W'^T - mean * rowsum(W')) + b' with
+    W' = W diag(gamma), b' = b + W beta -- the epilogue formula of the consumer kernels, restated in torch on the CPU."""
+    import torch
+    from moca_video_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(50, 96, generator=g) * 2.0 + 0.7
+    w, b = torch.randn(40, 96, generator=g) * 0.1, torch.randn(40, generator=g)
+    gamma, beta = torch.rand(96, generator=g) + 0.5, torch.randn(96, generator=g) * 0.2
+    wf, bf = ops.fold_layernorm(w, b, gamma, beta)
+    mean = x.mean(1, keepdim=True)
+    var = (x * x).mean(1, keepdim=True) - mean * mean            # what the row partial sums give the kernel
+    rstd = (var + 1e-5).rsqrt()
+    got = rstd * (x @ wf.t() - mean * wf.sum(1)[None, :]) + bf
+    ref = torch.nn.functional.layer_norm(x, (96,), gamma, beta, 1e-5) @ w.t() + b
+    assert (got - ref).abs().max() < 1e-4 * ref.abs().max()
+
+
+def test_split_k_factors_cpu():
+    """plan.gemm_splits: the measured rules of the 50-tile level (M = N = 1280) and the untouched small / full launches"""
+    import types
+    import torch
+    from moca_video_amd.plan import gemm_splits
+    pw = lambda n, k: types.SimpleNamespace(N=n, geglu=False, w=torch.empty(0, k))
+    assert gemm_splits(1280, pw(1280, 1280)) == 1          # unsplit: slabs + reduce launch cost more than the idle CUs
+    assert gemm_splits(1280, pw(1280, 3840)) == 4
+    assert gemm_splits(1280, pw(1280, 5120)) == 4
+    assert gemm_splits(1280, pw(1280, 11520)) == 5         # the 3x3 convs want every CU
+    assert gemm_splits(81920, pw(320, 320)) == 1
+    assert gemm_splits(5120, pw(1280, 1280)) == 1
