@@ -288,6 +288,59 @@ int moca_fifo_ddim_step_f32(const float* sample, const float* eps, const float* 
                             float beta, float one_minus_beta, float gamma, float one_minus_gamma,
                             void* stream);
 
+/* ---- one outer MoCA-FIFO iteration as device-side work (scripts/evaluation/funcs.py:305-371) --------------------
+ * The latent queue [C][Q][HW] f32 (batch 1: the reference's per-frame-timestep path needs B = 1, openaimodel3d.py:535)
+ * is a RING: queue frame j lives in slot (head + j) mod Q.  head, the iteration counter and the RNG seed live in a
+ * device-resident state block, so the whole iteration is a fixed launch sequence that is captured once into a hipGraph
+ * (moca_graph_begin/end) and replayed with no host round trip.                                                        */
+typedef struct moca_fifo_state {
+    int32_t head;        /* ring slot of queue frame 0 */
+    int32_t iter;        /* outer iterations completed (funcs.py:305 `i`) */
+    uint32_t seed_lo, seed_hi;
+    int32_t ext_noise;   /* 1: the host filled the noise buffer for this iteration (fixtures); cleared by the advance */
+    int32_t reserved_[3];
+} moca_fifo_state;       /* 32 bytes */
+
+/* out[0:n] ~ N(0,1): Philox4x32-10 keyed by the state's seed, counter (i/4, iter), Box-Muller.  Replaces the
+ * torch.randn draws of ddim.py:561 (`noise_like`, per frame) and funcs.py:92 (`new_noise`); no-op when ext_noise. */
+int moca_fifo_randn_f32(const moca_fifo_state* state, float* out, int64_t n, void* stream);
+/* x[(r nW + w)][c][j][p] = queue frame win_start[w] + j, r < reps (`latents[:,:,start:end].clone()`, funcs.py:315, repeated
+ * for the unconditional branch of ddim.py:366-369); anchor[c][p] = queue frame 0 (funcs.py:88), may be NULL. */
+int moca_fifo_gather_windows_f32(const moca_fifo_state* state, const float* queue, float* x, float* anchor,
+                                 const int32_t* win_start, int32_t nW, int32_t reps, int32_t C, int32_t Q, int32_t f,
+                                 int32_t HW, void* stream);
+typedef struct moca_fifo_step_params {
+    const moca_fifo_state* state;
+    const float* x;            /* [nW][C][f][HW] the windows as gathered BEFORE the iteration */
+    const float* eps_c;        /* [nW][C][f][HW] conditional noise prediction */
+    const float* eps_u;        /* unconditional one, or NULL (no guidance) */
+    const float* noise;        /* [nW][C][f][HW] standard normal (ddim.py:561) */
+    float* momentum;           /* [nW][C][f][HW]; frame 0 is read, never written (ddim.py:424) */
+    float* queue;              /* ring: x_prev frames wb_from..f-1 of window w -> queue frames win_start[w] + j (funcs.py:351-354); or NULL */
+    float* x_prev;             /* [nW][C][f][HW] or NULL */
+    float* pred_x0;            /* [nW][C][f][HW] or NULL (the loop discards it, funcs.py:320) */
+    const float* coef;         /* [nW][f][6] as moca_fifo_ddim_step_f32 */
+    const int32_t* win_start;  /* [nW] first queue frame of each window (funcs.py:307) */
+    const float* mask;         /* ring [Q][HW] (DAVIS masks, one channel) or NULL */
+    const float* mask_sums;    /* [Q] per-slot sums (ddim.py:585 `mask.sum() != 0`) */
+    const int32_t* mask_frame; /* [nW][f] queue frame consulted for window frame j (-1: none; ddim.py:565-567 incl. the clobbered index) */
+    const float* enh;          /* [nW][f] factor on cond (ddim.py:582) */
+    const float* cond;         /* [C][HW] conditioning image or NULL (zeros, ddim.py:573-574) */
+    float cfg_scale, beta, one_minus_beta, gamma, one_minus_gamma;
+    int32_t nW, C, Q, f, HW, wb_from;
+} moca_fifo_step_params;
+/* e = e_u + s (e_c - e_u) (ddim.py:372) + the MoCA ddim_step arithmetic of moca_fifo_ddim_step_f32 for all windows of an
+ * iteration (they are independent: funcs.py:305-355 walks ranks in reverse so every window reads pre-iteration frames) +
+ * the write-back of their second halves into the ring. */
+int moca_fifo_step_windows_f32(const moca_fifo_step_params* p, void* stream);
+/* funcs.py:357-371 minus the decode: emitted[iter mod n_slots][C][HW] = queue frame emit_frame (may be NULL); the slot of
+ * the dequeued frame receives `newframe` [C][HW] (the FreeInit mix, funcs.py:97) and becomes the tail; the mask ring keeps
+ * its last frame (funcs.py:113-116); then head = head + 1 mod Q, iter += 1, ext_noise = 0. */
+int moca_fifo_advance_f32(moca_fifo_state* state, float* queue, const float* newframe, float* emitted, int32_t n_slots,
+                          int32_t emit_frame, float* mask, float* mask_sums, int32_t C, int32_t Q, int32_t HW, void* stream);
+/* sums[fr] = sum of mask frame fr, mask [frames][HW] (ddim.py:585) */
+int moca_mask_frame_sums_f32(const float* mask, float* sums, int32_t frames, int32_t HW, void* stream);
+
 /* ---- FreeInit spectral mix (freeinit_utils.py:7-47) ------------------------------- */
 /* out = Re ifftn( fftshift^-1( fftshift(fftn x) * LPF + fftshift(fftn n) * (1-LPF) ) )
  * over the last three dims of x,n [C][T][H][W] f32; lpf [T][H][W] f32 (shifted layout,

@@ -44,6 +44,7 @@ class BlockRunner:
         pl = _Plan.__new__(_Plan)
         _PlanBase.__init__(pl, host, dev)
         pl.B, pl.T, pl.H, pl.W, pl.L, pl.BT = B, T, H, W, L, B * T
+        pl.segs, pl.ctx_rows = [(B, L)], B * L
         self.plan = pl
         P = host._packed
         if isinstance(block, _ResBlock):

@@ -1,0 +1,232 @@
+// One outer iteration of the MoCA-FIFO loop (scripts/evaluation/funcs.py:305-371) as device-side work: the 72-frame
+// latent queue is a RING in HBM whose head index, iteration counter and RNG seed live in a small device-resident state
+// block, so that an iteration -- window gather, batched UNet, classifier-free guidance + MoCA ddim_step of all 2n windows,
+// write-back, emission, FreeInit mix, queue shift -- is a fixed launch sequence the host captures ONCE into a hipGraph and
+// replays without reading anything back.  fp32 throughout, compiled with -ffp-contract=off like sampler.hip (the reference
+// evaluates these expressions as separate fp32 torch ops).
+#include "common.h"
+
+namespace {
+
+// ---- Philox4x32-10 (Salmon et al., SC'11) + Box-Muller: the noise of ddim.py:561 / funcs.py:92 drawn on the device ------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void fifo_randn_kernel(const moca_fifo_state* __restrict__ st, float* __restrict__ out, int64_t n) {
+    if (st->ext_noise) return;                      // the host filled the buffer for this iteration (fixtures)
+    const uint32_t k0 = st->seed_lo, k1 = st->seed_hi, it = (uint32_t)st->iter;
+    const int64_t n4 = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+        uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), it, 0x4d6f4341u};
+        philox4x32_10(c, k0, k1);
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;         // (0, 1]
+            const float u2 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+            const float r = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            z[2 * h] = r * cs;
+            z[2 * h + 1] = r * sn;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) out[q * 4 + j] = z[j];
+    }
+}
+
+// window w, repeat r: x[(r nW + w)][c][j][p] = queue[c][(head + win_start[w] + j) mod Q][p] (funcs.py:315, the .clone() of
+// the window); anchor[c][p] = queue[c][head][p] (funcs.py:88: the frame the shift dequeues; no write-back touches it)
+__global__ __launch_bounds__(256) void fifo_gather_kernel(const moca_fifo_state* __restrict__ st, const float* __restrict__ queue,
+                                                          float* __restrict__ x, float* __restrict__ anchor,
+                                                          const int32_t* __restrict__ win_start, int nW, int reps, int C, int Q,
+                                                          int f, int HW) {
+    const int head = st->head;
+    const int64_t per_rep = (int64_t)nW * C * f * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_rep; i += (int64_t)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        int64_t r = i / HW;
+        const int j = (int)(r % f); r /= f;
+        const int c = (int)(r % C);
+        const int w = (int)(r / C);
+        int fr = head + win_start[w] + j;
+        fr %= Q;
+        const float v = queue[((int64_t)c * Q + fr) * HW + p];
+        for (int rr = 0; rr < reps; ++rr) x[rr * per_rep + i] = v;
+    }
+    if (anchor) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)C * HW; i += (int64_t)gridDim.x * 256) {
+            const int p = (int)(i % HW), c = (int)(i / HW);
+            anchor[i] = queue[((int64_t)c * Q + head) * HW + p];
+        }
+    }
+}
+
+// classifier-free guidance (ddim.py:372) + MoCA ddim_step (ddim.py:405-430,556-609) of every window of an iteration + the
+// write-back of funcs.py:351-354.  One thread per (window, channel, pixel); the frame axis is walked sequentially (momentum
+// EMA, previous-frame dependence).  x is the gathered PRE-iteration copy of the windows: window r+1 reads the frames window
+// r writes back, and in the reference's reversed-rank order every window sees pre-iteration values.
+__global__ __launch_bounds__(256) void fifo_step_windows_kernel(moca_fifo_step_params P) {
+    const int head = P.state->head;
+    const int C = P.C, f = P.f, HW = P.HW, Q = P.Q;
+    const int64_t total = (int64_t)P.nW * C * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const int64_t wc = i / HW;
+        const int c = (int)(wc % C);
+        const int w = (int)(wc / C);
+        const int64_t base = wc * f * HW + p;
+        float prev = 0.f, mom_prev = P.momentum[base];        // momentum[:, :, 0] is never written (ddim.py:424: frames i >= 1 only)
+        const float cnd = P.cond ? P.cond[(int64_t)c * HW + p] : 0.f;
+        const int start = P.win_start[w];
+        for (int j = 0; j < f; ++j) {
+            const float* cf = P.coef + ((int64_t)w * f + j) * 6;
+            const int64_t o = base + (int64_t)j * HW;
+            float et = P.eps_c[o];
+            if (P.eps_u) {
+                const float u = P.eps_u[o];
+                et = u + P.cfg_scale * (et - u);               // :372
+            }
+            float p0 = (P.x[o] - cf[3] * et) / cf[0];          // :415
+            const float dir = cf[4] * et;                      // :418
+            if (j >= 1) {
+                float g = p0 - prev;                           // :422
+                g = g + 1.5f * dir;                            // :423
+                const float m = P.beta * mom_prev + P.one_minus_beta * g;   // :424-427
+                P.momentum[o] = m;
+                mom_prev = m;
+                p0 = p0 + cf[5] * m;                           // :428-430,557
+            }
+            prev = p0;                                         // :559
+            const float nz = cf[2] * P.noise[o];               // :561
+            const float xp = cf[1] * p0 + dir + nz;            // :562
+            if (P.x_prev) P.x_prev[o] = xp;
+            if (P.queue && j >= P.wb_from) {                   // funcs.py:351-354
+                int fr = head + start + j;
+                fr %= Q;
+                P.queue[((int64_t)c * Q + fr) * HW + p] = xp;
+            }
+            if (P.pred_x0) {
+                const int mf = P.mask ? P.mask_frame[w * f + j] : -1;
+                if (mf >= 0) {                                 // :565-590
+                    const int ms = (head + mf) % Q;
+                    if (P.mask_sums[ms] != 0.f && P.mask[(int64_t)ms * HW + p] > 0.5f) p0 = cnd * P.enh[w * f + j];
+                }
+                P.pred_x0[o] = P.one_minus_gamma * p0 + P.gamma * nz;   // :609
+            }
+        }
+    }
+}
+
+// funcs.py:357-371 without the decode: emitted[iter mod n_slots] = queue frame `emit_frame`; the slot of the dequeued frame 0
+// receives the FreeInit-mixed frame (it becomes the tail once the head moves on); the mask queue keeps its last frame (:116)
+__global__ __launch_bounds__(256) void fifo_advance_copy_kernel(const moca_fifo_state* __restrict__ st, float* __restrict__ queue,
+                                                                const float* __restrict__ newframe, float* __restrict__ emitted,
+                                                                int n_slots, int emit_frame, float* __restrict__ mask,
+                                                                float* __restrict__ mask_sums, int C, int Q, int HW) {
+    const int head = st->head;
+    const int slot = n_slots > 0 ? st->iter % n_slots : 0;
+    const int ef = (head + emit_frame) % Q, tail = (head + Q - 1) % Q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)C * HW; i += (int64_t)gridDim.x * 256) {
+        const int p = (int)(i % HW), c = (int)(i / HW);
+        if (emitted) emitted[(int64_t)slot * C * HW + i] = queue[((int64_t)c * Q + ef) * HW + p];
+        queue[((int64_t)c * Q + head) * HW + p] = newframe[i];
+        if (mask && c == 0) mask[(int64_t)head * HW + p] = mask[(int64_t)tail * HW + p];
+    }
+    if (mask_sums && blockIdx.x == 0 && threadIdx.x == 0) mask_sums[head] = mask_sums[tail];
+}
+
+__global__ void fifo_advance_bump_kernel(moca_fifo_state* st, int Q) {
+    st->head = (st->head + 1) % Q;
+    st->iter = st->iter + 1;
+    st->ext_noise = 0;
+}
+
+__global__ __launch_bounds__(256) void mask_frame_sums_kernel(const float* __restrict__ mask, float* __restrict__ sums, int HW) {
+    __shared__ float red[4];
+    const int fm = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) s += mask[(int64_t)fm * HW + i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[fm] = red[0] + red[1] + red[2] + red[3];
+}
+
+inline int grid_for(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int moca_fifo_randn_f32(const moca_fifo_state* state, float* out, int64_t n, void* stream) {
+    if (!state || !out || n <= 0) return MOCA_E_BADARG;
+    hipLaunchKernelGGL(fifo_randn_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, moca_stream(stream), state, out, n);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_fifo_gather_windows_f32(const moca_fifo_state* state, const float* queue, float* x, float* anchor,
+                                            const int32_t* win_start, int32_t nW, int32_t reps, int32_t C, int32_t Q, int32_t f,
+                                            int32_t HW, void* stream) {
+    if (!state || !queue || !x || !win_start || nW <= 0 || reps <= 0 || C <= 0 || Q <= 0 || f <= 0 || f > Q || HW <= 0)
+        return MOCA_E_BADARG;
+    hipLaunchKernelGGL(fifo_gather_kernel, dim3(grid_for((int64_t)nW * C * f * HW)), dim3(256), 0, moca_stream(stream), state, queue,
+                       x, anchor, win_start, nW, reps, C, Q, f, HW);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_fifo_step_windows_f32(const moca_fifo_step_params* p, void* stream) {
+    if (!p || !p->state || !p->x || !p->eps_c || !p->noise || !p->momentum || !p->coef || !p->win_start) return MOCA_E_BADARG;
+    if (p->nW <= 0 || p->C <= 0 || p->f <= 0 || p->HW <= 0 || p->wb_from < 0) return MOCA_E_BADARG;
+    if (p->queue && (p->Q < p->f)) return MOCA_E_BADARG;
+    if (p->mask && (!p->mask_sums || !p->mask_frame || !p->enh || p->Q <= 0)) return MOCA_E_BADARG;
+    if (!p->queue && !p->x_prev && !p->pred_x0) return MOCA_E_BADARG;
+    hipLaunchKernelGGL(fifo_step_windows_kernel, dim3(grid_for((int64_t)p->nW * p->C * p->HW)), dim3(256), 0, moca_stream(stream), *p);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_fifo_advance_f32(moca_fifo_state* state, float* queue, const float* newframe, float* emitted, int32_t n_slots,
+                                     int32_t emit_frame, float* mask, float* mask_sums, int32_t C, int32_t Q, int32_t HW,
+                                     void* stream) {
+    if (!state || !queue || !newframe || C <= 0 || Q <= 0 || HW <= 0 || emit_frame < 0 || emit_frame >= Q) return MOCA_E_BADARG;
+    if (emitted && n_slots <= 0) return MOCA_E_BADARG;
+    if (mask && !mask_sums) return MOCA_E_BADARG;
+    hipStream_t st = moca_stream(stream);
+    hipLaunchKernelGGL(fifo_advance_copy_kernel, dim3(grid_for((int64_t)C * HW)), dim3(256), 0, st, state, queue, newframe, emitted,
+                       n_slots, emit_frame, mask, mask_sums, C, Q, HW);
+    MOCA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fifo_advance_bump_kernel, dim3(1), dim3(1), 0, st, state, Q);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_mask_frame_sums_f32(const float* mask, float* sums, int32_t frames, int32_t HW, void* stream) {
+    if (!mask || !sums || frames <= 0 || HW <= 0) return MOCA_E_BADARG;
+    hipLaunchKernelGGL(mask_frame_sums_kernel, dim3(frames), dim3(256), 0, moca_stream(stream), mask, sums, HW);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}

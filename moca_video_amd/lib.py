@@ -51,6 +51,25 @@ class GemmParams(C.Structure):
     ]
 
 
+class FifoState(C.Structure):
+    """Mirror of `moca_fifo_state` (32 bytes, device-resident: the host writes it through an int32 tensor)."""
+    _fields_ = [("head", C.c_int32), ("iter", C.c_int32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
+                ("ext_noise", C.c_int32), ("reserved_", C.c_int32 * 3)]
+
+
+class FifoStepParams(C.Structure):
+    """Mirror of `moca_fifo_step_params` (include/moca_hip.h)."""
+    _fields_ = [
+        ("state", C.c_void_p), ("x", C.c_void_p), ("eps_c", C.c_void_p), ("eps_u", C.c_void_p), ("noise", C.c_void_p),
+        ("momentum", C.c_void_p), ("queue", C.c_void_p), ("x_prev", C.c_void_p), ("pred_x0", C.c_void_p), ("coef", C.c_void_p),
+        ("win_start", C.c_void_p), ("mask", C.c_void_p), ("mask_sums", C.c_void_p), ("mask_frame", C.c_void_p),
+        ("enh", C.c_void_p), ("cond", C.c_void_p),
+        ("cfg_scale", C.c_float), ("beta", C.c_float), ("one_minus_beta", C.c_float), ("gamma", C.c_float),
+        ("one_minus_gamma", C.c_float),
+        ("nW", C.c_int32), ("C", C.c_int32), ("Q", C.c_int32), ("f", C.c_int32), ("HW", C.c_int32), ("wb_from", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol of include/moca_hip.h
 _vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 SIGNATURES = {
@@ -85,6 +104,11 @@ SIGNATURES = {
     "moca_ddim_update_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i64, _vp]),
     "moca_fifo_ddim_step_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
+    "moca_fifo_randn_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "moca_fifo_gather_windows_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "moca_fifo_step_windows_f32": (C.c_int, [C.POINTER(FifoStepParams), _vp]),
+    "moca_fifo_advance_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "moca_mask_frame_sums_f32": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "moca_freq_mix_3d_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "moca_freq_mix_ws_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "moca_freq_filter_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _f64, _f64, _vp]),

@@ -270,11 +270,17 @@ class _Plan(_PlanBase):
         super().__init__(model, device)
         self.B, self.T, self.H, self.W, self.L = B, T, H, W, L
         self.BT = B * T
+        # context segments (videos, tokens) in batch order: one segment normally; the batched FIFO call carries the conditional
+        # windows (two prompts, 154 tokens) and the unconditional ones (77) in ONE forward: every cross-attention then runs one
+        # launch per segment on its own rows of the shared K|V projection -- no padded or masked keys
+        self.segs = [(B, L)] if isinstance(L, int) else [(int(n), int(l)) for n, l in L]
+        assert sum(n for n, _ in self.segs) == B
+        self.ctx_rows = sum(n * l for n, l in self.segs)
         m = model
         self.x_in = torch.empty(B, m.in_channels, T, H, W, dtype=in_dtype, device=device)
         self.t_rows = torch.empty(self.BT, dtype=torch.int64, device=device)
         self.fps_rows = torch.empty(self.BT, dtype=torch.int64, device=device)
-        self.ctx = torch.empty(B * L, m.context_dim, dtype=torch.float16, device=device)
+        self.ctx = torch.empty(self.ctx_rows, m.context_dim, dtype=torch.float16, device=device)
         self.out = torch.empty(B, m.out_channels, T, H, W, dtype=in_dtype, device=device)
         self._build()
 
@@ -417,8 +423,15 @@ class _Plan(_PlanBase):
         off, inner = self.model._kv_cols[id(att)]                # one K/V per video (context.repeat_interleave, :547),
         ld = self.kv_all.shape[1]                                # all layers' K|V projected by one GEMM up front
         o = self.pool.get(M, Cn)
-        self._emit(ops.attention, q, self.kv_all[:, off:off + inner], self.kv_all[:, off + inner:off + 2 * inner], o, Bq=F,
-                   heads=heads, Nq=HW, Nk=self.L, ldq=Cn, ldk=ld, ldv=ld, ldo=Cn, kv_div=self.T, scale=att.dim_head ** -0.5)
+        r0 = k0 = 0
+        for nv, Ls in self.segs:                                 # (one launch per context segment: rows of q / o, rows of K|V)
+            rows = nv * self.T * HW
+            kv = self.kv_all[k0:k0 + nv * Ls]
+            self._emit(ops.attention, q[r0:r0 + rows], kv[:, off:off + inner], kv[:, off + inner:off + 2 * inner], o[r0:r0 + rows],
+                       Bq=nv * self.T, heads=heads, Nq=HW, Nk=Ls, ldq=Cn, ldk=ld, ldv=ld, ldo=Cn, kv_div=self.T,
+                       scale=att.dim_head ** -0.5)
+            r0 += rows
+            k0 += nv * Ls
         self._release(q)
         return o
 
@@ -553,7 +566,7 @@ class _Plan(_PlanBase):
         self._pinned.add(self.emb_all.data_ptr())
         self.kv_all = None
         if "ctx_kv_all" in P:
-            self.kv_all = self.linear(self.ctx, B * self.L, P["ctx_kv_all"])  # [B*L][sum 2C]: every cross-attention K|V
+            self.kv_all = self.linear(self.ctx, self.ctx_rows, P["ctx_kv_all"])  # [sum B_i L_i][sum 2C]: every cross-attention K|V
             self._pinned.add(self.kv_all.data_ptr())
 
         x8 = self.pool.get(BT * H * W, 8)
@@ -597,6 +610,16 @@ class _Plan(_PlanBase):
         self._emit(ops.nhwc_to_ncthw, o.buf, o.C, self.out, B=B, Cout=m.out_channels, T=T, HW=H * W)
         self._release(o.buf)
 
+    def set_context(self, context):
+        """context [B, L, D], or one [n_i, L_i, D] tensor per segment"""
+        if torch.is_tensor(context):
+            self.ctx.copy_(context.reshape(self.ctx_rows, -1), non_blocking=True)
+            return
+        r = 0
+        for (nv, Ls), c in zip(self.segs, context):
+            self.ctx[r:r + nv * Ls].copy_(c.reshape(nv * Ls, -1), non_blocking=True)
+            r += nv * Ls
+
     def launch_async(self, x, t_rows, fps_rows, context, cur):
         """enqueue one forward on this plan's stream (ordered after `cur`); the caller joins"""
         self.stream.wait_stream(cur)
@@ -604,7 +627,7 @@ class _Plan(_PlanBase):
             self.x_in.copy_(x, non_blocking=True)
             self.t_rows.copy_(t_rows, non_blocking=True)
             self.fps_rows.copy_(fps_rows, non_blocking=True)
-            self.ctx.copy_(context.reshape(self.B * self.L, -1), non_blocking=True)
+            self.set_context(context)
             handle = self.stream.cuda_stream
             ops.set_stream(handle)
             try:

@@ -392,7 +392,7 @@ class UNetModel(nn.Module):
         self._packed = P
 
     # ---- forward -----------------------------------------------------------------------
-    def _prepare(self, x, timesteps, context, features_adapter, fps):
+    def _prepare(self, x, timesteps, context, features_adapter, fps, check_context=True):
         """argument checks + per-(b,t) timestep / fps rows shared by forward() and forward_concurrent()"""
         if features_adapter is not None:
             raise NotImplementedError("features_adapter is always None on the MoCA path")
@@ -428,11 +428,12 @@ class UNetModel(nn.Module):
                 fps_rows = fps.expand(B * T)
             else:
                 raise ValueError("fps must be an int or a tensor of B entries")
-        if context.shape[0] != B:
+        if check_context and context.shape[0] != B:
             raise ValueError("context batch must equal x batch")
         return t_rows, fps_rows
 
     def _plan_for(self, x, L, replica=0):
+        """L: context tokens, or a tuple of (videos, tokens) segments (see _Plan.segs)"""
         B, _, T, H, W = x.shape
         key = (B, T, H, W, L, x.dtype, x.device.index, replica)
         plan = self._plans.get(key)
@@ -448,6 +449,18 @@ class UNetModel(nn.Module):
         fps int or [B]; unknown kwargs (clean_cond, gamma, ...) are ignored exactly as upstream."""
         t_rows, fps_rows = self._prepare(x, timesteps, context, features_adapter, fps)
         return self._plan_for(x, context.shape[1]).run(x, t_rows, fps_rows, context)
+
+    @torch.no_grad()
+    def forward_segments(self, x, timesteps, contexts, fps=16):
+        """One forward over a batch whose videos carry contexts of DIFFERENT lengths: `contexts` = list of [n_i, L_i, D]
+        tensors in batch order (sum n_i = B), e.g. the 2n conditional FIFO windows with two prompts (154 tokens) followed
+        by their unconditional copies (77 tokens).  Same values as one forward() per segment: every UNet op is per-sample
+        and each cross-attention runs per segment on its own keys (no padding, no masking)."""
+        segs = tuple((int(c.shape[0]), int(c.shape[1])) for c in contexts)
+        if sum(n for n, _ in segs) != x.shape[0]:
+            raise ValueError("contexts must cover the batch of x")
+        t_rows, fps_rows = self._prepare(x, timesteps, contexts[0], None, fps, check_context=False)
+        return self._plan_for(x, segs).run(x, t_rows, fps_rows, list(contexts))
 
     @torch.no_grad()
     def forward_concurrent(self, calls):

@@ -39,3 +39,29 @@ def relerr(got, ref):
     got = torch.as_tensor(got).float()
     ref = torch.as_tensor(ref).float()
     return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+
+
+def loop_sam_candidates(call, F, H, W):
+    """Scripted Grounded-SAM-2 output for the `call`-th `ddim_step` of a sampling loop, one entry per frame (None = no box
+    detected): tools/make_golden.py::loop_cases feeds these to the REAL reference through fake predictor objects, the tests
+    hand the same lists to the oracle / the HIP path as `sam_masks`.  Cycles through: a detection, a shifted detection (IoU
+    fallback), no detection, a > 80 % mask followed by a small one, and an empty list."""
+    def rect(y0, y1, x0, x1):
+        m = torch.zeros(H, W)
+        m[y0 % H:max(y0 % H + 1, y1 % (H + 1)), x0 % W:max(x0 % W + 1, x1 % (W + 1))] = 1.0
+        return m
+    big = torch.ones(H, W)
+    out = []
+    for i in range(F):
+        k = (call * 3 + i) % 5
+        if k == 0:
+            out.append(rect(2 + call, 10 + call, 3, 12)[None])
+        elif k == 1:
+            out.append(rect(2 + call, 10 + call, 4 + i, 12 + i)[None])
+        elif k == 2:
+            out.append(None)
+        elif k == 3:
+            out.append(torch.stack([big, rect(1, 5 + i, 1 + call, 6 + call)]))
+        else:
+            out.append(rect(11, 15, call % 4, 5 + call % 4)[None])
+    return out

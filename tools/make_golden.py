@@ -485,6 +485,229 @@ def vae_cases():
                  enc_moments=torch.cat(moms, 2), enc_mode=torch.cat(modes, 2), enc_sample=torch.cat(samples, 2))
 
 
+
+def loop_sam_candidates(call, F, H, W):
+    """Scripted Grounded-SAM-2 output for the `call`-th ddim_step of a sampling loop (tests/helpers.py builds the same lists)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import loop_sam_candidates as f
+    return f(call, F, H, W)
+
+
+def loop_cases():
+    """The REAL sampling loops, end to end, on the real reduced-width UNet inside the real `DiffusionWrapper`, driven through the
+    real `LatentDiffusion.apply_model` / `decode_first_stage_2DAE` / `encode_first_stage_2DAE` methods on a holder with the real
+    reduced-width `AutoencoderKL`:
+      loop_base.npz  `base_ddim_sampling` -> `DDIMSampler.sample` -> `ddim_sampling` (funcs.py:177-241, ddim.py:109-252), S = 10,
+                     eta 1, CFG 12, use_scale, `latents_dir` caches 0.pt / 10.pt, decode of the samples;
+      loop_fifo.npz  `fifo_ddim_sampling` (funcs.py:243-373), 3 outer iterations, queue of 20 frames (f = 8, 2 partitions,
+                     lookahead), cond = two prompts (154 tokens), CFG 12:
+                       prompt mode -- no masks: `ddim_step` takes the segmentation branch (ddim.py:592-606) with fake
+                       Grounded-SAM-2 objects returning scripted masks, queue from the cached `16.pt`;
+                       DAVIS mode -- `davis_data = (frames, masks)`: queue from the VAE encoding of the frames, DAVIS masks in
+                       `ddim_step`, DAVIS branch of `shift_latents`.
+    Every torch.randn / randn_like / noise_like draw is replaced by a named weightgen tensor (recorded order = the reference's
+    call order), `.to("cuda")` is a no-op, `trange` is cut to 3 iterations, the text encoder is a table of named embeddings."""
+    import contextlib
+    import io
+    stub_t = sys.modules["torchvision"]
+    sys.modules["torchvision.transforms"] = stub_t.transforms
+    from scripts.evaluation import funcs as Fn
+    from lvdm.models.samplers import ddim as D
+    from lvdm.models import ddpm3d
+    from lvdm.models.autoencoder import AutoencoderKL
+    D.DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    D.DDIMSampler.initialize_segmentation_models = lambda self: None      # DDIMSampler(model) would load Grounded-SAM-2 (:49-50)
+
+    unet_cfg = {"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": dict(REDUCED)}
+    wrapper = ddpm3d.DiffusionWrapper(unet_cfg, "crossattn").eval()
+    fill(wrapper.diffusion_model, 11)
+    ae = AutoencoderKL(ddconfig=dict(VAE_DD, ch=64), lossconfig={"target": "torch.nn.Identity"}, embed_dim=4).eval()
+    fill(ae, seed=5)
+    text = {"a prompt": inp("loop.ctx1", (1, 77, 128)), "a conditioned prompt": inp("loop.ctx2", (1, 77, 128)),
+            "": inp("loop.uctx", (1, 77, 128))}
+
+    class LoopModel(FakeModel):
+        uncond_type = "empty_seq"
+        scale_factor = 0.18215
+        first_stage_model = ae
+        model = wrapper
+        apply_model = ddpm3d.LatentDiffusion.apply_model
+        decode_first_stage_2DAE = ddpm3d.LatentDiffusion.decode_first_stage_2DAE
+        encode_first_stage_2DAE = ddpm3d.LatentDiffusion.encode_first_stage_2DAE
+        get_first_stage_encoding = ddpm3d.LatentDiffusion.get_first_stage_encoding
+
+        def get_learned_conditioning(self, prompts):
+            return torch.cat([text[p] for p in prompts], 0).clone()
+
+    model = LoopModel()
+    real = dict(randn=torch.randn, randn_like=torch.randn_like, to=torch.Tensor.to, noise_like=D.noise_like, trange=Fn.trange)
+    counters = {}
+
+    def named(kind, shape):
+        k = counters.get(kind, 0)
+        counters[kind] = k + 1
+        return inp(f"{counters['tag']}.{kind}{k}", tuple(shape))
+
+    def rec_randn(*shape, **k):
+        shp = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else tuple(shape)
+        return named("randn", shp)
+
+    def to_nocuda(self, *a, **k):
+        if a and isinstance(a[0], str) and a[0] == "cuda":
+            return real["to"](self, **k) if k else self
+        return real["to"](self, *a, **k)
+
+    def patch(tag):
+        counters.clear()
+        counters["tag"] = tag
+        torch.randn = rec_randn
+        torch.randn_like = lambda t, *a, **k: named("randn_like", t.shape)
+        torch.Tensor.to = to_nocuda
+        D.noise_like = lambda shp, dev, repeat=False: named("noise_like", shp)
+        Fn.trange = lambda n, **k: range(min(n, 3))
+
+    def unpatch():
+        torch.randn, torch.randn_like, torch.Tensor.to = real["randn"], real["randn_like"], real["to"]
+        D.noise_like, Fn.trange = real["noise_like"], real["trange"]
+
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    fps = torch.tensor([10])
+    shape = [1, 4, 8, 16, 16]
+    try:
+        # ---------------- base sampling, 10 steps
+        patch("loop.base")
+        t0 = time.time()
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            cond = {"c_crossattn": [model.get_learned_conditioning(["a prompt"])], "fps": fps}
+            lat_dir = os.path.join(tmp, "base")
+            os.makedirs(lat_dir)
+            images, sampler, samples = Fn.base_ddim_sampling(model, cond, shape, ddim_steps=10, ddim_eta=1.0, cfg_scale=12.0,
+                                                             latents_dir=lat_dir, verbose=False)
+        unpatch()
+        x0pt, xNpt = torch.load(os.path.join(lat_dir, "0.pt")), torch.load(os.path.join(lat_dir, "10.pt"))
+        print(f"loop base: {time.time() - t0:.1f}s, samples std {samples.std():.3f} max {samples.abs().max():.2f}, "
+              f"draws {dict((k, v) for k, v in counters.items() if k != 'tag')}")
+        save("loop_base", samples=samples, images=images, pt0=x0pt, ptN=xNpt, n_randn=np.asarray(counters.get("randn", 0)),
+             n_noise_like=np.asarray(counters.get("noise_like", 0)))
+
+        # ---------------- FIFO loops
+        args = types.SimpleNamespace(num_inference_steps=16, video_length=8, lookahead_denoising=True, num_partitions=2,
+                                     new_video_length=10, save_frames=False)
+        cimg = (inp("loop.cimg", (1, 4, 1, 16, 16)) * 0.25 + 0.5).clamp(0, 1)
+        out = {}
+        for mode in ("prompt", "davis"):
+            patch("loop.fifo." + mode)
+            lat_dir = os.path.join(tmp, mode)
+            os.makedirs(lat_dir)
+            torch.save(inp("loop.z16", (1, 4, 8, 16, 16)), os.path.join(lat_dir, "16.pt"))
+            s = D.DDIMSampler(model)                                         # videocrafter_main.py:202-204 (cached latents)
+            s.make_schedule(ddim_num_steps=16, ddim_eta=1.0, verbose=False)
+            cond = {"c_crossattn": [model.get_learned_conditioning(["a prompt"]),
+                                    model.get_learned_conditioning(["a conditioned prompt"])], "fps": fps}
+            steps, shifts, frames = [], [], []
+            orig_step, orig_shift, orig_t2i = s.ddim_step, Fn.shift_latents, Fn.tensor2image
+
+            class Proc:
+                cands, k = None, 0
+
+                def __call__(self, images=None, text=None, return_tensors="pt"):
+                    return {"input_ids": torch.zeros(1, 4, dtype=torch.int64), "pixel_values": torch.zeros(1, 3, 2, 2)}
+
+                def post_process_grounded_object_detection(self, outputs, input_ids, box_threshold=0.4, text_threshold=0.3, target_sizes=None):
+                    c = self.cands[self.k]
+                    return [{"boxes": torch.zeros(0 if c is None else c.shape[0], 4)}]
+
+            class Pred:
+                def set_image(self, img):
+                    assert img.ndim == 3 and img.shape[2] == 3 and img.dtype == np.uint8
+
+                def predict(self, point_coords=None, point_labels=None, box=None, multimask_output=False):
+                    c = proc.cands[proc.k]
+                    assert box.shape[0] == c.shape[0]
+                    return c.numpy().copy(), None, None
+            proc = Proc()
+            s.processor, s.sam2_predictor, s.grounding_model = proc, Pred(), (lambda **kw: None)
+            orig_seg = s._apply_segmentation
+            seen = []
+
+            def counted(pred_x0, cond_image, target, step, pre_masks):
+                # entered once per frame with t <= 300, in frame order; `seen[-1]` = frames of this ddim_step call so far
+                proc.k = seen[-1]["frames"][len(seen[-1]["out"])]
+                res = orig_seg(pred_x0, cond_image, target, step, pre_masks)
+                seen[-1]["out"].append(int(res[0].shape[2]))
+                return res
+            s._apply_segmentation = counted
+
+            def spy_step(sample, noise_pred, indices, cond_image, target, ts, **kw):
+                call = len(steps)
+                F = sample.shape[2]
+                proc.cands = loop_sam_candidates(call, F, sample.shape[3], sample.shape[4])
+                seen.append({"frames": [i for i in range(F) if int(ts[i]) <= 300], "out": []})
+                xp, p0 = orig_step(sample, noise_pred, indices, cond_image, target, ts, **kw)
+                # fold the C-fold frame replication of injected frames (torch.where broadcast, see sampler_sam_cases)
+                counts = [1] * F
+                if kw.get("davis_masks") is None:
+                    for fr, n in zip(seen[-1]["frames"], seen[-1]["out"]):
+                        counts[fr] = n
+                parts, o = [], 0
+                for n in counts:
+                    blk = p0[:, :, o:o + n]
+                    for j in range(1, n):
+                        assert torch.equal(blk[:, :, [j]], blk[:, :, [0]])
+                    parts.append(blk[:, :, [0]])
+                    o += n
+                assert o == p0.shape[2]
+                steps.append((xp.clone(), torch.cat(parts, 2), np.asarray(counts), s.momentum.clone()))
+                return xp, p0
+            s.ddim_step = spy_step
+
+            def spy_shift(latents, *a, **k):
+                r = orig_shift(latents, *a, **k)
+                shifts.append((r[0] if isinstance(r, tuple) else r).clone())
+                if isinstance(r, tuple):
+                    out.setdefault(mode + "_masks_after", []).append(r[1][1].clone())
+                return r
+
+            def spy_t2i(frame_tensor):
+                frames.append(frame_tensor.clone())
+                return orig_t2i(frame_tensor)
+            Fn.shift_latents, Fn.tensor2image = spy_shift, spy_t2i
+            davis = None
+            if mode == "davis":
+                dframes = (inp("loop.davis.frames", (1, 4, 3, 128, 128)) * 0.5).clamp(-1, 1)          # RGBA, 3 frames
+                dmasks = (inp("loop.davis.masks", (1, 1, 20, 16, 16)) > 0.3).float()
+                dmasks[:, :, 7] = 0.0
+                davis = (dframes, dmasks)
+            t0 = time.time()
+            try:
+                with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                    Fn.fifo_ddim_sampling(args, model, cond, shape, s, cfg_scale=12.0, output_dir=tmp, latents_dir=lat_dir,
+                                          save_frames=False, conditioned_image=cimg, targets="object.", gamma=0.5,
+                                          use_self_attention=False, davis_data=davis)
+            finally:
+                Fn.shift_latents, Fn.tensor2image = orig_shift, orig_t2i
+                unpatch()
+            draws = dict((k, v) for k, v in counters.items() if k != "tag")
+            print(f"loop fifo {mode}: {time.time() - t0:.1f}s, {len(steps)} ddim_step calls, {len(shifts)} shifts, draws {draws}, "
+                  f"queue max {shifts[-1].abs().max():.2f}")
+            for k, v in draws.items():
+                out[f"{mode}_n_{k}"] = np.asarray(v)
+            out[mode + "_queue"] = torch.stack(shifts)                       # the queue after each iteration's shift
+            out[mode + "_frames"] = torch.stack(frames)                      # decoded emitted frame of each iteration
+            out[mode + "_x_prev"] = torch.stack([a for a, _, _, _ in steps])
+            out[mode + "_pred_x0"] = torch.stack([b for _, b, _, _ in steps])
+            out[mode + "_frame_copies"] = np.stack([c for _, _, c, _ in steps])
+            out[mode + "_momentum_last"] = steps[-1][3]
+            if mode + "_masks_after" in out:
+                out[mode + "_masks_after"] = torch.stack(out[mode + "_masks_after"])
+        save("loop_fifo", **out)
+    finally:
+        unpatch()
+        os.chdir(cwd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -492,7 +715,7 @@ def main():
     a = ap.parse_args()
     torch.set_num_threads(8)
     om, att = import_reference()
-    todo = a.only.split(",") if a.only else ["blocks", "reduced", "sampler", "sam", "freeinit", "fifo", "vae"] + (["full"] if a.full else [])
+    todo = a.only.split(",") if a.only else ["blocks", "reduced", "sampler", "sam", "freeinit", "fifo", "vae", "loop"] + (["full"] if a.full else [])
     if "blocks" in todo: blocks(om, att)
     if "reduced" in todo: unet_reduced(om)
     if "sampler" in todo: sampler_cases()
@@ -500,6 +723,7 @@ def main():
     if "freeinit" in todo: freeinit_cases()
     if "fifo" in todo: fifo_cases()
     if "vae" in todo: vae_cases()
+    if "loop" in todo: loop_cases()
     if "full" in todo: unet_full(om)
     if "fullN" in todo: unet_full(om, only_cfgN=True)
 
