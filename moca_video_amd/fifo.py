@@ -8,6 +8,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from .fifo_graph import FifoEngine, fifo_windows
 from .freeinit import freq_mix_3d, get_freq_filter
 from .sampler import DDIMSampler
 
@@ -116,28 +117,29 @@ def base_ddim_sampling(model, cond, noise_shape, ddim_steps=50, ddim_eta=1.0, cf
     return images, sampler, samples
 
 
-def fifo_windows(args):
-    """Window schedule of one outer iteration (funcs.py:290-312): yields (start, mid, end) for
-    rank = 2n-1 .. 0 (reversed so every window reads only not-yet-rewritten frames)."""
-    f = args.video_length
-    n = 2 * args.num_partitions if args.lookahead_denoising else args.num_partitions
-    for rank in reversed(range(n)):
-        start = rank * (f // 2) if args.lookahead_denoising else rank * f
-        yield start, start + f // 2, start + f
-
-
 def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg_scale=1.0, uc_emb=None,
                        latents=None, latents_dir=None, conditioned_image=None, masks=None, gamma=0.5, emit=None,
                        n_iterations=None, batch_windows=True, noises=None, shift_noises=None, decode=False, decode_batch=8,
-                       davis_data=None, anchor_noises=None, **kwargs):
+                       davis_data=None, anchor_noises=None, sam_masks=None, sam_masks_fn=None, targets=None, use_graph=True,
+                       seed=None, **kwargs):
     """funcs.py:243-373: returns the list of emitted latent frames [B,4,1,h,w]; with decode=True (and a model built with
     `first_stage_config`) the list of decoded frames [B,3,1,8h,8w] instead -- `model.decode_first_stage_2DAE` of funcs.py:360,
     run on `decode_batch` emitted frames at a time rather than once per iteration.
-    `masks` [B,1,Q,h,w] (Q = queue length) plays the role of the DAVIS masks (:296-302,315).  With `davis_data = (frames,
-    masks)` (DAVIS-video mode) the masks come from it and every queue shift takes the reference's DAVIS branch of
-    `shift_latents` (anchor = VAE encoding of the last DAVIS frame, mask tail refill; funcs.py:101-118,368-369).
-    batch_windows=True evaluates the 2n windows of an iteration as one batched UNet launch (SURVEY 8f N2);
-    `noises[i][w]` / `shift_noises[i]` optionally fix the per-window DDIM noise and the enqueued noise."""
+
+    Injection masks, as in the reference: with `davis_data = (frames, masks)` (DAVIS-video mode) the masks come from it and every
+    queue shift takes the DAVIS branch of `shift_latents` (funcs.py:101-118,368-369); `masks` [B,1,Q,h,w] handed in directly play
+    the same role (`davis_masks` of ddim_step: factor 1.5 / 1.0, every timestep).  WITHOUT either the reference's `ddim_step`
+    takes its segmentation branch (ddim.py:592-606: only frames with t <= 300, IoU fallback, > 80 % reset, factor 2) and asks
+    Grounded-SAM-2 for masks -- out of scope here, so they come in as `sam_masks[i][w]` (iteration i, window w in the reference's
+    call order: the list over frames of [n,h,w] candidate masks; or a callable (i, w) -> that list) or from `sam_masks_fn(pred_x0_frame, targets, frame) -> [n,h,w]`
+    (see DDIMSampler.ddim_step); with neither, nothing is injected.
+
+    batch_windows=True evaluates the 2n windows of an iteration as one batched UNet launch; with `use_graph` (and a
+    call `FifoEngine.supported` accepts) the WHOLE iteration -- gather, UNet, guidance, ddim_step of all windows, write-back,
+    emission, FreeInit mix, shift -- is one hipGraph on a device-resident ring queue (fifo_graph.py) and the host never
+    synchronises inside the loop; `latents` / `masks` are updated in place at the end like the reference's tensors.
+    `noises[i][w]` / `shift_noises[i]` optionally fix the per-window DDIM noise and the enqueued noise (else: device Philox
+    stream keyed by `seed` on the graph path, torch.randn on the host path)."""
     kwargs.update({"clean_cond": True})
     cond = conditioning
     uc = None
@@ -158,6 +160,36 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
         indices = np.concatenate([np.full((f // 2,), 0), indices])
     total = args.new_video_length + args.num_inference_steps - f if n_iterations is None else n_iterations
     frames, pending = [], []
+
+    if (batch_windows and use_graph and sam_masks is None and
+            FifoEngine.supported(model, cond, latents, davis_data=davis_data, sam_masks_fn=sam_masks_fn) and
+            (masks is None or masks.shape[2] == latents.shape[2])):
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())                # follows torch.manual_seed like the randn draws it replaces
+        eng = FifoEngine(args, model, ddim_sampler, cond, uc, cfg_scale, latents, conditioned_image=conditioned_image, masks=masks,
+                         n_slots=decode_batch if decode else max(total, 1), seed=seed)
+        try:
+            for i in range(total):
+                if noises is not None or shift_noises is not None:
+                    nz = noises[i] if noises is not None else [torch.randn(noise_shape, device=latents.device) for _ in eng.wins]
+                    sn = shift_noises[i] if shift_noises is not None else torch.randn_like(latents[:, :, -1])
+                    eng.step(noise=nz, shift_noise=sn)
+                else:
+                    eng.step()
+                if decode and ((i + 1) % decode_batch == 0 or i + 1 == total):
+                    i0 = (i // decode_batch) * decode_batch
+                    img = model.decode_first_stage_2DAE(eng.emitted_frames(i0, i + 1))
+                    frames.extend(img[:, :, [k]] for k in range(img.shape[2]))
+            if not decode and total > 0:
+                z = eng.emitted_frames(0, total)
+                frames = [z[:, :, [k]].clone() if emit is None else emit(z[:, :, [k]].clone()) for k in range(total)]
+            latents.copy_(eng.latents().to(latents.dtype))
+            if masks is not None:
+                masks.copy_(eng.mask_queue().to(masks.dtype))
+        finally:
+            eng.close()
+        return frames
+
     for i in range(total):
         wins = list(fifo_windows(args))
         eps_list = None
@@ -171,15 +203,17 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
             input_latents = latents[:, :, start:end].clone()
             input_masks = masks[:, :, start:end].clone() if masks is not None else None
             noise = None if noises is None else noises[i][wi]
+            sam = dict(sam_masks=None if sam_masks is None else (sam_masks(i, wi) if callable(sam_masks) else sam_masks[i][wi]),
+                       sam_masks_fn=sam_masks_fn)
             if eps_list is not None:
                 ts_t = torch.as_tensor(np.asarray(t).copy(), device=latents.device).to(torch.long)
-                output_latents, _ = ddim_sampler.ddim_step(input_latents, eps_list[wi], idx, conditioned_image, None, ts_t,
-                                                           davis_masks=input_masks, noise=noise)
+                output_latents, _ = ddim_sampler.ddim_step(input_latents, eps_list[wi], idx, conditioned_image, targets, ts_t,
+                                                           davis_masks=input_masks, noise=noise, **sam)
             else:
                 output_latents, _ = ddim_sampler.fifo_onestep(cond=cond, shape=noise_shape, latents=input_latents, timesteps=t,
                                                               indices=idx, unconditional_guidance_scale=cfg_scale,
                                                               unconditional_conditioning=uc, cond_image=conditioned_image,
-                                                              davis_masks=input_masks, noise=noise, **kwargs)
+                                                              target=targets, davis_masks=input_masks, noise=noise, **sam, **kwargs)
             if args.lookahead_denoising:
                 latents[:, :, mid:end] = output_latents[:, :, -(f // 2):]
             else:

@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from .fifo import base_ddim_sampling, fifo_ddim_sampling, prepare_latents, tensor2image
+from .fifo import base_ddim_sampling, fifo_ddim_sampling, fifo_windows, prepare_latents, tensor2image
 from .sampler import DDIMSampler
 
 _FIELDS = ("prompt", "conditioned_object", "conditioned_image_path", "conditioned_prompt", "gamma")
@@ -177,12 +177,17 @@ def _empty_prompt_embedding(model, embed_text, uc_emb):
 
 
 def run_prompts(args, model, embed_text, cond_image_fn=None, mask_fn=None, root=".", uc_emb=None, decode=True, rank=None,
-                num_processes=None, n_iterations=None):
+                num_processes=None, n_iterations=None, sam_masks_fn=None):
     """The prompt-mode loop of videocrafter_main.py:176-232 on the drop-in classes.
 
     embed_text(str) -> [1,77,1024] replaces `model.get_learned_conditioning` (OpenCLIP, out of scope);
-    cond_image_fn(row) -> conditioned-image latents [1,4,1,h,w]; mask_fn(row, shape) -> masks [1,1,Q,h,w] (the
-    Grounded-SAM-2 output).  Rows go to `rank` by `indices[rank::num_processes]`.  Returns {row index: output path}."""
+    cond_image_fn(row) -> conditioned-image latents [1,4,1,h,w].  Prompt mode reaches `ddim_step` WITHOUT DAVIS masks, i.e. its
+    segmentation branch (ddim.py:592-606 -> `_apply_segmentation` :739-903: frames with t <= 300 only, IoU fallback, > 80 % reset,
+    factor 2); the Grounded-SAM-2 producer it calls is out of scope and comes in as either
+      sam_masks_fn(pred_x0_frame [1,4,1,h,w], target, frame) -> candidate masks [n,h,w] or None  (the producer interface), or
+      mask_fn(row, shape) -> [1,1,Q,h,w]: one precomputed object mask per queue frame (e.g. `load_masks`), moving with the queue;
+      the mask of a window frame is offered as that frame's single candidate.
+    Rows go to `rank` by `indices[rank::num_processes]`.  Returns {row index: output path}."""
     rows = load_prompts(args.prompt_file, getattr(args, "prompt_index", None))
     uc_emb = _empty_prompt_embedding(model, embed_text, uc_emb)
     rank = getattr(args, "rank", 0) if rank is None else rank
@@ -208,9 +213,17 @@ def run_prompts(args, model, embed_text, cond_image_fn=None, mask_fn=None, root=
             cond["c_crossattn"].append(embed_text(data["conditioned_prompt"]))
         Q = args.num_inference_steps + (args.video_length // 2 if args.lookahead_denoising else 0)
         cimg = cond_image_fn(data) if cond_image_fn is not None else None
-        masks = mask_fn(data, (1, 1, Q, h, w)) if mask_fn is not None else None
+        sam = None
+        if mask_fn is not None:
+            mq = mask_fn(data, (1, 1, Q, h, w))[0, 0]
+            wins = list(fifo_windows(args))
+
+            def sam(i, wi, _mq=mq, _wins=wins):       # the mask queue moves with the latent queue: one shift per iteration, tail kept
+                s0, _, e0 = _wins[wi]
+                return [_mq[min(s0 + j + i, _mq.shape[0] - 1)][None] for j in range(e0 - s0)]
         frames = fifo_ddim_sampling(args, model, cond, noise_shape, sampler, args.unconditional_guidance_scale, uc_emb=uc_emb,
-                                    latents_dir=lat_dir, conditioned_image=cimg, masks=masks, gamma=data["gamma"],
+                                    latents_dir=lat_dir, conditioned_image=cimg, gamma=data["gamma"], sam_masks=sam,
+                                    sam_masks_fn=sam_masks_fn, targets=(data.get("conditioned_object") or "") + ".",
                                     decode=decode, n_iterations=n_iterations)
         keep = frames[-args.new_video_length // 2:]                          # videocrafter_main.py:228-230 (verbatim: -N//2 floors)
         if decode:

@@ -228,14 +228,14 @@ class DDIMSampler(object):
     @torch.no_grad()
     def fifo_onestep(self, cond, shape, latents=None, timesteps=None, indices=None, unconditional_guidance_scale=1.,
                      unconditional_conditioning=None, cond_image=None, target=None, use_self_attention=False,
-                     davis_masks=None, noise=None, **kwargs):
+                     davis_masks=None, noise=None, sam_masks=None, sam_masks_fn=None, **kwargs):
         """ddim.py:255-271"""
         device = self.model.betas.device
         ts = torch.as_tensor(np.asarray(timesteps).copy(), device=device).to(dtype=torch.long)
         noise_pred = self.unet(latents, cond, ts, unconditional_guidance_scale=unconditional_guidance_scale,
                                unconditional_conditioning=unconditional_conditioning, **kwargs)
         return self.ddim_step(latents, noise_pred, indices, cond_image, target, ts, use_self_attention=use_self_attention,
-                              davis_masks=davis_masks, noise=noise)
+                              davis_masks=davis_masks, noise=noise, sam_masks=sam_masks, sam_masks_fn=sam_masks_fn)
 
     @staticmethod
     def calculate_iou(masks1, masks2):
@@ -286,32 +286,16 @@ class DDIMSampler(object):
             midx[i] = i
         return eff, midx
 
-    @torch.no_grad()
-    def ddim_step(self, sample, noise_pred, indices, cond_image, target, ts, gamma=0.5, use_self_attention=False,
-                  davis_masks=None, noise=None, sam_masks=None):
-        """ddim.py:377-649.  Returns (x_prev, pred_x0); `self.momentum` persists across calls (:395-397).
-
-        Mask semantics follow the reference bit for bit, quirk included: its plotting loops
-        reuse the loop variable `i` (ddim.py:477,502,533), so for every frame i >= 1 the mask
-        frame consulted at :565-567 is ceil(H/4)-1, not i (frame 0 uses mask frame 0).  Set
-        `self.reference_index_quirk = False` for the per-frame mask the code evidently meant.
-        Without `davis_masks` the reference calls Grounded-SAM-2 per frame (out of scope); pass what it would
-        return as `sam_masks` (list over frames of [n,H,W] candidate masks) to get that branch's behaviour
-        (`select_sam_masks`: t <= 300 only, IoU fallback, > 80 % reset, factor 2); with neither, no injection."""
-        b, Cc, f, H, W = sample.shape
-        device = sample.device
-        sample, noise_pred = _f32c(sample), _f32c(noise_pred)
-        if noise is None:
-            noise = torch.randn(sample.shape, device=device)          # per-frame noise_like draws, :561
-        noise = _f32c(noise)
-        if not hasattr(self, 'momentum') or self.momentum.shape != sample.shape:
-            self.momentum = torch.zeros_like(sample)                   # :395-397
+    def step_tables(self, indices, ts_np, H, Fm):
+        """Host-side tables of one `ddim_step` call (they depend on the window slot only, not on the data): coef [f][6] =
+        {sqrt(a_t), sqrt(a_prev), sigma_t, sqrt(1-a_t), sqrt(1-a_prev-sigma^2), 2(1-t/1000)} evaluated in fp32 exactly as the
+        reference's 0-dim tensors are (ddim.py:409-428), enh [f] (:582) and the mask frame consulted for each frame (:565-567
+        incl. the clobbered loop variable, -1 = none; `Fm` = mask frames available)."""
         f32 = np.float32
-        ts_np = np.asarray(ts.detach().cpu()) if torch.is_tensor(ts) else np.asarray(ts)
+        f = len(indices)
         coef = np.zeros((f, 6), dtype=np.float32)
         enh = np.ones((f,), dtype=np.float32)
         midx = np.full((f,), -1, dtype=np.int32)
-        Fm = int(davis_masks.shape[2]) if davis_masks is not None else 0
         for i, index in enumerate(indices):
             a_t, a_prev = f32(self.ddim_alphas[index]), f32(self.ddim_alphas_prev[index])
             sigma, s1m = f32(self.ddim_sigmas[index]), f32(self.ddim_sqrt_one_minus_alphas[index])
@@ -325,8 +309,43 @@ class DDIMSampler(object):
             mi = i
             if self.reference_index_quirk and i >= 1:
                 mi = len(range(0, H, 4)) - 1                            # clobbered `i` (:477,502,533)
-            if davis_masks is not None and Fm > mi:                     # :565
+            if Fm > mi:                                                 # :565
                 midx[i] = mi
+        return coef, enh, midx
+
+    @torch.no_grad()
+    def ddim_step(self, sample, noise_pred, indices, cond_image, target, ts, gamma=0.5, use_self_attention=False,
+                  davis_masks=None, noise=None, sam_masks=None, sam_masks_fn=None):
+        """ddim.py:377-649.  Returns (x_prev, pred_x0); `self.momentum` persists across calls (:395-397).
+
+        Mask semantics follow the reference bit for bit, quirk included: its plotting loops
+        reuse the loop variable `i` (ddim.py:477,502,533), so for every frame i >= 1 the mask
+        frame consulted at :565-567 is ceil(H/4)-1, not i (frame 0 uses mask frame 0).  Set
+        `self.reference_index_quirk = False` for the per-frame mask the code evidently meant.
+        Without `davis_masks` the reference calls Grounded-SAM-2 per frame (out of scope); pass what it would
+        return as `sam_masks` (list over frames of [n,H,W] candidate masks) to get that branch's behaviour
+        (`select_sam_masks`: t <= 300 only, IoU fallback, > 80 % reset, factor 2); with neither, no injection.
+        `sam_masks_fn(pred_x0_frame [1,C,1,H,W], target, frame) -> [n,H,W] or None` is the mask PRODUCER interface (what
+        `_apply_segmentation` does with Grounded-SAM-2, ddim.py:745-801): it is shown the momentum-corrected pred_x0 of every frame
+        with t <= 300 (a first pass of the same kernel without injection and gamma = 0 yields it) and its answers go through the
+        same bookkeeping as `sam_masks`."""
+        if sam_masks_fn is not None and sam_masks is None and davis_masks is None:
+            _, p0 = self.ddim_step(sample, noise_pred, indices, cond_image, target, ts, gamma=0.0, use_self_attention=True, noise=noise
+                                   if noise is not None else torch.zeros_like(sample))
+            ts_h = np.asarray(ts.detach().cpu()) if torch.is_tensor(ts) else np.asarray(ts)
+            sam_masks = [sam_masks_fn(p0[:, :, [i]], target, i) if ts_h[i] <= 300 else None for i in range(sample.shape[2])]
+        b, Cc, f, H, W = sample.shape
+        device = sample.device
+        sample, noise_pred = _f32c(sample), _f32c(noise_pred)
+        if noise is None:
+            noise = torch.randn(sample.shape, device=device)          # per-frame noise_like draws, :561
+        noise = _f32c(noise)
+        if not hasattr(self, 'momentum') or self.momentum.shape != sample.shape:
+            self.momentum = torch.zeros_like(sample)                   # :395-397
+        f32 = np.float32
+        ts_np = np.asarray(ts.detach().cpu()) if torch.is_tensor(ts) else np.asarray(ts)
+        Fm = int(davis_masks.shape[2]) if davis_masks is not None else 0
+        coef, enh, midx = self.step_tables(indices, ts_np, H, Fm)
         x_prev, pred_x0 = torch.empty_like(sample), torch.empty_like(sample)
         coef_d = torch.from_numpy(coef).to(device)
         mask_d = cond_d = midx_d = enh_d = ws = None
