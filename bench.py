@@ -29,6 +29,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+N_PROMPTS = 64                      # BASELINE.json configs[4]: 64 rows of prompts/prompts.csv, sharded over the ranks
+PROMPTS_PER_FORWARD = 8             # x 2 CFG branches = one B = 16 forward
 FLOP_PER_UNET_STEP = 12.581e12      # FlopCounterMode on the reference UNet, [1,4,16,40,64], L=77
 PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
 # L2<->fabric bytes of one batched (B=2) UNet forward launch come from separate rocprofv3 --pmc FETCH_SIZE and
@@ -57,14 +59,62 @@ FULL = dict(in_channels=4, out_channels=4, model_channels=320, attention_resolut
             fps_cond=True)
 
 
-def build_model(device, seed=321):
+def build_model(device, seed=321, materialise=True):
+    """materialise=False (ranks != 0 of a multi-GPU job): the parameters are allocated and filled with NaN -- they exist only
+    once rank 0's copy has arrived through the C1 broadcast; a broadcast that did not happen cannot go unnoticed."""
     from moca_video_amd import DenoiseModel
     from moca_video_amd.weightgen import init_random_
     with torch.device(device):
         dm = DenoiseModel({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": FULL})
     dm = dm.to(device)
-    init_random_(dm.model.diffusion_model, seed)
+    if materialise:
+        init_random_(dm.model.diffusion_model, seed)
+    else:
+        with torch.no_grad():
+            for p in dm.model.diffusion_model.parameters():
+                p.fill_(float("nan"))
+        dm.model.diffusion_model._invalidate()
     return dm
+
+
+def param_checksum(module):
+    """(sum, sum of squares) over every parameter in float64: identical bytes give identical values (same reduction on every
+    rank); a NaN-filled (never received) tensor makes it NaN, which equals nothing"""
+    s = torch.zeros(2, dtype=torch.float64, device=next(module.parameters()).device)
+    with torch.no_grad():
+        for p in module.parameters():
+            d = p.detach().double()
+            s[0] += d.sum()
+            s[1] += (d * d).sum()
+    return s
+
+
+def broadcast_and_verify(module, device, world, rank):
+    """C1 with proof: barrier, timed flat-bucket broadcast from rank 0 (RCCL over xGMI; gloo in the CPU self-test), then the
+    per-rank parameter checksums are all-gathered and must all equal rank 0's.  Returns the dict that goes into the JSON line;
+    raises (non-zero exit on every rank) when a rank's weights differ."""
+    import torch.distributed as tdist
+    from moca_video_amd import dist as mdist
+    sync = (lambda: torch.cuda.synchronize(device)) if device.type == "cuda" else (lambda: None)
+    mdist.barrier(); sync()
+    t0 = time.perf_counter()
+    if os.environ.get("MOCA_BENCH_STUB_BROADCAST") == "1":       # negative test hook (tests/test_dist_cpu.py): C1 skipped
+        nbytes = 0
+    else:
+        nbytes = mdist.broadcast_parameters(module, src=0)
+    sync(); mdist.barrier()
+    dt = mdist.max_over_ranks(time.perf_counter() - t0, device)
+    cs = param_checksum(module)
+    allcs = [torch.empty_like(cs) for _ in range(world)]
+    tdist.all_gather(allcs, cs)
+    sums = [[float(c[0]), float(c[1])] for c in allcs]
+    equal = all(torch.equal(c, allcs[0]) for c in allcs) and bool(torch.isfinite(allcs[0]).all())
+    info = {"rccl_ranks": tdist.get_world_size(), "backend": tdist.get_backend(), "broadcast_bytes": int(nbytes),
+            "broadcast_s": round(dt, 4), "broadcast_GBps_per_receiver": round(nbytes / dt / 1e9, 2) if dt > 0 else None,
+            "param_checksums_equal": equal, "param_checksum_rank0": sums[0]}
+    if not equal:
+        raise RuntimeError(f"rank {rank}: parameter checksums differ after the C1 broadcast: {sums}")
+    return info
 
 
 def cpu_baseline(dm, x, ctx, ts, threads, runs=2):
@@ -270,59 +320,83 @@ def _free_port():
     return port
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, timeout_s=3000):
     """`python bench.py --gpus N` without a launcher: start N fresh child processes of this file, one per GPU
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, the reference idiom of hand-launched ranks,
-    videocrafter_main.py:179-181).  The parent never touches the GPU (no HIP call, no torch.cuda call): it only
-    forwards rank 0's stdout (the JSON line) and returns the worst exit code.  Children are new processes, not a re-exec."""
+    videocrafter_main.py:179-181).  The parent never touches the GPU (no HIP call, no torch.cuda call): it polls ALL children,
+    forwards rank 0's stdout (the JSON line) and returns the worst exit code; the first child that fails (or the overall
+    timeout) ends the others -- exact PIDs of children it started, never a pattern -- so a rank that dies during start-up does
+    not leave the rest waiting in the rendezvous holding their GPUs."""
     import subprocess
+    import tempfile
     port = _free_port()
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        out = subprocess.PIPE if r == 0 else sys.stderr        # only rank 0 owns stdout: ONE JSON line
+        out = out0 if r == 0 else sys.stderr                    # only rank 0 owns stdout: ONE JSON line
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
-    text, _ = procs[0].communicate()
-    for line in (text.decode() if text else "").splitlines():
+    t_end = time.monotonic() + timeout_s
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                rc = rc or code
+        if rc != 0 or time.monotonic() > t_end:
+            rc = rc or 124
+            for p in live:                                       # exact PIDs of our own children
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            break
+        time.sleep(0.2)
+    out0.seek(0)
+    for line in out0.read().splitlines():
         # stdout carries the JSON line only; anything else rank 0 printed (gloo/RCCL banners) goes to stderr
         (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=300 if rc == 0 else 20)
-        except subprocess.TimeoutExpired:
-            p.kill()                                             # exact PID of a child we started
-            p.wait()
-        rc = rc or p.returncode
     return rc
 
 
 def launcher_selftest(args):
     """`--selftest-cpu`: the multi-rank plumbing of this file WITHOUT the hot path (CPU, gloo): rendezvous from the
-    environment, C1 parameter broadcast, barrier, K no-op "steps", max-over-ranks timing, C2 gather, rank 0 prints one
-    JSON line.  Test infrastructure for tests/test_dist_cpu.py -- it measures nothing and says so in `metric`."""
+    environment, C1 exactly as the GPU job runs it (only rank 0 holds real parameters, the others NaN; timed broadcast;
+    all-gathered checksums must agree -- `broadcast_and_verify`), prompt-row striding of config[4], barrier, K no-op "steps",
+    max-over-ranks timing, C2 gather, rank 0 prints one JSON line.  Test infrastructure for tests/test_dist_cpu.py -- it
+    measures nothing and says so in `metric`; a stubbed-out broadcast makes every rank exit non-zero."""
     from moca_video_amd import dist as mdist
     rank, local, world = mdist.init_from_env(backend="gloo")
-    torch.manual_seed(100 + rank)
-    m = torch.nn.Linear(64, 64)
-    sent = mdist.broadcast_parameters(m, src=0)
-    w_sum = float(m.weight.detach().sum())
+    torch.manual_seed(100)
+    m = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.Linear(64, 8))
+    if rank != 0:
+        with torch.no_grad():
+            for p in m.parameters():
+                p.fill_(float("nan"))
+    info = broadcast_and_verify(m, torch.device("cpu"), world, rank)
+    rows = mdist.shard_indices(N_PROMPTS, rank, world)
     mdist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pass
     mdist.barrier()
     dt = mdist.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
-    outs = mdist.gather_results(torch.tensor([float(rank), w_sum]), dst=0)
+    outs = mdist.gather_results(torch.tensor([float(rank)] + [float(r) for r in rows]), dst=0)
     if rank == 0:
         ranks = [int(o[0]) for o in outs]
-        same_w = all(abs(float(o[1]) - w_sum) < 1e-6 for o in outs)
+        got_rows = sorted(int(v) for o in outs for v in o[1:])
         print(json.dumps({"metric": "launcher-selftest (no compute)", "value": 0.0, "unit": "none", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ranks_gathered": ranks, "weights_equal_after_broadcast": same_w,
-                          "broadcast_bytes": sent, "elapsed_s": dt}))
+                          "steps": args.steps, "warmup": args.warmup, "ranks_gathered": ranks,
+                          "weights_equal_after_broadcast": info["param_checksums_equal"], "multi_gpu": info,
+                          "rows_covered": got_rows == list(range(N_PROMPTS)), "elapsed_s": dt}))
 
 
 def main():
@@ -339,6 +413,9 @@ def main():
     ap.add_argument("--height", type=int, default=40)
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--no-video", action="store_true", help="skip the measured whole-video leg (base sampling + 148 FIFO iterations + decode)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="1-GPU rehearsal of rank 0's share of the N-GPU configs[4] job (its 64/N prompt rows in B=16 forwards, no "
+                         "collectives): `value` is then THIS GPU's UNet-steps/s on that workload; extra legs are skipped")
     ap.add_argument("--selftest-cpu", action="store_true", help="launcher/collective plumbing only (CPU, gloo): see launcher_selftest")
     args = ap.parse_args()
 
@@ -359,9 +436,10 @@ def main():
     torch.cuda.set_device(device)
     lib = mlib.load()
 
-    dm = build_model(device, seed=321)
+    dm = build_model(device, seed=321, materialise=(rank == 0))           # ranks != 0: NaN until C1 delivers rank 0's weights
+    multi = None
     if world > 1:
-        nbytes = mdist.broadcast_parameters(dm.model.diffusion_model, src=0)     # C1 (RCCL over xGMI)
+        multi = broadcast_and_verify(dm.model.diffusion_model, device, world, rank)     # C1 (RCCL over xGMI) + checksum proof
     unet = dm.model.diffusion_model
     sampler = DDIMSampler(dm)
     sampler.cfg_mode = args.cfg_mode
@@ -369,22 +447,37 @@ def main():
     sampler.make_schedule(S, ddim_eta=1.0, verbose=False)
 
     T, H, W = args.frames, args.height, args.width
-    g = torch.Generator(device=device).manual_seed(321 + rank)      # independent prompt/seed per rank
-    x = torch.randn(1, 4, T, H, W, device=device, generator=g)
-    ctx = torch.randn(1, 77, 1024, device=device, generator=g)
-    uctx = torch.randn(1, 77, 1024, device=device, generator=g)
-    fps = torch.tensor([10], device=device)
-    cond = {"c_crossattn": [ctx], "fps": fps}
-    uc = {"c_crossattn": [uctx], "fps": fps}
+    # N = 1: BASELINE.json configs[1], one prompt (B = 2 with the CFG branch).  N > 1: configs[4], the 64 prompt rows strided
+    # over the ranks (videocrafter_main.py:181), each rank running its rows in batches of 8 prompts (B = 16 per forward);
+    # prompt row r has seed 321 + r: latents and context are drawn per row, whatever rank owns it
+    emu = args.emulate_world if world == 1 and args.emulate_world > 1 else 0
+    rows = mdist.shard_indices(N_PROMPTS, 0, emu) if emu else ([0] if world == 1 else mdist.shard_indices(N_PROMPTS, rank, world))
+    batches = []
+    for i in range(0, len(rows), PROMPTS_PER_FORWARD):
+        xs, cs, us = [], [], []
+        for r in rows[i:i + PROMPTS_PER_FORWARD]:
+            g = torch.Generator(device=device).manual_seed(321 + r)
+            xs.append(torch.randn(1, 4, T, H, W, device=device, generator=g))
+            cs.append(torch.randn(1, 77, 1024, device=device, generator=g))
+            us.append(torch.randn(1, 77, 1024, device=device, generator=g))
+        nb = len(xs)
+        fps = torch.tensor([10] * nb, device=device)
+        batches.append(dict(x=torch.cat(xs), cond={"c_crossattn": [torch.cat(cs)], "fps": fps},
+                            uc={"c_crossattn": [torch.cat(us)], "fps": fps}, n=nb))
+    x, ctx, cond = batches[0]["x"][:1], batches[0]["cond"]["c_crossattn"][0][:1], None
+    cond = {"c_crossattn": [ctx], "fps": torch.tensor([10], device=device)}
 
-    def ddim_step(i, img):
+    def ddim_step(i, imgs):
         index = S - 1 - (i % S)
-        ts = torch.full((1,), int(sampler.ddim_timesteps[index]), device=device, dtype=torch.long)
-        img, _ = sampler.p_sample_ddim(img, cond, ts, index=index, unconditional_guidance_scale=12.0,
-                                       unconditional_conditioning=uc)
-        return img
+        out = []
+        for b, img in zip(batches, imgs):
+            ts = torch.full((b["n"],), int(sampler.ddim_timesteps[index]), device=device, dtype=torch.long)
+            img, _ = sampler.p_sample_ddim(img, b["cond"], ts, index=index, unconditional_guidance_scale=12.0,
+                                           unconditional_conditioning=b["uc"])
+            out.append(img)
+        return out
 
-    img = x
+    img = [b["x"] for b in batches]
     for i in range(max(args.warmup, 2)):       # >= 2: eager pass + hipGraph capture pass
         img = ddim_step(i, img)
     torch.cuda.synchronize()
@@ -413,7 +506,7 @@ def main():
     mdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    img = x
+    img = [b["x"] for b in batches]
     for i in range(args.steps):
         img = ddim_step(i, img)
     torch.cuda.synchronize()
@@ -429,12 +522,21 @@ def main():
         lib.moca_event_elapsed_ms(a, b, C.byref(ms))
         unet_ms.append(ms.value)
         lib.moca_event_destroy(a); lib.moca_event_destroy(b)
+    img = torch.cat(img)                                                     # [prompts of this rank, 4, T, H, W]
     finite = bool(torch.isfinite(img).all().item())
+    if world > 1 and len(rows) * world != N_PROMPTS:                         # uneven shards: pad to the longest for the gather
+        pad = -(-N_PROMPTS // world) - len(rows)
+        img = torch.cat([img, img[-1:].expand(pad, -1, -1, -1, -1)]) if pad > 0 else img
     outs = mdist.gather_results(img, dst=0)                                  # C2
 
     if rank != 0:
         return
-    unet_steps = 2 * args.steps * world
+    n_prompts = (len(rows) if emu else 1) if world == 1 else N_PROMPTS
+    if multi is not None:
+        multi.update({"prompts_total": N_PROMPTS, "prompts_per_rank": len(rows), "prompts_per_forward": batches[0]["n"],
+                      "forwards_per_step_per_rank": len(batches), "gathered_result_tensors": len(outs),
+                      "gathered_results_finite": all(bool(torch.isfinite(o).all()) for o in outs)})
+    unet_steps = 2 * args.steps * n_prompts
     value = unet_steps / dt
     concurrent = args.cfg_mode == "concurrent"
     avg_launch_ms = sum(unet_ms) / max(len(unet_ms), 1)
@@ -445,7 +547,7 @@ def main():
         flop_per_launch = flop_unit
         achieved = 2 * flop_unit / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
     else:
-        flop_per_launch = 2 * flop_unit            # one launch = batched cond+uncond forward
+        flop_per_launch = 2 * batches[0]["n"] * flop_unit      # one launch = batched (cond + uncond) x prompts forward
         achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
     name, cus = mlib.device_info()
     traffic_bytes, traffic_src = traffic_from_profile()
@@ -459,13 +561,18 @@ def main():
         "warmup": max(args.warmup, 2),
         "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if world == 1 else "strong",
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
-        "config": {"workload": "VideoCrafter2 3D-UNet 16x320x512 (latents [1,4,%d,%d,%d]), DDIM S=50 eta=1 CFG=12, single prompt "
-                               "per GPU; step = 1 DDIM step = 2 UNet-steps (batched cond+uncond) + CFG + DDIM update" % (T, H, W),
-                   "unet_steps_per_step": 2, "context_tokens": 77, "weights": "random-init, 1.41B params, fp16 packed",
+        "config": {"workload": ("VideoCrafter2 3D-UNet 16x320x512 (latents [1,4,%d,%d,%d]), DDIM S=50 eta=1 CFG=12, single prompt; "
+                                "step = 1 DDIM step = 2 UNet-steps (batched cond+uncond) + CFG + DDIM update" % (T, H, W)) if world == 1 else
+                               ("BASELINE configs[4]: %d prompt rows strided over %d GPUs (videocrafter_main.py:181), VideoCrafter2 3D-UNet "
+                                "16x320x512, DDIM S=50 eta=1 CFG=12; step = 1 DDIM step of ALL %d prompts = %d UNet-steps, each rank "
+                                "running its %d rows as %d forward(s) of B=%d" % (N_PROMPTS, world, N_PROMPTS, 2 * N_PROMPTS, len(rows),
+                                                                                  len(batches), 2 * batches[0]["n"])),
+                   "unet_steps_per_step": 2 * n_prompts, "context_tokens": 77, "weights": "random-init, 1.41B params, fp16 packed" +
+                   ("" if world == 1 else "; materialised on rank 0 only, RCCL broadcast (C1), checksums all-gathered"),
                    "parallelism": f"dp{world} (independent prompts, no collective in the loop)",
                    "hipgraph_replay": graph_on, "cfg_mode": args.cfg_mode, "device": name, "compute_units": cus, "output_finite": finite},
         "achieved_tflops": round(value / world * FLOP_PER_UNET_STEP / 1e12, 2),
@@ -474,9 +581,17 @@ def main():
                      "kernel": "UNet forward launch sequence (hipGraph of %d launches; the implicit-GEMM conv/linear kernels "
                                "gemm_w80s/gemm_glds/gemm_g4 are 80%% of its kernel time, "
                                "profiles/r02_bench_kernel_stats_summary.txt)" % n_launches +
-                               (", two B=1 graphs on two streams" if concurrent else ", batch 2"),
+                               (", two B=1 graphs on two streams" if concurrent else ", batch %d" % (2 * batches[0]["n"])),
                      "flop_per_launch": flop_per_launch, "avg_launch_ms": round(avg_launch_ms, 3), "launches": len(unet_ms)},
     }
+    if multi is not None:
+        res["multi_gpu"] = multi
+    if emu:
+        res["emulated_world"] = emu
+        res["config"]["workload"] = ("1-GPU rehearsal of rank 0 of the %d-GPU configs[4] job: %d prompt rows as %d forward(s) of B=%d per DDIM "
+                                     "step; no collectives; value = this GPU alone" % (emu, len(rows), len(batches), 2 * batches[0]["n"]))
+        print(json.dumps(res))
+        return
     if world == 1 and not args.no_fifo:
         zdd = ZeroDataDenoiser(dm)
         res["fifo"] = fifo_leg(dm, device, T, H, W)

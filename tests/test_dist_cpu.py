@@ -85,6 +85,52 @@ def test_bench_launches_its_own_ranks():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["ranks_gathered"] == [0, 1] and res["weights_equal_after_broadcast"]
     assert res["steps"] == 3
+    mg = res["multi_gpu"]                          # C1 proof: ranks as the backend saw them, bytes moved, checksums equal and finite
+    assert mg["rccl_ranks"] == 2 and mg["backend"] == "gloo" and mg["broadcast_bytes"] == (64 * 64 + 64 + 64 * 8 + 8) * 4
+    assert mg["param_checksums_equal"] and mg["broadcast_s"] > 0 and all(v == v for v in mg["param_checksum_rank0"])
+    assert res["rows_covered"]                     # the 64 prompt rows of config[4], strided over the ranks, all accounted for
+
+
+def test_bench_fails_when_the_broadcast_is_skipped():
+    """negative test: only rank 0 materialises the weights (the others hold NaN), so a C1 that does not happen must end the job
+    with a non-zero exit code and no JSON line -- promptly (the launcher ends the remaining ranks)"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["MOCA_BENCH_STUB_BROADCAST"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--selftest-cpu"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "checksums differ" in r.stderr
+    assert not any(l.lstrip().startswith("{") for l in r.stdout.splitlines())
+    assert time.time() - t0 < 300
+
+
+def test_launcher_ends_the_job_when_one_rank_dies():
+    """a rank that dies during start-up must not leave the others waiting in the rendezvous: launch_ranks polls every child"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, time\n"
+            "sys.argv = ['bench.py']\n"
+            "sys.path.insert(0, %r)\n"
+            "import bench\n"
+            "bench.__file__ = os.path.join(%r, 'tools', '_rank_stub.py')\n"
+            "t0 = time.time(); rc = bench.launch_ranks(2, [], timeout_s=120); print('rc', rc, 'dt', round(time.time() - t0, 1))\n") % (root, root)
+    stub = os.path.join(root, "tools", "_rank_stub.py")
+    with open(stub, "w") as f:
+        f.write("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(3)\ntime.sleep(600)\n")
+    try:
+        t0 = time.time()
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert "rc 3" in r.stdout, (r.stdout, r.stderr[-500:])
+        assert time.time() - t0 < 60
+    finally:
+        os.remove(stub)
 
 
 def test_bench_under_torchrun_env_does_not_relaunch():
