@@ -55,7 +55,7 @@ extern "C" {
                            /* moca_gemm_rowsum_cols() > 0                                     */
 #define MOCA_EP_GSTAT  256 /* GroupNorm statistics of the consumer, finished: every block adds */
                            /* the sums / sums of squares of what it stores, per (statistics    */
-                           /* group, channel group), to p.gstat (f64 atomics; zero before the  */
+                           /* group, channel group), to p.gstat (i64 fixed point; zero before  */
                            /* launch); moca_groupnorm_gstat_f16 then needs no finalize launch. */
                            /* Same kernels as MOCA_EP_COLSUM (moca_gemm_colsum_rows() > 0) and */
                            /* p.gstat_rows % that == 0                                         */
@@ -113,15 +113,13 @@ typedef struct moca_gemm_params {
     const float* lnf_wsum; /* MOCA_EP_LNFOLD: f32 [N], sum over k of the packed fp16 W'[n][k]                           */
     int32_t     lnf_nparts;
     int32_t     reserved2_;
-    double*     gstat;     /* MOCA_EP_GSTAT: f64 [M / gstat_rows][32][2] accumulators (sum, sum of squares) per
+    int64_t*    gstat;     /* MOCA_EP_GSTAT: i64 [M / gstat_rows][32][2] fixed-point accumulators (sum in 2^-30 units, sum of squares
+                              in 2^-16 units: integer atomics, so the result does not depend on the arrival order of the blocks) per
                               (statistics group, GroupNorm channel group of N / 32 columns)                             */
     int32_t     gstat_rows;/* rows per statistics group (frames_per_stat * H*W of the consumer's GroupNorm)             */
     float       tattn_scale;/* MOCA_EP_TATTN: softmax scale (dim_head ** -0.5); frames / pixels per frame in T / HW     */
-    uint32_t*   sk_sync;   /* two-piece split (sk_big > 0): 2 words per output tile, zero before the first launch; the
-                              launch leaves them zero                                                                 */
-    int32_t     sk_big;    /* > 0: every 256-row output tile is computed by TWO blocks, k-tiles [0, sk_big) and [sk_big, end);
-                              the first to finish leaves its fp32 partial sums in splitk_ws, the second adds them and runs
-                              the epilogue -- no reduce launch (what moca_gemm_two_piece() returned, with splits == 1)       */
+    void*       reserved5_;
+    int32_t     reserved6_;
     int32_t     reserved4_;
 } moca_gemm_params;
 
@@ -148,11 +146,6 @@ int moca_gemm_lnfold_ok(const moca_gemm_params* p);
 /* 1 when this call can run as MOCA_EP_TATTN (linear, K % 64 == 0, N % 192 == 0, T == 16, HW % 20 == 0, M % (16 HW) == 0,
  * no split-K / residual / row add); else 0 (the caller then runs the projection and moca_temporal_attention_f16).       */
 int moca_gemm_tattn_ok(const moca_gemm_params* p);
-/* Launches of the 256-row kernel whose tile count leaves more than an eighth of the chip idle for a whole (long) tile time
- * (e.g. 200 tiles on 256 CUs at M = 5120, N = 1280) can run as 2 x tiles blocks instead: returns sk_big (64-deep k-tiles of the
- * first piece, chosen so that big and small pieces pack into tiles / CUs of a tile time under dynamic dispatch) or 0 when the
- * call does not qualify; *ws_bytes = fp32 workspace needed (tiles x 256 x BN x 4), *sync_words = 2 x tiles.                  */
-int moca_gemm_two_piece(const moca_gemm_params* p, int64_t* ws_bytes, int32_t* sync_words);
 /* bytes of split-K workspace moca_gemm_f16 needs for (M,N,splits) */
 int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits);
 
@@ -175,16 +168,16 @@ int moca_groupnorm_colsum_f16(const void* x, void* y, const float* gamma, const 
                               int32_t tile_rows, int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
                               float eps, int32_t silu, float* ws, void* stream);
 
-/* The same GroupNorm when the producer of x was a moca_gemm_f16 call with MOCA_EP_GSTAT: gstat f64 [F / frames_per_stat][32][2]
+/* The same GroupNorm when the producer of x was a moca_gemm_f16 call with MOCA_EP_GSTAT: gstat i64 [F / frames_per_stat][32][2]
  * holds the finished sums, so this is ONE launch (apply) and x is read once.                                          */
-int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gamma, const float* beta, const double* gstat,
+int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gamma, const float* beta, const int64_t* gstat,
                              int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
                              float eps, int32_t silu, void* stream);
 /* torch.cat([a, b], dim=channels) (openaimodel3d.py:571) of a [F*HW][C1] and b [F*HW][C2] that also ADDS the GroupNorm
  * statistics of its output to gstat (as MOCA_EP_GSTAT; zero before the launch): the ResBlock.in_layers GroupNorm that
  * follows (openaimodel3d.py:149) is then one moca_groupnorm_gstat_f16 launch.                                        */
 int moca_concat_channels_gstat_f16(const void* a, const void* b, void* out, int32_t F, int32_t HW, int32_t C1, int32_t C2,
-                                   int32_t frames_per_stat, double* gstat, void* stream);
+                                   int32_t frames_per_stat, int64_t* gstat, void* stream);
 /* zero `bytes` bytes at the 16-byte aligned `ptr` on the stream (the MOCA_EP_GSTAT accumulators of a forward are zeroed by one call) */
 int moca_memset_zero(void* ptr, int64_t bytes, void* stream);
 
@@ -366,6 +359,16 @@ int moca_event_create(void** ev_out);
 int moca_event_record(void* ev, void* stream);
 int moca_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out);
 int moca_event_destroy(void* ev);
+
+/* process-wide KERNEL-CHOICE knobs for tests and A/B runs (they select which kernel runs a shape, never what it computes);
+ * value 0..2, 1 = the default rule.  Returns the previous value or MOCA_E_BADARG. */
+#define MOCA_TUNE_GEMM_W80   0   /* 320 x 160 staggered kernel: 0 never, 1 where its tiles fill the chip, 2 wherever it applies */
+#define MOCA_TUNE_GEMM_G4    1   /* two-blocks-per-CU 256 x 128 kernel: 0 never, 1 GEGLU with K <= 640, 2 wherever it applies   */
+#define MOCA_TUNE_GEMM_SQ256 2   /* 256 x 256 staggered kernel: 0 never, 1 wide linears g4 does not take, 2 every wide linear   */
+#define MOCA_TUNE_GEMM_WIDE  3   /* 160 x 320 tiling: 0 only with MOCA_EP_LN, 1 linears with N % 320 == 0, 2 convs too          */
+#define MOCA_TUNE_GN_SLAB    4   /* single-launch GroupNorm: 0 never, 1 small tensors, 2 always                                 */
+#define MOCA_TUNE_COUNT      5
+int moca_set_tuning(int32_t knob, int32_t value);
 
 /* device query: returns 0 and fills name[len] / cu count, or MOCA_E_NODEVICE */
 int moca_device_info(char* name, int32_t len, int32_t* cu_count);

@@ -713,21 +713,9 @@ extern "C" int moca_attention_f16(const void* q, const void* k, const void* v, v
     if (ldq < heads * D || ldk < heads * D || ldv < heads * D || ldo < heads * D) return MOCA_E_BADARG;
     if ((int64_t)Bq * heads > 65535) return MOCA_E_BADARG;
     const dim3 grid((Nq + QB - 1) / QB, Bq * heads), block(256);
-    const char* e_v4 = getenv("MOCA_ATTN_V4");       // A/B runs: 0 = the first-generation kernel everywhere
-    if ((!e_v4 || atoi(e_v4) != 0) && Nk >= 2 * KT) {
-        // 8 waves (256 queries) per block (MOCA_ATTN_W8 = 1: from 2048 queries on, 2: from 512 on; A/B runs): -2.8 % at 2560 tokens in
-        // isolation on a slow box (half the K/V staging traffic per query), +6 % at 640 (too few blocks, the 8-wave barrier), and
-        // -0.1 % on the whole step on a fast box -> off by default
-        const char* e_w8 = getenv("MOCA_ATTN_W8");
-        const int w8 = e_w8 ? atoi(e_w8) : 0;
-        if (w8 != 0 && Nq >= (w8 == 2 ? 512 : 2048)) {
-            hipLaunchKernelGGL(attention_v4_kernel<8>, dim3((Nq + 255) / 256, Bq * heads), dim3(512), 0, moca_stream(stream),
-                               reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
-                               reinterpret_cast<const half_t*>(v), reinterpret_cast<half_t*>(out),
-                               heads, Nq, Nk, ldq, ldk, ldv, ldo, kv_div, scale * 1.4426950408889634f);
-            MOCA_CHECK_LAUNCH();
-            return MOCA_OK;
-        }
+    if (Nk >= 2 * KT) {
+        // (an 8-wave form, 256 queries per block, measured -2.8 % at 2560 tokens in isolation and -0.1 % on the whole step in round 2:
+        //  not kept)
         hipLaunchKernelGGL(attention_v4_kernel<4>, grid, block, 0, moca_stream(stream),
                            reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
                            reinterpret_cast<const half_t*>(v), reinterpret_cast<half_t*>(out),
@@ -735,8 +723,7 @@ extern "C" int moca_attention_f16(const void* q, const void* k, const void* v, v
         MOCA_CHECK_LAUNCH();
         return MOCA_OK;
     }
-    const char* e_short = getenv("MOCA_ATTN_SHORT");   // A/B runs: 0 = the general kernel for the short context too
-    if ((!e_short || atoi(e_short) != 0) && Nk <= KS96) {
+    if (Nk <= KS96) {
         // query groups of 128 per block: as many as keep >= ~3 blocks per CU in the launch (K / V are staged once per block)
         const int qgroups = (Nq + QB - 1) / QB;
         int q_iters = (int)(((int64_t)qgroups * Bq * heads) / 768);

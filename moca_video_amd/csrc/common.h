@@ -21,6 +21,9 @@ typedef float    f32x16 __attribute__((ext_vector_type(16)));
 
 static inline hipStream_t moca_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// current value of a MOCA_TUNE_* knob (runtime.hip; set through moca_set_tuning)
+int moca_tuning_get(int knob);
+
 // x * sigmoid(x) with v_exp + v_rcp (1 ulp each, far below the fp16 output resolution) instead of an IEEE division: the
 // GroupNorm apply pass runs it on every activation and the division's ~10 instructions were a third of its VALU work
 __device__ __forceinline__ float moca_silu(float x) {
@@ -61,6 +64,23 @@ __device__ __forceinline__ f32x2 moca_erf2(f32x2 x) {
 // value * gelu(gate) for two (value, gate) pairs
 __device__ __forceinline__ f32x2 moca_geglu2(f32x2 v, f32x2 g) {
     return v * (g * 0.5f) * (moca_erf2(g * 0.70710678118654752f) + 1.0f);
+}
+
+// GroupNorm statistics accumulated across blocks (MOCA_EP_GSTAT, concat with statistics): 64-bit FIXED-POINT atomics -- integer
+// addition is associative, so the finished statistics do not depend on the order in which the producer's blocks arrive and a
+// replayed graph reproduces its output bit for bit by construction (f64 atomicAdd did so only "in practice").  Sum: 2^-30 units
+// (|sum| < 8.6e9), sum of squares: 2^-16 units (< 1.4e14, i.e. an rms of 1.8e4 over a 4e5-element group: beyond what fp16
+// activations can hold); the rounding of a partial to those units changes a group's mean of squares by < 2^-17 * partials / elements
+// < 1e-8, far below the eps (1e-6 / 1e-5) added to the variance.  Out-of-range partials saturate.
+#define MOCA_GSTAT_SUM_SCALE 1073741824.0
+#define MOCA_GSTAT_SQ_SCALE 65536.0
+__device__ __forceinline__ void moca_gstat_add(int64_t* acc, int comp, float partial) {
+    double v = (double)partial * (comp ? MOCA_GSTAT_SQ_SCALE : MOCA_GSTAT_SUM_SCALE);
+    v = fmin(fmax(v, -9.2e18), 9.2e18);
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)__double2ll_rn(v));
+}
+__device__ __forceinline__ double moca_gstat_get(const int64_t* acc, int comp) {
+    return (double)*acc * (comp ? 1.0 / MOCA_GSTAT_SQ_SCALE : 1.0 / MOCA_GSTAT_SUM_SCALE);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

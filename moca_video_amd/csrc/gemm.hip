@@ -48,13 +48,6 @@ __device__ __forceinline__ void remap_tile_2d(int tiles_m, int tiles_n, int xn, 
     tile_n = xj * sn + j % sn;
 }
 
-// the same remap for an explicit physical index (two-piece mode of the 256-row kernel)
-__device__ __forceinline__ void remap_index(int nblk, int b, int& logical) {
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = b & 7, j = b >> 3;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-}
-
 template <int BN>
 __device__ __forceinline__ void remap_block(int nblk, int& logical) {
     // XCD-aware bijective remap: physical blocks b, b+8, b+16, ... share an XCD (L2);
@@ -579,21 +572,11 @@ struct BGather {
     unsigned a_off[NAP];          // per-lane byte offset of row slot g for the current tap
     int tap = -1, tin = 0, tiles_per_tap;
     int kt_next, kt_last;         // even tile of the next pair to issue; last pair of this block's k range
-    // Order in which the k range is walked (the sum does not care).  Tap-major = the packing order of W: all channels of tap 0,
-    // then tap 1, ...: a block sweeps its whole A footprint nine times, and with 32 tiles per XCD that footprint (6-9 MB) does not
-    // stay in the 4 MB L2 -- every sweep comes from the fabric again (GEMM FETCH_SIZE 60 GB per forward for 23 GB of operands).
-    // Channel-major (p.reserved4_ != 0; MOCA_CONV_CMAJOR=1, off by default -- see moca_gemm_f16): the nine taps of one 64-channel slice, then the next slice: the live
-    // footprint is (320 + halo) rows x 128 B per tile = 1.8 MB per XCD, the taps of a slice hit L2.  Costs one set_tap() per k-tile
-    // pair instead of one per C / 64 pairs; the weight k offset follows (tap * C + slice * 64).
-    const int ntap, cmajor;
-    int cp = 0;                   // channel-major: 64-channel slice of the next pair
-    // channel-major changes tap every pair: the per-tap address becomes  centre offset + block-uniform tap delta, selected by a
-    // per-row validity bit mask (3 VALU per row slot and pair instead of ~12); not with the fused x2 upsample (iy >> 1 is not affine)
-    unsigned a_centre[NAP], a_valid[NAP];
-
+    // The k range is walked tap-major (the packing order of W): all channels of tap 0, then tap 1, ...  A channel-major walk (the
+    // nine taps of one 64-channel slice before the next slice, so that the taps hit L2) was measured in round 2: -8 % GEMM fabric
+    // reads, +2-5 % on some convs in isolation, -0.4 % on the whole step (profiles/r02_ab_conv_channel_major.txt) -- removed.
     __device__ __forceinline__ BGather(const moca_gemm_params& p_, int lch_, int kt_begin, int kt_last_pair)
-        : p(p_), lch(lch_), tiles_per_tap(AMODE == MOCA_A_LINEAR ? (1 << 30) : p_.C / KS), kt_next(kt_begin), kt_last(kt_last_pair),
-          ntap(AMODE == MOCA_A_CONV3X3 ? 9 : (AMODE == MOCA_A_TCONV3 ? 3 : 1)), cmajor(AMODE != MOCA_A_LINEAR && (p_.reserved4_ & 0xff) != 0) {}
+        : p(p_), lch(lch_), tiles_per_tap(AMODE == MOCA_A_LINEAR ? (1 << 30) : p_.C / KS), kt_next(kt_begin), kt_last(kt_last_pair) {}
 
     __device__ __forceinline__ void init_row(int g, int m) {
         row_ok[g] = m < p.M;
@@ -628,39 +611,8 @@ struct BGather {
         }
     }
 
-    // (after the init_row() calls) centre offsets and validity masks of the channel-major walk
-    __device__ __forceinline__ void prepare_cmajor() {
-        if (!cmajor || p.up) return;
-#pragma unroll
-        for (int g = 0; g < NAP; ++g) {
-            unsigned m = 0;
-            if (AMODE == MOCA_A_CONV3X3) {
-                a_centre[g] = (unsigned)(((row_off[g] + (int64_t)(row_y[g] + 1) * p.inW + (row_x[g] + 1)) * p.C + lch * 8) * 2);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int iy = row_y[g] + t / 3, ix = row_x[g] + t % 3;
-                    if (row_ok[g] && iy >= 0 && iy < p.inH && ix >= 0 && ix < p.inW) m |= 1u << t;
-                }
-            } else {
-                a_centre[g] = (unsigned)((row_off[g] * p.C + lch * 8) * 2);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int tt = row_y[g] + t - 1;
-                    if (row_ok[g] && tt >= 0 && tt < p.T) m |= 1u << t;
-                }
-            }
-            a_valid[g] = m;
-        }
-    }
-
     __device__ __forceinline__ void set_tap(int t) {
         tap = t;
-        if (AMODE != MOCA_A_LINEAR && cmajor && !p.up) {
-            const int d = AMODE == MOCA_A_CONV3X3 ? ((t / 3 - 1) * p.inW + (t % 3 - 1)) * p.C * 2 : (t - 1) * p.HW * p.C * 2;   // block-uniform
-#pragma unroll
-            for (int g = 0; g < NAP; ++g) a_off[g] = ((a_valid[g] >> t) & 1u) ? a_centre[g] + (unsigned)d : OOB_OFF;
-            return;
-        }
         if (AMODE == MOCA_A_LINEAR) {
 #pragma unroll
             for (int g = 0; g < NAP; ++g) a_off[g] = row_ok[g] ? (unsigned)((row_off[g] + lch * 8) * 2) : OOB_OFF;
@@ -687,12 +639,6 @@ struct BGather {
     // position the stream on the pair whose even tile is kt (one integer division, prologue only)
     __device__ __forceinline__ void seek(int kt) {
         kt_next = kt;
-        if (cmajor) {
-            const int q = kt >> 1;
-            cp = q / ntap;
-            set_tap(q - cp * ntap);
-            return;
-        }
         const int t = kt / tiles_per_tap;
         tin = kt - t * tiles_per_tap;
         set_tap(t);
@@ -701,19 +647,13 @@ struct BGather {
     __device__ __forceinline__ void advance() {
         if (kt_next + 2 <= kt_last) {
             kt_next += 2;
-            if (cmajor) {
-                int t = tap + 1;
-                if (t == ntap) { t = 0; ++cp; }
-                set_tap(t);
-                return;
-            }
             tin += 2;
             if (tin >= tiles_per_tap) { tin = 0; set_tap(tap + 1); }
         }
     }
     // block-uniform byte offsets of the pair's EVEN tile (the odd one is + KS*2 bytes)
-    __device__ __forceinline__ unsigned a_soff() const { return (unsigned)((cmajor ? 2 * cp : tin) * KS * 2); }
-    __device__ __forceinline__ unsigned w_soff() const { return (unsigned)((cmajor ? tap * tiles_per_tap + 2 * cp : kt_next) * KS * 2); }
+    __device__ __forceinline__ unsigned a_soff() const { return (unsigned)(tin * KS * 2); }
+    __device__ __forceinline__ unsigned w_soff() const { return (unsigned)(kt_next * KS * 2); }
 };
 
 // ---- epilogue stage 2 of the direct-to-LDS kernels: the fp16 tile staged in LDS (`rows` x `out_bn`, row pitch `pitch` bytes)
@@ -798,8 +738,8 @@ __device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p
     __syncthreads();
     if (p.flags & MOCA_EP_GSTAT) {
         // finished statistics: column totals -> LDS, then one thread per (GroupNorm channel group touched by this tile, sum or sum
-        // of squares) adds its columns and issues ONE f64 atomic on gstat[statistics group][channel group] (a row tile lies
-        // inside one statistics group).  Sums of <= 320 x 40 values per atomic in fp32; the cross-tile accumulation is f64.
+        // of squares) adds its columns and issues ONE fixed-point atomic on gstat[statistics group][channel group] (a row tile lies
+        // inside one statistics group).  Sums of <= 320 x 40 values per atomic in fp32; the cross-tile accumulation is 64-bit fixed point (order independent, common.h).
         float a[2] = {0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -824,7 +764,7 @@ __device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p
             float t = 0.f;
             for (int c = c0; c < c1; ++c) t += red[c * 2 + comp];
             const int sg = m0 / p.gstat_rows;
-            atomicAdd(p.gstat + ((int64_t)sg * 32 + g) * 2 + comp, (double)t);
+            moca_gstat_add(p.gstat + ((int64_t)sg * 32 + g) * 2 + comp, comp, t);
         }
         return;
     }
@@ -963,7 +903,6 @@ struct LnFoldRaw { float2 p0, p1; float ws, b; };
 template <int TM, int BN>
 __device__ __forceinline__ LnFoldRaw lnfold_issue(const moca_gemm_params& p, int row, int n0, int tid) {
     LnFoldRaw r = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
-    if (p.reserved2_ & 1) return r;
     if (tid < BN) {
         r.ws = p.lnf_wsum[n0 + tid];
         r.b = p.bias ? p.bias[n0 + tid] : 0.f;
@@ -981,7 +920,7 @@ __device__ __forceinline__ LnFoldRegs lnfold_finish(const moca_gemm_params& p, c
     if (tid < TM) {
         const int m = min(row, p.M - 1);
         float s = raw.p0.x + raw.p1.x, q = raw.p0.y + raw.p1.y;
-        for (int i = 2; i < ((p.reserved2_ & 1) ? 0 : p.lnf_nparts); ++i) {
+        for (int i = 2; i < p.lnf_nparts; ++i) {
             const float2 v = *reinterpret_cast<const float2*>(p.lnf_part + ((int64_t)i * p.M + m) * 2);
             s += v.x; q += v.y;
         }
@@ -1035,17 +974,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     const int tiles_n = p.N / BN;
     const int nk_total = (p.K + BK - 1) / BK;      // (W rows are readable and zero beyond K up to the next multiple of 64)
     int split, tile, kt_begin, kt_end;
-    if (p.sk_big > 0) {
-        // two-piece mode: blocks [0, tiles) compute k-tiles [0, sk_big) of their tile, blocks [tiles, 2 tiles) the rest.  With
-        // sk_big / nk = tiles / CUs the big pieces take tiles / CUs of a tile time on `tiles` CUs while the other CUs work
-        // through the small pieces (dynamic dispatch): the launch ends after ~tiles / CUs of a tile time instead of a whole one.
-        const int ntile = tiles_m * tiles_n;
-        const int piece = (int)blockIdx.x >= ntile ? 1 : 0;
-        remap_index(ntile, (int)blockIdx.x - piece * ntile, tile);
-        split = 0;
-        kt_begin = piece ? p.sk_big : 0;
-        kt_end = piece ? nk_total : p.sk_big;
-    } else {
+    {
         const int nblk = tiles_m * tiles_n * p.splits;
         int logical;
         remap_block<BN>(nblk, logical);
@@ -1206,52 +1135,6 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     for (; i < nk; ++i) step(no_t{}, i, i + 1 < nk);       // last two tiles: nothing left to prefetch
     MOCA_STAMP(3);
     __syncthreads();   // all fragment reads done before the ring is reused by the epilogue
-
-    if (p.sk_big > 0) {
-        // two-piece mode: whichever block of the tile finishes first leaves its accumulators (in register order: coalesced 16-byte
-        // stores) in splitk_ws and raises the tile's flag; the second adds them (a + b == b + a: the result does not depend on
-        // who was first) and runs the epilogue.  sk_sync[2 tile] = arrival counter, [2 tile + 1] = "partial sums are visible";
-        // the second block zeroes both.  The only wait is the second block's, for a first block that is already storing.
-        unsigned* __restrict__ sync = p.sk_sync + 2 * tile;
-        unsigned* s_old = reinterpret_cast<unsigned*>(smem);
-        if (tid == 0) *s_old = atomicAdd(sync, 1u);
-        __syncthreads();
-        const bool first = *s_old == 0;
-        float* ws = p.splitk_ws + (int64_t)tile * (TM * BN);
-        // The partial sums travel as agent-scope (write-through / cache-bypassing) accesses of their own: an agent-scope FENCE
-        // here writes back and invalidates the whole L2 of the XCD under the other blocks' operand streams (measured: +80-100 us
-        // per launch).  Element e of (mt, nt) of thread t lives at ((mt NT + nt) 4 + e) 512 + t: 256-byte runs per wavefront.
-        if (first) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        __hip_atomic_store(ws + ((mt * NT + nt) * 4 + e) * 512 + tid, acc[mt][nt][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every store acknowledged at the coherence point
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(2);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[mt][nt][e] += __hip_atomic_load(ws + ((mt * NT + nt) * 4 + e) * 512 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) {
-            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-    }
 
     // The MFMAs above compute the TRANSPOSED tile (W fragment as A operand), so accumulator element r
     // of tile (mt, nt) is row m = wave_m*64 + mt*16 + fr, column n = wave_n*BN/2 + nt*16 + 4*fg + r:
@@ -1462,7 +1345,8 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
         }
     };
     // k-tiles travel in (even, odd) pairs: the two 64-byte halves of every 128-byte line are requested back to back
-    // (see gemm_w80_kernel); the pair's 12 DMA instructions are interleaved, so a pair lands as a unit
+    // (one phase apart the 32 KiB vector L1 has turned over and every line crosses L2 -> L1 twice: +10-22 % on the short-K
+    // linears, measured); the pair's 12 DMA instructions are interleaved, so a pair lands as a unit
     auto issue_pair = [&](int kt_even, int slot_even, int slot_odd) {
         ga.begin_tile(kt_even);
 #pragma unroll
@@ -1570,7 +1454,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     const int out_bn = geglu ? BN / 2 : BN;
     const int on0 = geglu ? n0 / 2 : n0;
     const int pitch = out_bn * 2 + 16;
-    const bool fold = (p.flags & MOCA_EP_LNFOLD) != 0 && !(p.reserved2_ & 2);         // Linear(LayerNorm(x)) from x: row statistics -> LDS behind the staged tile
+    const bool fold = (p.flags & MOCA_EP_LNFOLD) != 0;         // Linear(LayerNorm(x)) from x: row statistics -> LDS behind the staged tile
     float* rst = reinterpret_cast<float*>(smem + TM * (BN * 2 + 16));
     if (fold) lnfold_publish<TM, BN>(lf, rst, tid);
     if (geglu) {
@@ -1620,477 +1504,6 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     }
     __syncthreads();
     store_fp16_tile<256>(p, smem, pitch, TM, out_bn, m0, on0, tid);
-}
-
-
-// =====================================================================================
-// "w80" kernel: 320 x 160 x 32 block tile, 512 threads = 8 wavefronts (4 x 2, two per SIMD), wave tile 80 x 80 as
-// 5 x 5 v_mfma_f32_16x16x32_f16 accumulators.
-//
-// Why this shape.  (1) Every layer of this UNet has M = 5 * 2^a rows and N = 5 * 2^b columns, so 320 x 160 tiles
-// give power-of-two tile counts -- whole rounds of the 256 CUs; the 256 x 128 tiling leaves 400 tiles (1.56 rounds)
-// at the 640-channel level and 640 (2.5 rounds) for the N = 320 layers.  (2) LDS traffic: a 64 x 64 wave tile needs 8
-// ds_read_b128 per 16 MFMAs, an 80 x 80 tile 10 per 25 -- 20 % fewer reads per flop out of the LDS array that the
-// ring's DMA writes also go through.  (3) tools/micro/mfma_peak.hip: back-to-back v_mfma_f32_16x16x32_f16 from ONE
-// wave per SIMD top out at 58-63 % of the matrix peak (1.44-1.58 PFLOP/s), two waves per SIMD reach 90 %; a
-// one-wave-per-SIMD variant of this kernel with 160 x 80 register tiles measured 20 % slower than the 8-wave kernel.
-// So: two waves per SIMD, <= 256 registers each (100 accumulators + 2 x 40 fragment registers).
-//
-// Pipeline: k-tiles of 32 (64-byte LDS rows, swizzle and DMA image of g4), 5-slot direct-to-LDS ring of 30 KiB tiles,
-// DMA five tiles ahead; fragments double-buffered in registers: phase i runs the 25 MFMAs of tile i from set (i & 1)
-// while the 10 ds_reads of tile i+1 fill the other set and this wave's 4 DMA instructions of tile i+5 go out,
-// hand-interleaved; one counted s_waitcnt + s_barrier per phase.  k-tiles are fetched in pairs by the even phases (8 DMA
-// instructions per wave, none in odd phases) so that both 64-byte halves of a 128-byte line are requested together; every
-// wave issues the same number (past the end of the k range the last pair is fetched again into slots nobody reads; the two
-// left-over W pieces are fetched twice), so the two vmcnt immediates (even / odd phase) are right for every wave.
-// =====================================================================================
-template <int AMODE, bool FAST>
-__global__ __launch_bounds__(512, 2) void gemm_w80_kernel(const moca_gemm_params p) {
-    constexpr int MT = 5, NT = 5, BN = 160, KS = 32, RB = 64;
-    constexpr int TM = 320;
-    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB;     // 20 + 10 KiB
-    constexpr int NS = 5;
-    constexpr int PPW = 4;                               // DMA instructions per wave per k-tile (30 pieces + 2 repeats)
-    constexpr int NAP = 3;                               // A piece slots per wave (the third one only for waves 0..3)
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    MOCA_STAMP(0);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 1, wave_n = wave & 1;
-
-    const int tiles_m = (p.M + TM - 1) / TM;
-    const int tiles_n = p.N / BN;
-    const int nblk = tiles_m * tiles_n * p.splits;
-    int logical;
-    remap_block<BN>(nblk, logical);
-    const int split = logical % p.splits;
-    const int tile = logical / p.splits;
-    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
-    const int m0 = tile_m * TM, n0 = tile_n * BN;
-
-    const int nk_total = 2 * ((p.K + 63) / 64);
-    const int kts = 2 * (((p.K + 63) / 64 + p.splits - 1) / p.splits);      // split in 64-deep units, as the host sizes it
-    const int kt_begin = split * kts;
-    const int nk = min(kt_begin + kts, nk_total) - kt_begin;
-
-    const half_t* __restrict__ Wptr = reinterpret_cast<const half_t*>(p.w);
-
-    // DMA piece = 16 rows x 64 B: lane -> row (lane >> 2), physical chunk lane & 3.  Wave w moves
-    //   j = 0: A piece w        j = 1: A piece 8 + w
-    //   j = 2: A piece 16 + w (w < 4)  or  W piece w - 4 (w >= 4)
-    //   j = 3: W piece 4 + w (w < 6)   or  W piece 2 + w (w = 6, 7: a repeat of what waves 4, 5 fetch)
-    const int lrow = lane >> 2, pch = lane & 3;
-    const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
-    const bool flex_is_a = wave < 4;
-    AGather<AMODE, FAST, NAP, KS> ga(p, lch);
-#pragma unroll
-    for (int g = 0; g < NAP; ++g) ga.init_row(g, m0 + (g < 2 ? g * 8 + wave : 16 + (wave & 3)) * 16 + lrow);
-    const int w_piece0 = wave & 3;                        // j = 2 (waves 4..7)
-    const int w_piece1 = wave < 6 ? 4 + wave : 2 + wave;  // j = 3
-    const half_t* w_row[2];
-    w_row[0] = Wptr + (int64_t)(n0 + w_piece0 * 16 + lrow) * p.ldw + lch * 8;
-    w_row[1] = Wptr + (int64_t)(n0 + w_piece1 * 16 + lrow) * p.ldw + lch * 8;
-
-    // DMA instruction j (0..3) of this wave for absolute k-tile kt (= pair base + odd) into ring slot `slot`
-    auto dma_piece = [&](int kt, int slot, int j, int odd) {
-        const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
-        if (j < 2) {
-#if defined(W80_A_HOT)       // diagnostic: every A piece re-fetches the block's first k-tile (L1-hot): instruction count and LDS writes kept, L2->L1 bytes gone
-            __builtin_amdgcn_global_load_lds((glb_ptr)(ga.a_base[j] + odd * KS), sa + (j * 8 + wave) * 1024, 16, 0, 0);
-#elif defined(W80_A_SKIP)    // diagnostic: A pieces only for one k-tile pair in nine (what an LDS-resident conv halo would fetch)
-            if ((kt >> 1) % 9 == 0) __builtin_amdgcn_global_load_lds((glb_ptr)ga.src(kt, j, odd), sa + (j * 8 + wave) * 1024, 16, 0, 0);
-#else
-            __builtin_amdgcn_global_load_lds((glb_ptr)ga.src(kt, j, odd), sa + (j * 8 + wave) * 1024, 16, 0, 0);
-#endif
-        } else if (j == 2) {
-            const half_t* sA = ga.src(kt, 2, odd);
-            const half_t* sw = w_row[0] + kt * KS;
-            const half_t* src = flex_is_a ? sA : sw;
-            const lds_ptr dst = flex_is_a ? sa + (16 + (wave & 3)) * 1024 : sa + A_BYTES + w_piece0 * 1024;
-            __builtin_amdgcn_global_load_lds((glb_ptr)src, dst, 16, 0, 0);
-        } else {
-            __builtin_amdgcn_global_load_lds((glb_ptr)(w_row[1] + kt * KS), sa + A_BYTES + w_piece1 * 1024, 16, 0, 0);
-        }
-    };
-    // k-tiles are fetched in PAIRS (2m, 2m+1): the two 64-byte halves of every 128-byte line of A and W are requested back
-    // to back, so the second one merges with / hits behind the first in the vector L1.  (Fetched one k-tile per phase, the
-    // second half came ~1 us later, after 30 KiB of other lines had gone through the 32 KiB L1: every line crossed the
-    // L2 -> L1 path twice.)
-    auto issue_pair = [&](int kt_even, int slot_even, int slot_odd) {
-        ga.begin_tile(kt_even);
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            dma_piece(kt_even, slot_even, j, 0);
-            dma_piece(kt_even + 1, slot_odd, j, 1);
-        }
-    };
-
-    const int fr = lane & 15, fg = lane >> 4;
-    // accumulators start from the bias of their 4 columns (n = wave_n*80 + nt*16 + 4*fg + r): the epilogue is then a pure
-    // fp32 -> fp16 conversion.  With split-k the bias is added once, by the reduce kernel.
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && p.splits == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + wave_n * 80 + nt * 16 + 4 * fg);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
-    }
-
-    // fragment byte offsets inside a slot; tile rows advance in steps of 16, which leaves the swizzle term unchanged
-    const int swz = (fg ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
-    const int a_off0 = (wave_m * 80 + fr) * RB + swz;
-    const int b_off0 = A_BYTES + (wave_n * 80 + fr) * RB + swz;
-
-    half8v af[2][MT], bf[2][NT];
-    auto read_frag = [&](auto set_tag, int slot, int r) {      // r-th fragment read of a tile: W first, then A
-        constexpr int S = decltype(set_tag)::value;
-        const char* cur = smem + slot * STAGE;
-        if (r < NT) bf[S][r] = *reinterpret_cast<const half8v*>(cur + b_off0 + r * 1024);
-        else af[S][r - NT] = *reinterpret_cast<const half8v*>(cur + a_off0 + (r - NT) * 1024);
-    };
-    auto sync_tiles = [&](auto n_tag) {      // at most n younger DMA groups of this wave in flight, then barrier
-        constexpr int n = decltype(n_tag)::value;
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n * PPW) : "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-    const int kt_last_pair = kt_begin + nk - 2;          // nk is even: the last (even, odd) pair of this block's k range
-    int s_cur = 0, s_nxt = 1;          // ring slots of tiles i and i+1
-    constexpr int NMMA = MT * NT, NRD = MT + NT;
-    // phase i: MFMAs of tile i from fragment set S = i & 1; reads of tile i+1 into the other set; EVEN phases also issue the
-    // pair (i+4, i+5): tile i+4 goes to the slot of tile i-1, tile i+5 to the slot of tile i (both fully read by now).
-    auto phase = [&](auto set_tag, int i) {
-        constexpr int S = decltype(set_tag)::value;
-        const int ktn = min(kt_begin + i + 4, kt_last_pair);
-        const int s_prev = s_cur == 0 ? NS - 1 : s_cur - 1;
-        if constexpr (S == 0) ga.begin_tile(ktn);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < NMMA; ++j) {
-            const int mt = j / NT, nt = j % NT;
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[S][nt], af[S][mt], acc[mt][nt], 0, 0, 0);   // D^T: lane = row m
-            // (the fences keep the first read BEHIND MFMA 0: the compiler cannot see the inline-asm waits, so it puts an
-            //  lgkmcnt(0) of its own in front of the first use of the fragment registers -- free while nothing is in flight)
-            if (j % 2 == 0 && j / 2 < NRD) {
-                __builtin_amdgcn_sched_barrier(0);
-#ifndef W80_NO_READ
-                read_frag(int_c<1 - S>{}, s_nxt, j / 2);      // (past the last tile this reads a never-used slot into the idle set)
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (S == 0) {
-                if (j % 3 == 1 && j / 3 < 2 * PPW) {
-                    const int q = j / 3;                       // 0..7: piece q>>1 of the even tile, then of its odd partner
-                    __builtin_amdgcn_sched_barrier(0);
-#ifndef W80_NO_DMA
-                    if (q & 1) dma_piece(ktn + 1, s_cur, q >> 1, 1);
-                    else dma_piece(ktn, s_prev, q >> 1, 0);
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        s_cur = s_nxt;
-        s_nxt = (s_nxt + 1 == NS) ? 0 : s_nxt + 1;
-    };
-
-    // ---- prologue: tiles 0..3 (two pairs) in flight, fragments of tile 0 in set 0 ----
-    // The DMA instructions of a pair are issued interleaved (even piece j, odd piece j, ...), so a pair lands as a unit:
-    // the waits count whole pairs (8 instructions per wave).
-    issue_pair(kt_begin, 0, 1);
-    issue_pair(min(kt_begin + 2, kt_last_pair), 2, 3);
-    MOCA_STAMP(1);
-    sync_tiles(int_c<2>{});                          // pair (0, 1) landed; pair (2, 3) may fly
-    MOCA_STAMP(2);
-#pragma unroll
-    for (int r = 0; r < NRD; ++r) read_frag(int_c<0>{}, 0, r);
-    sync_tiles(int_c<2>{});                          // everyone has read tile 0 (its slot is reused by phase 0's DMA)
-    // even phase i issues pair (i+4, i+5) and then needs tile i+2: pair (i+2, i+3) complete, the new pair may fly;
-    // the odd phase i+1 issues nothing and needs tile i+3, which landed with its partner
-    for (int i = 0; i < nk; i += 2) {
-        phase(int_c<0>{}, i);
-        sync_tiles(int_c<2>{});
-        phase(int_c<1>{}, i + 1);
-        sync_tiles(int_c<2>{});
-    }
-    sync_tiles(int_c<0>{});            // every DMA (incl. the repeats) and fragment read is done: the ring is free for the epilogue
-    MOCA_STAMP(3);
-
-    // ---- epilogue: lane owns 4 consecutive columns n = wave_n*80 + nt*16 + 4*fg + r of row m = wave_m*80 + mt*16 + fr ----
-    if (p.splits > 1) {
-        float* ws = p.splitk_ws + (int64_t)split * p.M * p.N;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int row = m0 + wave_m * 80 + mt * 16 + fr;
-            if (row < p.M) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int col = n0 + wave_n * 80 + nt * 16 + 4 * fg;
-                    *reinterpret_cast<f32x4*>(ws + (int64_t)row * p.N + col) = acc[mt][nt];
-                }
-            }
-        }
-        return;
-    }
-    constexpr int pitch = BN * 2 + 16;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = wave_n * 80 + nt * 16 + 4 * fg;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int row = wave_m * 80 + mt * 16 + fr;
-            *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = __builtin_convertvector(acc[mt][nt], half4v);
-        }
-    }
-    __syncthreads();
-    MOCA_STAMP(4);
-    store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
-    MOCA_STAMP(5);
-#ifdef MOCA_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_stamps[blockIdx.x * STAMP_SLOTS + 6] = hw;
-        g_stamps[blockIdx.x * STAMP_SLOTS + 7] = xcc;
-    }
-#endif
-}
-
-// "w80b": the w80 kernel with BUFFER-addressed LDS-DMA (BGather above): descriptor in SGPRs + one 32-bit VGPR offset per row
-// slot + scalar k offsets, zero fill by the hardware range check.  Same tiles, ring, schedule, fragment reads and epilogue as
-// gemm_w80_kernel; only the source addressing of the DMA stream differs.  Fast-gather shapes only (C % 64 == 0 / K % 64 == 0).
-template <int AMODE>
-__global__ __launch_bounds__(512, 2) void gemm_w80b_kernel(const moca_gemm_params p) {
-#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the launch stub; __amdgpu_buffer_rsrc_t is a device-only type)
-    constexpr int MT = 5, NT = 5, BN = 160, KS = 32, RB = 64;
-    constexpr int TM = 320;
-    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB;     // 20 + 10 KiB
-    constexpr int NS = 5;
-    constexpr int PPW = 4;                               // DMA instructions per wave per k-tile (30 pieces + 2 repeats)
-    constexpr int NAP = 3;                               // A piece slots per wave (the third one only for waves 0..3)
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    MOCA_STAMP(0);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 1, wave_n = wave & 1;
-
-    const int tiles_m = (p.M + TM - 1) / TM;
-    const int tiles_n = p.N / BN;
-    const int nblk = tiles_m * tiles_n * p.splits;
-    int logical;
-    remap_block<BN>(nblk, logical);
-    const int split = logical % p.splits;
-    const int tile = logical / p.splits;
-    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
-    const int m0 = tile_m * TM, n0 = tile_n * BN;
-
-    const int nk_total = 2 * ((p.K + 63) / 64);
-    const int kts = 2 * (((p.K + 63) / 64 + p.splits - 1) / p.splits);      // split in 64-deep units, as the host sizes it
-    const int kt_begin = split * kts;
-    const int nk = min(kt_begin + kts, nk_total) - kt_begin;
-
-    // DMA piece = 16 rows x 64 B: lane -> row (lane >> 2), physical chunk lane & 3.  Wave w moves
-    //   j = 0: A piece w        j = 1: A piece 8 + w
-    //   j = 2: A piece 16 + w (w < 4)  or  W piece w - 4 (w >= 4)
-    //   j = 3: W piece 4 + w (w < 6)   or  W piece 2 + w (w = 6, 7: a repeat of what waves 4, 5 fetch)
-    const int lrow = lane >> 2, pch = lane & 3;
-    const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
-    const bool flex_is_a = wave < 4;
-    const int kt_last_pair = kt_begin + nk - 2;          // nk is even: the last (even, odd) pair of this block's k range
-    BGather<AMODE, NAP, KS> ga(p, lch, kt_begin, kt_last_pair);
-#pragma unroll
-    for (int g = 0; g < NAP; ++g) ga.init_row(g, m0 + (g < 2 ? g * 8 + wave : 16 + (wave & 3)) * 16 + lrow);
-    const int w_piece0 = wave & 3;                        // j = 2 (waves 4..7)
-    const int w_piece1 = wave < 6 ? 4 + wave : 2 + wave;  // j = 3
-    const unsigned w_off0 = (unsigned)(((int64_t)(n0 + w_piece0 * 16 + lrow) * p.ldw + lch * 8) * 2);
-    const unsigned w_off1 = (unsigned)(((int64_t)(n0 + w_piece1 * 16 + lrow) * p.ldw + lch * 8) * 2);
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, OOB_OFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, OOB_OFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_f = flex_is_a ? rsrc_a : rsrc_w;          // wave-uniform: piece j = 2 is an A piece for waves 0..3
-
-    // DMA instruction j (0..3) of this wave for the tile `odd` of the pair the gather stream stands on, into ring slot `slot`
-    // (the k offset of the odd tile goes into soffset, NOT the instruction's immediate: on an LDS-DMA the immediate offset is
-    //  added to the LDS address as well as to the memory address)
-    auto dma_piece = [&](int slot, int j, auto odd_tag) {
-        constexpr int odd = decltype(odd_tag)::value;
-        const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
-        if (j < 2) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, sa + (j * 8 + wave) * 1024, 16, ga.a_off[j], ga.a_soff() + odd * KS * 2, 0, 0);
-        } else if (j == 2) {
-            const unsigned voff = flex_is_a ? ga.a_off[2] : w_off0;
-            const unsigned soff = flex_is_a ? ga.a_soff() : ga.w_soff();
-            const lds_ptr dst = flex_is_a ? sa + (16 + (wave & 3)) * 1024 : sa + A_BYTES + w_piece0 * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_f, dst, 16, voff, soff + odd * KS * 2, 0, 0);
-        } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, sa + A_BYTES + w_piece1 * 1024, 16, w_off1, ga.w_soff() + odd * KS * 2, 0, 0);
-        }
-    };
-    // k-tiles are fetched in PAIRS (2m, 2m+1): the two 64-byte halves of every 128-byte line of A and W are requested back
-    // to back (see gemm_w80_kernel)
-    auto issue_pair = [&](int slot_even, int slot_odd) {
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            dma_piece(slot_even, j, int_c<0>{});
-            dma_piece(slot_odd, j, int_c<1>{});
-        }
-    };
-
-    const int fr = lane & 15, fg = lane >> 4;
-    // accumulators start from the bias of their 4 columns (n = wave_n*80 + nt*16 + 4*fg + r): the epilogue is then a pure
-    // fp32 -> fp16 conversion.  With split-k the bias is added once, by the reduce kernel.
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && p.splits == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + wave_n * 80 + nt * 16 + 4 * fg);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
-    }
-
-    // fragment byte offsets inside a slot; tile rows advance in steps of 16, which leaves the swizzle term unchanged
-    const int swz = (fg ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
-    const int a_off0 = (wave_m * 80 + fr) * RB + swz;
-    const int b_off0 = A_BYTES + (wave_n * 80 + fr) * RB + swz;
-
-    half8v af[2][MT], bf[2][NT];
-    auto read_frag = [&](auto set_tag, int slot, int r) {      // r-th fragment read of a tile: W first, then A
-        constexpr int S = decltype(set_tag)::value;
-        const char* cur = smem + slot * STAGE;
-        if (r < NT) bf[S][r] = *reinterpret_cast<const half8v*>(cur + b_off0 + r * 1024);
-        else af[S][r - NT] = *reinterpret_cast<const half8v*>(cur + a_off0 + (r - NT) * 1024);
-    };
-    auto sync_tiles = [&](auto n_tag) {      // at most n younger DMA groups of this wave in flight, then barrier
-        constexpr int n = decltype(n_tag)::value;
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n * PPW) : "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-    int s_cur = 0, s_nxt = 1;          // ring slots of tiles i and i+1
-    constexpr int NMMA = MT * NT, NRD = MT + NT;
-    // phase i: MFMAs of tile i from fragment set S = i & 1; reads of tile i+1 into the other set; EVEN phases also issue the
-    // pair (i+4, i+5): tile i+4 goes to the slot of tile i-1, tile i+5 to the slot of tile i (both fully read by now).
-    auto phase = [&](auto set_tag, int i) {
-        constexpr int S = decltype(set_tag)::value;
-        const int s_prev = s_cur == 0 ? NS - 1 : s_cur - 1;
-        if constexpr (S == 0) ga.advance();               // the pair (i+4, i+5) (clamped to the last pair of the k range)
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < NMMA; ++j) {
-            const int mt = j / NT, nt = j % NT;
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[S][nt], af[S][mt], acc[mt][nt], 0, 0, 0);   // D^T: lane = row m
-            // (the fences keep the first read BEHIND MFMA 0: the compiler cannot see the inline-asm waits, so it puts an
-            //  lgkmcnt(0) of its own in front of the first use of the fragment registers -- free while nothing is in flight)
-            if (j % 2 == 0 && j / 2 < NRD) {
-                __builtin_amdgcn_sched_barrier(0);
-#ifndef W80_NO_READ
-                read_frag(int_c<1 - S>{}, s_nxt, j / 2);      // (past the last tile this reads a never-used slot into the idle set)
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (S == 0) {
-                if (j % 3 == 1 && j / 3 < 2 * PPW) {
-                    const int q = j / 3;                       // 0..7: piece q>>1 of the even tile, then of its odd partner
-                    __builtin_amdgcn_sched_barrier(0);
-#ifndef W80_NO_DMA
-                    if (q & 1) dma_piece(s_cur, q >> 1, int_c<1>{});
-                    else dma_piece(s_prev, q >> 1, int_c<0>{});
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        s_cur = s_nxt;
-        s_nxt = (s_nxt + 1 == NS) ? 0 : s_nxt + 1;
-    };
-
-    // ---- prologue: tiles 0..3 (two pairs) in flight, fragments of tile 0 in set 0 ----
-    // The DMA instructions of a pair are issued interleaved (even piece j, odd piece j, ...), so a pair lands as a unit:
-    // the waits count whole pairs (8 instructions per wave).
-    ga.prepare_cmajor();
-    ga.seek(kt_begin);
-    issue_pair(0, 1);
-    ga.advance();
-    issue_pair(2, 3);
-    MOCA_STAMP(1);
-    sync_tiles(int_c<2>{});                          // pair (0, 1) landed; pair (2, 3) may fly
-    MOCA_STAMP(2);
-#pragma unroll
-    for (int r = 0; r < NRD; ++r) read_frag(int_c<0>{}, 0, r);
-    sync_tiles(int_c<2>{});                          // everyone has read tile 0 (its slot is reused by phase 0's DMA)
-    // even phase i issues pair (i+4, i+5) and then needs tile i+2: pair (i+2, i+3) complete, the new pair may fly;
-    // the odd phase i+1 issues nothing and needs tile i+3, which landed with its partner
-    for (int i = 0; i < nk; i += 2) {
-        phase(int_c<0>{}, i);
-        sync_tiles(int_c<2>{});
-        phase(int_c<1>{}, i + 1);
-        sync_tiles(int_c<2>{});
-    }
-    sync_tiles(int_c<0>{});            // every DMA (incl. the repeats) and fragment read is done: the ring is free for the epilogue
-    MOCA_STAMP(3);
-
-    // ---- epilogue: lane owns 4 consecutive columns n = wave_n*80 + nt*16 + 4*fg + r of row m = wave_m*80 + mt*16 + fr ----
-    if (p.splits > 1) {
-        float* ws = p.splitk_ws + (int64_t)split * p.M * p.N;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int row = m0 + wave_m * 80 + mt * 16 + fr;
-            if (row < p.M) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int col = n0 + wave_n * 80 + nt * 16 + 4 * fg;
-                    *reinterpret_cast<f32x4*>(ws + (int64_t)row * p.N + col) = acc[mt][nt];
-                }
-            }
-        }
-        return;
-    }
-    constexpr int pitch = BN * 2 + 16;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = wave_n * 80 + nt * 16 + 4 * fg;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int row = wave_m * 80 + mt * 16 + fr;
-            *reinterpret_cast<half4v*>(smem + row * pitch + col * 2) = __builtin_convertvector(acc[mt][nt], half4v);
-        }
-    }
-    __syncthreads();
-    MOCA_STAMP(4);
-    store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
-    MOCA_STAMP(5);
-#ifdef MOCA_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_stamps[blockIdx.x * STAMP_SLOTS + 6] = hw;
-        g_stamps[blockIdx.x * STAMP_SLOTS + 7] = xcc;
-    }
-#endif
-#endif
-}
-
-template <int AMODE, bool FAST>
-int launch_gemm_w80(const moca_gemm_params& p, hipStream_t st) {
-    const int tiles_m = (p.M + 319) / 320, tiles_n = p.N / 160;
-    const int nblk = tiles_m * tiles_n * p.splits;
-    constexpr int lds = 5 * (320 + 160) * 64;       // 150 KiB ring; the fp16 epilogue tile (320 x 336 B) fits inside it
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w80_kernel<AMODE, FAST>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return MOCA_E_LAUNCH;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_w80_kernel<AMODE, FAST>), dim3(nblk), dim3(512), lds, st, p);
-    MOCA_CHECK_LAUNCH();
-    return MOCA_OK;
 }
 
 
@@ -2279,7 +1692,6 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     // ---- prologue: pairs (0,1) and (2,3) in flight, pair (0,1) landed everywhere ----
     LnFoldRaw lraw = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
     if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, grow(tid), n0, tid);
-    ga.prepare_cmajor();
     ga.seek(kt_begin);
     issue_pair(0, 1);
     ga.advance();
@@ -2365,7 +1777,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         }
         return;
     }
-    const bool fold = (p.flags & MOCA_EP_LNFOLD) != 0 && !(p.reserved2_ & 2);
+    const bool fold = (p.flags & MOCA_EP_LNFOLD) != 0;
     if constexpr (SQ) {
         if (p.flags & MOCA_EP_GEGLU) {                   // per 64-column group: value tiles +0, +1 and their gate tiles +2, +3 (bias is in the accumulators)
             constexpr int gpitch = (BN / 2) * 2 + 16;
@@ -2494,10 +1906,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
 // launch: estimated fabric bytes = W part + A part.  W: an XCD whose W sub-range ((tiles_n / xn) BN x K) fits its L2 (<= 3 MB)
 // fetches it once -> xm |W| in total; one that does not streams it again for every M tile it owns -> tiles_m |W| whatever
 // the partition.  A is consumed row tile by row tile -> xn |A|.  Only partitions that divide both tile counts; a 2-D partition is
-// taken when it saves >= 20 % (MOCA_GEMM_XCD2D=0: never).
+// taken when it saves >= 20 %.
 static int choose_xcd_n(const moca_gemm_params& p, int tiles_m, int tiles_n, int TM, int BN) {
-    const char* e2 = getenv("MOCA_GEMM_XCD2D");
-    if ((e2 && atoi(e2) == 0) || p.splits != 1 || p.a_mode != MOCA_A_LINEAR) return 1;
+    if (p.splits != 1 || p.a_mode != MOCA_A_LINEAR) return 1;
     const double Wtot = (double)p.N * p.K * 2, Atot = (double)p.M * p.K * 2;
     auto cost = [&](int xn) {
         const int xm = 8 / xn;
@@ -2534,22 +1945,6 @@ int launch_gemm_w80s(const moca_gemm_params& p, hipStream_t st) {
     return MOCA_OK;
 }
 
-template <int AMODE>
-int launch_gemm_w80b(const moca_gemm_params& p, hipStream_t st) {
-    const int tiles_m = (p.M + 319) / 320, tiles_n = p.N / 160;
-    const int nblk = tiles_m * tiles_n * p.splits;
-    constexpr int lds = 5 * (320 + 160) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w80b_kernel<AMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return MOCA_E_LAUNCH;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_w80b_kernel<AMODE>), dim3(nblk), dim3(512), lds, st, p);
-    MOCA_CHECK_LAUNCH();
-    return MOCA_OK;
-}
-
 // bytes spanned by the A operand / the W operand: the buffer-addressed kernels need every in-range offset below 2^31
 static inline int64_t a_span_bytes(const moca_gemm_params& p) {
     if (p.a_mode == MOCA_A_LINEAR) return ((int64_t)p.M * p.lda + 64) * 2;
@@ -2560,13 +1955,10 @@ static inline bool buffer_addressable(const moca_gemm_params& p) {
     return a_span_bytes(p) < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
 }
 
-static inline int sq256_mode() {
-    const char* e = getenv("MOCA_GEMM_SQ256");
-    return e ? atoi(e) : 1;
-}
+static inline int sq256_mode() { return moca_tuning_get(MOCA_TUNE_GEMM_SQ256); }
 static inline bool fast_gather(const moca_gemm_params& p);
 static inline bool buffer_addressable(const moca_gemm_params& p);
-// the staggered kernel on 256 x 256 tiles for the wide projections (MOCA_GEMM_SQ256 = 0: never, 1: not where g4 is preferred,
+// the staggered kernel on 256 x 256 tiles for the wide projections (MOCA_TUNE_GEMM_SQ256 = 0: never, 1: not where g4 is preferred,
 // 2: every wide linear -- A/B runs); asked after takes_w80()
 static inline bool takes_sq256(const moca_gemm_params& p, bool use_g4) {
     const int mode = sq256_mode();
@@ -2574,33 +1966,27 @@ static inline bool takes_sq256(const moca_gemm_params& p, bool use_g4) {
            !(p.flags & (MOCA_EP_OUT_F32 | MOCA_FORCE_SMALL_TILE)) && ((p.M + 255) / 256) * (p.N / 256) * p.splits >= 200 &&
            (mode == 2 || !use_g4);
 }
-static inline int w80_variant() {                     // A/B runs: 0 = flat-address w80, 1 = buffer-addressed w80b, 2 (default) = staggered w80s
-    const char* e_buf = getenv("MOCA_GEMM_BUF");
-    return e_buf ? atoi(e_buf) : 2;
-}
 static inline bool fast_gather(const moca_gemm_params& p) {
     return (p.a_mode == MOCA_A_LINEAR) ? (p.K % BK == 0 && p.K <= 8192) : (p.C % BK == 0 && p.C <= 8192);
 }
 // does this (validated, split-normalised) call run on the 320 x 160 kernels / on their staggered buffer-addressed form?
 static inline bool takes_w80(const moca_gemm_params& p) {
-    const char* e_w80 = getenv("MOCA_GEMM_W80");
-    const int w80_mode = e_w80 ? atoi(e_w80) : 1;
+    const int w80_mode = moca_tuning_get(MOCA_TUNE_GEMM_W80);
     const int tiles320 = ((p.M + 319) / 320) * (p.N / 160);
     return w80_mode && p.N % 160 == 0 && !(p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32 | MOCA_FORCE_SMALL_TILE)) && p.M > 160 &&
-           (tiles320 * p.splits >= 200 || w80_mode == 2);
+           (tiles320 * p.splits >= 200 || w80_mode == 2) && fast_gather(p) && buffer_addressable(p);
 }
 static inline bool takes_w80s(const moca_gemm_params& p) {
-    return takes_w80(p) && fast_gather(p) && w80_variant() == 2 && buffer_addressable(p);
+    return takes_w80(p);
 }
 // which form of the staggered kernel a call that takes_w80s() runs on.  The 160 x 320 tiling is required by the LayerNorm store
 // loop and taken by every N % 320 == 0 contraction: A is fetched once per 320 columns instead of once per 160 (linears: 37 vs 38 us
 // at M = 81920, N = K = 320; 99 vs 103 at K = 1280; 182 vs 193 / 366 vs 384 at M = 327680; N = 640: 22.7 vs 25.1).
 // Convs / temporal convs gain nothing from it (+-1 %, A/B on one device) and stay on the 320 x 160 form.
-// MOCA_GEMM_WIDE = 0: only with MOCA_EP_LN; 1 (default): linears; 2: convs / temporal convs too (A/B runs)
+// MOCA_TUNE_GEMM_WIDE = 0: only with MOCA_EP_LN; 1 (default): linears; 2: convs / temporal convs too (tests)
 static inline bool w80s_wide(const moca_gemm_params& p) {
     if (p.flags & MOCA_EP_LN) return true;
-    const char* e_wide = getenv("MOCA_GEMM_WIDE");
-    const int mode = e_wide ? atoi(e_wide) : 1;
+    const int mode = moca_tuning_get(MOCA_TUNE_GEMM_WIDE);
     if (mode == 0 || p.N % 320) return false;
     return p.a_mode == MOCA_A_LINEAR || mode == 2;
 }
@@ -2608,22 +1994,11 @@ static inline bool takes_w80t_ln(const moca_gemm_params& p) {     // the 160 x 3
     return p.a_mode == MOCA_A_LINEAR && p.N == 320 && p.splits == 1 && takes_w80s(p) && !(p.flags & (MOCA_EP_COLSUM | MOCA_EP_GSTAT));
 }
 
-int launch_gemm_w80_mode(const moca_gemm_params& p, bool fastp, hipStream_t st) {
-    const int buf_mode = w80_variant();
-    if (fastp && buf_mode == 2 && buffer_addressable(p)) {
-        const bool wide = w80s_wide(p);
-        if (p.a_mode == MOCA_A_LINEAR) return wide ? launch_gemm_w80s<MOCA_A_LINEAR, 1>(p, st) : launch_gemm_w80s<MOCA_A_LINEAR, 0>(p, st);
-        if (p.a_mode == MOCA_A_CONV3X3) return wide ? launch_gemm_w80s<MOCA_A_CONV3X3, 1>(p, st) : launch_gemm_w80s<MOCA_A_CONV3X3, 0>(p, st);
-        return wide ? launch_gemm_w80s<MOCA_A_TCONV3, 1>(p, st) : launch_gemm_w80s<MOCA_A_TCONV3, 0>(p, st);
-    }
-    if (fastp && buf_mode == 1 && buffer_addressable(p)) {
-        if (p.a_mode == MOCA_A_LINEAR) return launch_gemm_w80b<MOCA_A_LINEAR>(p, st);
-        if (p.a_mode == MOCA_A_CONV3X3) return launch_gemm_w80b<MOCA_A_CONV3X3>(p, st);
-        return launch_gemm_w80b<MOCA_A_TCONV3>(p, st);
-    }
-    if (p.a_mode == MOCA_A_LINEAR) return fastp ? launch_gemm_w80<MOCA_A_LINEAR, true>(p, st) : launch_gemm_w80<MOCA_A_LINEAR, false>(p, st);
-    if (p.a_mode == MOCA_A_CONV3X3) return fastp ? launch_gemm_w80<MOCA_A_CONV3X3, true>(p, st) : launch_gemm_w80<MOCA_A_CONV3X3, false>(p, st);
-    return fastp ? launch_gemm_w80<MOCA_A_TCONV3, true>(p, st) : launch_gemm_w80<MOCA_A_TCONV3, false>(p, st);
+int launch_gemm_w80_mode(const moca_gemm_params& p, hipStream_t st) {
+    const bool wide = w80s_wide(p);
+    if (p.a_mode == MOCA_A_LINEAR) return wide ? launch_gemm_w80s<MOCA_A_LINEAR, 1>(p, st) : launch_gemm_w80s<MOCA_A_LINEAR, 0>(p, st);
+    if (p.a_mode == MOCA_A_CONV3X3) return wide ? launch_gemm_w80s<MOCA_A_CONV3X3, 1>(p, st) : launch_gemm_w80s<MOCA_A_CONV3X3, 0>(p, st);
+    return wide ? launch_gemm_w80s<MOCA_A_TCONV3, 1>(p, st) : launch_gemm_w80s<MOCA_A_TCONV3, 0>(p, st);
 }
 
 template <int AMODE, bool FAST>
@@ -2648,7 +2023,7 @@ int launch_gemm_g4(const moca_gemm_params& p, hipStream_t st) {
 template <int BN, int AMODE, bool FAST>
 int launch_gemm_glds(const moca_gemm_params& p, hipStream_t st) {
     const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / BN;
-    const int nblk = tiles_m * tiles_n * (p.sk_big > 0 ? 2 : p.splits);
+    const int nblk = tiles_m * tiles_n * p.splits;
     constexpr int lds_pipe = 3 * (256 + BN) * ROW_BYTES;
     constexpr int lds_epi = 256 * BN * 4;
     constexpr int lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
@@ -2700,8 +2075,7 @@ static int takes_glds_bn(const moca_gemm_params& p) {
     if (takes_w80(p)) return 0;
     const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
     if (!(big_bn != 0 && p.M > 128 && !(p.flags & MOCA_FORCE_SMALL_TILE))) return 0;
-    const char* e_g4 = getenv("MOCA_GEMM_G4");
-    const int g4_mode = e_g4 ? atoi(e_g4) : 1;
+    const int g4_mode = moca_tuning_get(MOCA_TUNE_GEMM_G4);
     const bool use_g4 = !(p.flags & MOCA_EP_OUT_F32) && (g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640));
     if (takes_sq256(p, use_g4)) return 0;
     if (big_bn == 128 && use_g4) return 0;
@@ -2712,8 +2086,6 @@ static int takes_glds_bn(const moca_gemm_params& p) {
 static int colsum_rows(const moca_gemm_params& p) {
     if (p.splits != 1) return 0;
     if (takes_w80s(p)) return w80s_wide(p) ? 160 : 320;
-    const char* e = getenv("MOCA_GN_COLSUM_GLDS");       // A/B runs: 0 = only the staggered kernel leaves column sums
-    if (e && atoi(e) == 0) return 0;
     if (!(p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32)) && takes_glds_bn(p) != 0) return 256;
     return 0;
 }
@@ -2731,8 +2103,7 @@ static bool lnfold_ok(const moca_gemm_params& p) {
     if (takes_w80(p)) return !(p.flags & MOCA_EP_GEGLU) && takes_w80s(p);
     const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
     if (!(big_bn != 0 && p.M > 128)) return false;
-    const char* e_g4 = getenv("MOCA_GEMM_G4");
-    const int g4_mode = e_g4 ? atoi(e_g4) : 1;
+    const int g4_mode = moca_tuning_get(MOCA_TUNE_GEMM_G4);
     const bool use_g4 = g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640);
     if (takes_sq256(p, use_g4)) return true;
     if (big_bn == 128 && use_g4) return true;
@@ -2748,46 +2119,6 @@ static bool tattn_ok(const moca_gemm_params& p) {
     if (p.N % 192 || p.T != 16 || p.HW <= 0 || p.HW % 20 || p.M % (16 * p.HW)) return false;
     if (p.ldo % 4 || p.ldo < p.N / 3) return false;
     return true;
-}
-
-// two-piece mode of the 256-row kernel: sk_big for this call, 0 when it does not qualify (measured, tools/bench_quant.py: a
-// 200-tile launch takes exactly as long as a 250-tile one)
-static int two_piece_big(const moca_gemm_params& p) {
-    // OFF unless MOCA_GEMM_TWO_PIECE = n > 1 (n = the smallest k-tile count that qualifies): in the whole CFG step the mode LOSES
-    // 0.8 % (33.75 -> 34.04 ms, same-device A/B) although the long convs gain 7 % in isolation -- kept as a measured experiment.
-    const char* e = getenv("MOCA_GEMM_TWO_PIECE");
-    if (!e || atoi(e) <= 1) return 0;
-    if (p.splits != 1 || (p.flags & (MOCA_EP_OUT_F32 | MOCA_EP_GEGLU | MOCA_FORCE_SMALL_TILE | MOCA_EP_GELU | MOCA_EP_TATTN))) return 0;
-    const int bn = takes_glds_bn(p);
-    if (bn == 0) return 0;
-    const int tiles = ((p.M + 255) / 256) * (p.N / bn);
-    const int nk = (p.K + BK - 1) / BK;
-    // measured (tools/bench_two_piece.py, M = 5120, N = 1280): K = 11520: 168 -> 157 us with the big piece at tiles / CUs + 0.06 of
-    // the k range (the small pieces pay a prologue, the partial-sum exchange and an epilogue each, ~3.6 of them per free CU);
-    // K = 3840 / 5120: +10 us -- the exchange costs more than the idle CUs.  So: only >= 160 k-tiles (K >= 10240).
-    const int min_nk = e ? atoi(e) : 160;                // (MOCA_GEMM_TWO_PIECE = n > 1: the smallest k-tile count that qualifies)
-    if (tiles < 136 || tiles > 232 || nk < (min_nk > 1 ? min_nk : 160)) return 0;
-    int big = (nk * tiles + 128) / 256 + (nk * 6 + 50) / 100;
-    if (big < 1) big = 1;
-    if (big > nk - 1) big = nk - 1;
-    return big;
-}
-
-extern "C" int moca_gemm_two_piece(const moca_gemm_params* pp, int64_t* ws_bytes, int32_t* sync_words) {
-    if (ws_bytes) *ws_bytes = 0;
-    if (sync_words) *sync_words = 0;
-    if (!pp) return 0;
-    moca_gemm_params p = *pp;
-    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
-    normalise_splits(p);
-    const int big = two_piece_big(p);
-    if (big > 0) {
-        const int bn = takes_glds_bn(p);
-        const int tiles = ((p.M + 255) / 256) * (p.N / bn);
-        if (ws_bytes) *ws_bytes = (int64_t)tiles * 256 * bn * 4;
-        if (sync_words) *sync_words = 2 * tiles;
-    }
-    return big;
 }
 
 extern "C" int moca_gemm_tattn_ok(const moca_gemm_params* pp) {
@@ -2877,12 +2208,11 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     const bool fastp = fast_gather(p);
     // g4 (4 waves, two blocks per CU) wins where the epilogue is VALU-heavy and K is short (GEGLU at C = 320 / 640:
     // one block's erf-GELU epilogue runs under the other block's MFMAs, -5 % on the same device); the 8-wave kernel's
-    // deeper pipeline wins everywhere else (K >= 1280: 1137 vs 880 TFLOP/s).  MOCA_GEMM_G4=0/2 forces never/always.
-    const char* e_g4 = getenv("MOCA_GEMM_G4");      // read per call (tests / A-B runs flip it inside one process)
-    const int g4_mode = e_g4 ? atoi(e_g4) : 1;
+    // deeper pipeline wins everywhere else (K >= 1280: 1137 vs 880 TFLOP/s).  MOCA_TUNE_GEMM_G4 = 0 / 2 forces never / always (tests).
+    const int g4_mode = moca_tuning_get(MOCA_TUNE_GEMM_G4);
     const bool use_g4 = !(p.flags & MOCA_EP_OUT_F32) && (g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640));
     // w80 (320 x 160 tiles, 80 x 80 wave tiles): every non-GEGLU contraction whose N is a multiple of 160 and whose
-    // 320-row tiles fill the chip.  MOCA_GEMM_W80=0 disables it (A/B against the 256-row kernel), 2 drops the tile-count rule.
+    // 320-row tiles fill the chip.  (MOCA_TUNE_GEMM_W80: 0 never, 2 drops the tile-count rule -- tests.)
     const bool use_w80 = takes_w80(p);
     if ((p.flags & MOCA_EP_COLSUM) && !(p.colsum && colsum_rows(p) != 0)) return MOCA_E_BADARG;   // ask moca_gemm_colsum_rows() first
     if ((p.flags & MOCA_EP_LN) && !(p.ln_gamma && p.ln_beta && p.ln_out && p.ld_ln % 8 == 0 && takes_w80t_ln(p))) return MOCA_E_BADARG;   // ask moca_gemm_ln_ok() first
@@ -2892,24 +2222,14 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
               p.N % 32 == 0)) return MOCA_E_BADARG;
     }
     if ((p.flags & MOCA_EP_ROWSUM) && !(p.rowsum && rowsum_cols(p) != 0)) return MOCA_E_BADARG;             // ask moca_gemm_rowsum_cols() first
-    {   // k order of the conv / temporal-conv gathers of the buffer-addressed kernels: tap-major unless MOCA_CONV_CMAJOR=1.
-        // Measured (same device): channel-major is 2-5 % faster on the 640- / 960-channel convs in isolation, cuts the GEMM
-        // FETCH_SIZE of a forward from 59.7 to 54.9 GB -- and the whole CFG step gets 0.4 % SLOWER (34.11 -> 34.25 ms).  Off.
-        const char* e_cm = getenv("MOCA_CONV_CMAJOR");
-        p.reserved4_ = (e_cm && atoi(e_cm) != 0) ? 1 : 0;
-    }
-    if (p.sk_big != 0) {                              // ask moca_gemm_two_piece() first
-        const int nk = (p.K + BK - 1) / BK;
-        if (!(p.sk_big > 0 && p.sk_big < nk && p.splitk_ws && p.sk_sync && p.splits == 1 && takes_glds_bn(p) != 0 &&
-              !(p.flags & (MOCA_EP_OUT_F32 | MOCA_EP_GEGLU | MOCA_FORCE_SMALL_TILE | MOCA_EP_GELU | MOCA_EP_TATTN)))) return MOCA_E_BADARG;
-    }
+    p.reserved4_ = 0;                                 // (bits 8.. carry the XCD partition chosen by the launcher)
     if (p.flags & MOCA_EP_TATTN) {                    // ask moca_gemm_tattn_ok() first
         if (!tattn_ok(p) || ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1))) return MOCA_E_BADARG;
         return launch_gemm_w80s<MOCA_A_LINEAR, 3>(p, st);
     }
     if ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1 && lnfold_ok(p))) return MOCA_E_BADARG;   // ask moca_gemm_lnfold_ok() first
     if (use_w80) {
-        rc = launch_gemm_w80_mode(p, fastp, st);
+        rc = launch_gemm_w80_mode(p, st);
     } else if (takes_sq256(p, use_g4)) {
         rc = launch_gemm_w80s<MOCA_A_LINEAR, 2>(p, st);
     } else if (use_big && big_bn == 128 && use_g4) {

@@ -182,12 +182,12 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
     }
 }
 
-// ---- K3': apply with the statistics a MOCA_EP_GSTAT producer accumulated: gstat f64 [statistics group][32][2] = (sum, sum of
+// ---- K3': apply with the statistics a MOCA_EP_GSTAT producer accumulated: gstat i64 fixed point [statistics group][32][2] = (sum, sum of
 // squares), finished.  The first 32 threads of a block turn its statistics group's 32 pairs into (mean, rstd) in fp64 while the
 // block's first batch of x loads is in flight; no finalize launch exists.
 __global__ void gn_apply_gstat_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                      const double* __restrict__ gstat, int HW, int C, int nchunk,
+                                      const int64_t* __restrict__ gstat, int HW, int C, int nchunk,
                                       int frames_per_stat, double inv_count, float eps, int silu) {
     __shared__ float s_mr[2 * GN_GROUPS];
     const int f = blockIdx.x, chunk = blockIdx.y;
@@ -207,7 +207,7 @@ __global__ void gn_apply_gstat_kernel(const half_t* __restrict__ x, half_t* __re
     half8v cur[4], nxt[4];
     load4(cur, pp);
     if (tid < GN_GROUPS) {
-        const double a = gstat[((int64_t)sg * GN_GROUPS + tid) * 2], b = gstat[((int64_t)sg * GN_GROUPS + tid) * 2 + 1];
+        const double a = moca_gstat_get(gstat + ((int64_t)sg * GN_GROUPS + tid) * 2, 0), b = moca_gstat_get(gstat + ((int64_t)sg * GN_GROUPS + tid) * 2 + 1, 1);
         const double mean = a * inv_count;
         double var = b * inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -249,10 +249,10 @@ __global__ void gn_apply_gstat_kernel(const half_t* __restrict__ x, half_t* __re
 // ---- torch.cat(dim=channels) that also leaves the GroupNorm statistics of its output behind (openaimodel3d.py:571 followed by
 // ResBlock.in_layers[0], :149): the copy is a streaming pass over both inputs anyway; every thread owns 8 fixed channels of
 // the concatenated row, accumulates their sums / sums of squares over its pixels, the block combines them per channel group
-// through LDS and adds them to gstat (f64 atomics, as MOCA_EP_GSTAT) -- the consumer GroupNorm is then one apply launch instead
+// through LDS and adds them to gstat (fixed-point atomics, as MOCA_EP_GSTAT) -- the consumer GroupNorm is then one apply launch instead
 // of partial + finalize + apply.  blockDim = (C/8, ppb), grid (F, nchunk) as the GroupNorm passes. ----
 __global__ void concat_gstat_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, half_t* __restrict__ out,
-                                    double* __restrict__ gstat, int HW, int C1, int C2, int nchunk, int frames_per_stat) {
+                                    int64_t* __restrict__ gstat, int HW, int C1, int C2, int nchunk, int frames_per_stat) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int C = C1 + C2;
     float* s_sum = reinterpret_cast<float*>(smem_raw);   // [ppb][C]
@@ -297,7 +297,7 @@ __global__ void concat_gstat_kernel(const half_t* __restrict__ a, const half_t* 
         float t = 0.f;
         for (int y = 0; y < ppb; ++y)
             for (int c = g * cpg; c < (g + 1) * cpg; ++c) t += base[y * C + c];
-        atomicAdd(gstat + ((int64_t)(f / frames_per_stat) * GN_GROUPS + g) * 2 + comp, (double)t);
+        moca_gstat_add(gstat + ((int64_t)(f / frames_per_stat) * GN_GROUPS + g) * 2 + comp, comp, t);
     }
 }
 
@@ -534,8 +534,7 @@ extern "C" int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamm
     hipStream_t st = moca_stream(stream);
     const double inv_count = 1.0 / ((double)frames_per_stat * HW * (C / GN_GROUPS));
     {   // small tensors: one launch (gn_slab_kernel)
-        const char* e_slab = getenv("MOCA_GN_SLAB");     // 0: always the streaming path, 2: always the slab path (tests / A-B)
-        const int slab_mode = e_slab ? atoi(e_slab) : 1;
+        const int slab_mode = moca_tuning_get(MOCA_TUNE_GN_SLAB);   // 0: always the streaming path, 2: always the slab path (tests)
         const int cpg = C / GN_GROUPS;
         const int64_t bytes = (int64_t)F * HW * C * 2;
         const int64_t R64 = (int64_t)frames_per_stat * HW;
@@ -545,10 +544,9 @@ extern "C" int moca_groupnorm_nhwc_f16(const void* x, void* y, const float* gamm
             //  lose to the streaming path's full-row reads as soon as the tensor is more than a few MB)
             const int R = (int)R64;
             const int n_slabs = (F / frames_per_stat) * GN_GROUPS;
-            {   // slab in registers (MOCA_GN_SLAB_REG=0: never): <= 4096 chunks of 16 B, rows of >= 160 B ... or many rows
-                const char* e_reg = getenv("MOCA_GN_SLAB_REG");
+            {   // slab in registers: <= 4096 chunks of 16 B, rows of >= 160 B ... or many rows
                 const int nchunks = R * (cpg / 8);
-                if (!(e_reg && atoi(e_reg) == 0) && cpg % 8 == 0 && nchunks <= 4096 && nchunks >= 256) {
+                if (cpg % 8 == 0 && nchunks <= 4096 && nchunks >= 256) {
                     const int cpt = (nchunks + 1023) / 1024;
                     const int thr = ((nchunks + cpt - 1) / cpt + 63) / 64 * 64;
                     const half_t* xi = reinterpret_cast<const half_t*>(x);
@@ -616,7 +614,7 @@ extern "C" int moca_groupnorm_colsum_f16(const void* x, void* y, const float* ga
     return MOCA_OK;
 }
 
-extern "C" int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gamma, const float* beta, const double* gstat,
+extern "C" int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gamma, const float* beta, const int64_t* gstat,
                                         int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
                                         float eps, int32_t silu, void* stream) {
     if (!x || !y || !gamma || !beta || !gstat) return MOCA_E_BADARG;
@@ -636,7 +634,7 @@ extern "C" int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gam
 }
 
 extern "C" int moca_concat_channels_gstat_f16(const void* a, const void* b, void* out, int32_t F, int32_t HW, int32_t C1, int32_t C2,
-                                              int32_t frames_per_stat, double* gstat, void* stream) {
+                                              int32_t frames_per_stat, int64_t* gstat, void* stream) {
     if (!a || !b || !out || !gstat || F <= 0 || HW <= 0 || C1 <= 0 || C2 <= 0 || C1 % 8 || C2 % 8) return MOCA_E_BADARG;
     const int C = C1 + C2;
     if (C % GN_GROUPS || frames_per_stat <= 0 || F % frames_per_stat) return MOCA_E_BADARG;

@@ -18,7 +18,7 @@ extern "C" int moca_graph_end(void* stream, void** graph_exec_out) {
     if (hipStreamEndCapture(moca_stream(stream), &g) != hipSuccess || !g) return MOCA_E_GRAPH;
     hipGraphExec_t ge = nullptr;
     hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess || !ge) return MOCA_E_GRAPH;
     *graph_exec_out = reinterpret_cast<void*>(ge);
     return MOCA_OK;
@@ -102,6 +102,16 @@ extern "C" int moca_memset_zero(void* ptr, int64_t bytes, void* stream) {
                        reinterpret_cast<unsigned char*>(ptr) + n16 * 16, (int)(bytes - n16 * 16));
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
+}
+
+// ---- kernel-choice knobs for tests / A-B runs (never results): one table instead of getenv() calls in the launchers
+static int g_tuning[MOCA_TUNE_COUNT] = {1, 1, 1, 1, 1};
+int moca_tuning_get(int knob) { return (knob >= 0 && knob < MOCA_TUNE_COUNT) ? g_tuning[knob] : 0; }
+extern "C" int moca_set_tuning(int32_t knob, int32_t value) {
+    if (knob < 0 || knob >= MOCA_TUNE_COUNT || value < 0 || value > 2) return MOCA_E_BADARG;
+    const int old = g_tuning[knob];
+    g_tuning[knob] = value;
+    return old;
 }
 
 extern "C" const char* moca_version(void) { return "moca_hip 0.1 (gfx950)"; }

@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get("MOCA_HIP_LIB") or os.path.join(_HERE, "libmoca_hip.so
 MOCA_A_LINEAR, MOCA_A_CONV3X3, MOCA_A_TCONV3 = 0, 1, 2
 MOCA_EP_GEGLU, MOCA_EP_OUT_F32, MOCA_FORCE_SMALL_TILE, MOCA_EP_GELU, MOCA_EP_COLSUM, MOCA_EP_LN = 1, 2, 4, 8, 16, 32
 MOCA_EP_ROWSUM, MOCA_EP_LNFOLD, MOCA_EP_GSTAT, MOCA_EP_TATTN = 64, 128, 256, 512
+MOCA_TUNE_GEMM_W80, MOCA_TUNE_GEMM_G4, MOCA_TUNE_GEMM_SQ256, MOCA_TUNE_GEMM_WIDE, MOCA_TUNE_GN_SLAB = 0, 1, 2, 3, 4
 
 _ERR = {0: "ok", -1: "bad argument (shape/alignment contract)", -2: "HIP launch/runtime error",
         -3: "no gfx950 device", -4: "graph capture/replay failed"}
@@ -47,7 +48,7 @@ class GemmParams(C.Structure):
         ("rowsum", C.c_void_p), ("lnf_part", C.c_void_p), ("lnf_wsum", C.c_void_p),
         ("lnf_nparts", C.c_int32), ("reserved2_", C.c_int32),
         ("gstat", C.c_void_p), ("gstat_rows", C.c_int32), ("tattn_scale", C.c_float),
-        ("sk_sync", C.c_void_p), ("sk_big", C.c_int32), ("reserved4_", C.c_int32),
+        ("reserved5_", C.c_void_p), ("reserved6_", C.c_int32), ("reserved4_", C.c_int32),
     ]
 
 
@@ -80,7 +81,6 @@ SIGNATURES = {
     "moca_gemm_rowsum_cols": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_lnfold_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_tattn_ok": (C.c_int, [C.POINTER(GemmParams)]),
-    "moca_gemm_two_piece": (C.c_int, [C.POINTER(GemmParams), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "moca_groupnorm_colsum_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "moca_groupnorm_nhwc_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "moca_groupnorm_ws_bytes": (_i64, [_i32, _i32, _i32]),
@@ -123,6 +123,7 @@ SIGNATURES = {
     "moca_event_record": (C.c_int, [_vp, _vp]),
     "moca_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(_f32)]),
     "moca_event_destroy": (C.c_int, [_vp]),
+    "moca_set_tuning": (C.c_int, [_i32, _i32]),
     "moca_device_info": (C.c_int, [C.c_char_p, _i32, C.POINTER(_i32)]),
     "moca_version": (C.c_char_p, []),
 }
@@ -159,6 +160,14 @@ def ptr(t):
     if t is None:
         return None
     return C.c_void_p(t.data_ptr())
+
+
+def set_tuning(knob: int, value: int) -> int:
+    """kernel-choice knob for tests / A-B runs (include/moca_hip.h MOCA_TUNE_*); returns the previous value"""
+    old = load().moca_set_tuning(knob, value)
+    if old < 0:
+        raise MocaHipError(f"moca_set_tuning({knob}, {value}): bad argument")
+    return old
 
 
 def version() -> str:

@@ -132,7 +132,7 @@ def finish_lnfold(pw: PackedWeight) -> PackedWeight:
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
                  residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None,
-                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, two_piece=None):
+                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None):
     p = _l.GemmParams()
     p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), (out.data_ptr() if out is not None else None)
     p.bias = pw.bias.data_ptr() if pw.bias is not None else None
@@ -165,14 +165,10 @@ def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR
     if rowsum is not None:                   # f32 [N / cols][M][2] (cols = gemm_rowsum_cols), or True when only probing
         p.flags |= _l.MOCA_EP_ROWSUM
         p.rowsum = rowsum.data_ptr() if torch.is_tensor(rowsum) else None
-    if two_piece is not None:                # (sk_big, fp32 workspace, sync words): two blocks per output tile, no reduce launch
-        p.sk_big = two_piece[0]
-        p.splitk_ws = two_piece[1].data_ptr() if two_piece[1] is not None else None
-        p.sk_sync = two_piece[2].data_ptr() if two_piece[2] is not None else None
     if tattn is not None:                    # (T, HW, softmax scale): projection + temporal attention in one launch (MOCA_EP_TATTN)
         p.flags |= _l.MOCA_EP_TATTN
         p.T, p.HW, p.tattn_scale = tattn
-    if gstat is not None:                    # (f64 [M / rows][32][2] accumulators, zeroed before the launch; rows per statistics group)
+    if gstat is not None:                    # (i64 [M / rows][32][2] fixed-point accumulators, zeroed before the launch; rows per statistics group)
         p.flags |= _l.MOCA_EP_GSTAT
         p.gstat = gstat[0].data_ptr()
         p.gstat_rows = gstat[1]
@@ -183,7 +179,6 @@ def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR
         p.ln_eps = lnfold[2]
         p.lnf_wsum = pw.wsum.data_ptr() if pw.wsum is not None else None
     p.splits = splits
-    p.reserved2_ = int(os.environ.get('MOCA_LNFOLD_DBG', '0'))
     return p
 
 
@@ -212,14 +207,6 @@ def gemm_lnfold_ok(a, pw: PackedWeight, **kw):
     """does the kernel this call runs on have the MOCA_EP_LNFOLD epilogue?"""
     p = _gemm_params(a, pw, None, **kw)
     return bool(_l.load().moca_gemm_lnfold_ok(C.byref(p)))
-
-
-def gemm_two_piece(a, pw: PackedWeight, **kw):
-    """(sk_big, workspace bytes, sync words) when this launch should run as two blocks per output tile (see moca_hip.h), else (0, 0, 0)"""
-    p = _gemm_params(a, pw, None, **kw)
-    wsb, sw = C.c_int64(0), C.c_int32(0)
-    big = int(_l.load().moca_gemm_two_piece(C.byref(p), C.byref(wsb), C.byref(sw)))
-    return big, int(wsb.value), int(sw.value)
 
 
 def gemm_tattn_ok(a, pw: PackedWeight, **kw):
@@ -268,7 +255,7 @@ def groupnorm_gstat(x, y, gamma, beta, gstat, *, F, HW, Cn, frames_per_stat, eps
 
 
 def concat_channels_gstat(a, b, out, gstat, *, F, HW, C1, C2, frames_per_stat):
-    """torch.cat(dim=channels) + the GroupNorm statistics of the result added to gstat (f64 [F / frames_per_stat][32][2])"""
+    """torch.cat(dim=channels) + the GroupNorm statistics of the result added to gstat (i64 [F / frames_per_stat][32][2])"""
     _l.check(_l.load().moca_concat_channels_gstat_f16(_l.ptr(a), _l.ptr(b), _l.ptr(out), F, HW, C1, C2, frames_per_stat,
                                                       _l.ptr(gstat), _st()), "moca_concat_channels_gstat_f16")
     return out

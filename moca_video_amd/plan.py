@@ -79,7 +79,6 @@ class _PlanBase:
         self.n_runs = 0
         self._gstat_buf, self._gstat_used, self._last_gemm_step = None, 0, None
         self._gstat_full = []
-        self._sk_sync = None
 
     def close(self):
         """release the instantiated hipGraph (moca_graph_destroy); the plan falls back to eager launches if used again"""
@@ -126,21 +125,8 @@ class _PlanBase:
             rows = ops.gemm_colsum_rows(a, pw, M=M, splits=splits, **kw)
             if rows > 0:
                 cs = (self.pool.get((M + rows - 1) // rows, 2 * pw.N, torch.float32), rows)
-        tp = None
-        if splits == 1:
-            # launches of the 256-row kernel that leave > 1/8 of the chip idle for a whole long tile (200 tiles on 256 CUs at the
-            # 1280-channel level): two blocks per tile with uneven k ranges, partial sums through a workspace, no reduce launch
-            big, ws_bytes, sync_words = ops.gemm_two_piece(a, pw, M=M, **kw)
-            if big > 0:
-                ws = self.pool.get(ws_bytes // 4, 1, torch.float32)
-                if self._sk_sync is None or self._sk_sync.numel() < sync_words:
-                    self._sk_sync = torch.zeros(max(1024, sync_words), dtype=torch.int32, device=self.device)
-                tp = (big, ws, self._sk_sync)
         self._last_gemm_step = len(self.steps)
-        if tp is not None:
-            self._emit(ops.gemm, a, pw, out, M=M, splits=1, two_piece=tp, colsum=None if cs is None else cs[0], **kw)
-        else:
-            self._emit(ops.gemm, a, pw, out, M=M, splits=splits, splitk_ws=ws, colsum=None if cs is None else cs[0], **kw)
+        self._emit(ops.gemm, a, pw, out, M=M, splits=splits, splitk_ws=ws, colsum=None if cs is None else cs[0], **kw)
         if ws is not None:
             self.pool.put(ws)
         return (out, cs) if want_colsum else out
@@ -178,7 +164,7 @@ class _PlanBase:
                        eps=eps, silu=silu)
         elif cs is not None and (fps * HW) % cs[1] == 0 and fm.src is not None and os.environ.get("MOCA_GN_GSTAT", "1") != "0":
             # the producer is re-targeted: instead of per-tile column sums it accumulates the FINISHED statistics of this
-            # GroupNorm (f64 atomics per (statistics group, channel group), MOCA_EP_GSTAT) -- no finalize launch
+            # GroupNorm (fixed-point atomics per (statistics group, channel group), MOCA_EP_GSTAT) -- no finalize launch
             prod = self.steps[fm.src]
             slot = self._gstat_slot((fm.F // fps) * 64)
             kw = dict(prod.keywords)
@@ -200,12 +186,12 @@ class _PlanBase:
         return y
 
     def _gstat_slot(self, n_doubles):
-        """f64 accumulators of one GEMM -> GroupNorm pair, carved from ONE buffer that a single memset zeroes at the start of
+        """64-bit fixed-point accumulators of one GEMM -> GroupNorm pair, carved from ONE buffer that a single memset zeroes at the start of
         every run (_run_steps)"""
         if self._gstat_buf is None or self._gstat_used + n_doubles > self._gstat_buf.numel():
             if self._gstat_buf is not None:                # the chunk is full: keep it (its slots are in use), open another one
                 self._gstat_full.append(self._gstat_buf[:self._gstat_used])
-            self._gstat_buf = torch.zeros(max(1 << 20, n_doubles), dtype=torch.float64, device=self.device)      # 8 MiB chunks
+            self._gstat_buf = torch.zeros(max(1 << 20, n_doubles), dtype=torch.int64, device=self.device)      # 8 MiB chunks
             self._gstat_used = 0
         s = self._gstat_buf[self._gstat_used:self._gstat_used + n_doubles]
         self._gstat_used += n_doubles
@@ -579,6 +565,7 @@ class _Plan(_PlanBase):
                 if m.addition_attention:
                     nh = self.transformer(m.init_attn[0], h, False)
                     self._release(h.buf)
+                    self._drop_colsum(h)
                     h = nh
             else:
                 h = self.run_seq(module, h)
@@ -600,6 +587,8 @@ class _Plan(_PlanBase):
             else:
                 self._emit(ops.concat_channels, h.buf, skip.buf, cat, rows=h.M, C1=h.C, C2=skip.C)   # torch.cat(dim=1), :571
             self._pinned.discard(skip.buf.data_ptr())
+            self._drop_colsum(h)          # (a concat consumed h: its producer goes back to the plain store loop)
+            self._drop_colsum(skip)
             self._release(h.buf, skip.buf)
             h = self.run_seq(module, _FMap(cat, h.F, h.H, h.W, Cc, gstat=gst))
         g = self.gn(h, P[id(m.out[0])], fps=1, eps=1e-5, silu=True)

@@ -77,7 +77,7 @@ def test_hip_text_tower_vs_oracle(layer):
     ref = CO.encode_with_transformer(sd, tok, CFG["heads"], layer_idx=m.layer_idx)
     out = m.encode_with_transformer(tok.cuda())
     assert out.shape == ref.shape == (3, 77, 128)
-    assert relerr(out.cpu(), ref) < 2e-2
+    assert relerr(out.cpu(), ref) < 2e-3          # 1.5 x the observed 1.07e-3 (24 blocks, fp16 storage)
     with pytest.raises(NotImplementedError):
         m(["a prompt"])
     with pytest.raises(ValueError):

@@ -1,8 +1,9 @@
 """End-to-end parity of the whole pipelines on the reduced-width UNet: the HIP path driven through the drop-in classes
 (DenoiseModel / DDIMSampler / fifo_ddim_sampling) against the SAME pipelines composed from the oracle's pieces (UNet +
 p_sample_ddim + ddim_step + prepare/shift_latents), with every random draw fixed.  The denoising loop feeds its own output
-back in, so the fp16-storage error of the UNet accumulates: tolerance 3e-2 * max|ref| after 10 CFG steps / 2 FIFO iterations
-(observed ~1e-2), still far below what a wrong coefficient, index or mask would produce (O(1))."""
+back in, so the fp16-storage error of the UNet accumulates (and enters 12-fold through the guidance e_u + 12 (e_c - e_u)): observed
+8.2e-3 * max|ref| after 10 CFG steps, 4.3e-3 after 2 FIFO iterations (gpurun_out/r3_errlog.txt) -> bound 1.2e-2 (1.5 x), far below
+what a wrong coefficient, index or mask would produce (O(1))."""
 import types
 
 import numpy as np
@@ -13,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 from helpers import REDUCED, inp, relerr, state_dict_for  # noqa: E402
 
-TOL = 3e-2
+TOL = 1.2e-2
 
 
 @pytest.fixture(scope="module")

@@ -128,14 +128,26 @@ def test_gemm_tconv(B, T, HW, C, N):
     check(got, ref[..., 0] + res.float().view(B, T, HW, pw.N).permute(0, 3, 1, 2), TOL16, "tconv3")
 
 
+@pytest.fixture
+def tune():
+    """kernel-choice knobs (include/moca_hip.h MOCA_TUNE_*: which kernel runs a shape, never what it computes), restored afterwards"""
+    saved = []
+
+    def set_(knob, value):
+        saved.append((knob, L.set_tuning(knob, value)))
+    yield set_
+    for knob, old in reversed(saved):
+        L.set_tuning(knob, old)
+
+
 # ---------------------------------------------------------------- norms
 @pytest.mark.parametrize("Fr,HW,C,fps,silu,eps", [(4, 100, 320, 1, True, 1e-5), (4, 100, 320, 2, True, 1e-5),
                                                    (16, 40, 1280, 16, False, 1e-6), (2, 2560, 320, 1, False, 1e-6),
                                                    (3, 37, 64, 1, True, 1e-5), (2, 64, 2560, 1, True, 1e-5),
                                                    (8, 64, 960, 8, True, 1e-5)])
-@pytest.mark.parametrize("path", ["0", "2"])     # MOCA_GN_SLAB: 0 = three-launch streaming path, 2 = single-launch slab path
-def test_groupnorm(Fr, HW, C, fps, silu, eps, path, monkeypatch):
-    monkeypatch.setenv("MOCA_GN_SLAB", path)
+@pytest.mark.parametrize("path", [0, 2])     # MOCA_TUNE_GN_SLAB: 0 = three-launch streaming path, 2 = single-launch slab path
+def test_groupnorm(Fr, HW, C, fps, silu, eps, path, tune):
+    tune(L.MOCA_TUNE_GN_SLAB, path)
     x = (rnd(Fr, HW, C) * 1.5 + 0.7).half()
     g = rnd(C, dtype=torch.float32) * 0.2 + 1.0
     b = rnd(C, dtype=torch.float32) * 0.2
@@ -202,16 +214,20 @@ def test_gemm_colsum_feeds_groupnorm(mode, Fr, HW, C, N, fps, with_res):
     xr = out.float().view(Fr // fps, fps * HW, N).permute(0, 2, 1)
     gref = F.silu(F.group_norm(xr, 32, g, be, 1e-5)).permute(0, 2, 1).reshape(Fr * HW, N)
     check(y, gref, TOL16, f"groupnorm from column sums ({mode})")
-    # MOCA_EP_GSTAT: the same launch accumulating the FINISHED statistics (f64 atomics per (statistics group, channel group));
+    # MOCA_EP_GSTAT: the same launch accumulating the FINISHED statistics (64-bit fixed-point atomics per (statistics group,
+    # channel group): order independent, so a second launch reproduces the accumulators bit for bit);
     # the GroupNorm is then a single apply launch
     n_sg = Fr // fps
-    gst = torch.zeros(n_sg * 64, dtype=torch.float64, device=DEV)
+    gst = torch.zeros(n_sg * 64, dtype=torch.int64, device=DEV)
     out2 = torch.empty_like(out)
     ops.gemm(a, pw, out2, M=M, residual=res, gstat=(gst, fps * HW), **kw)
     assert torch.equal(out2, out)
     xg = out.float().view(n_sg, fps * HW, 32, N // 32)
-    gs = gst.view(n_sg, 32, 2).float()
+    gs = gst.view(n_sg, 32, 2).double() * torch.tensor([2.0 ** -30, 2.0 ** -16], dtype=torch.float64, device=DEV)   # fixed point
     assert relerr(gs[..., 0], xg.sum(dim=(1, 3))) < 1e-3 and relerr(gs[..., 1], (xg * xg).sum(dim=(1, 3))) < 1e-3
+    gst2 = torch.zeros_like(gst)
+    ops.gemm(a, pw, out2, M=M, residual=res, gstat=(gst2, fps * HW), **kw)
+    assert torch.equal(gst2, gst)
     y3 = torch.full_like(y, float("nan"))
     ops.groupnorm_gstat(out, y3, g, be, gst, F=Fr, HW=HW, Cn=N, frames_per_stat=fps, eps=1e-5, silu=True)
     check(y3, gref, TOL16, f"groupnorm from accumulated statistics ({mode})")
@@ -360,14 +376,14 @@ def _sweep_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("kernel,env", [("w80", {"MOCA_GEMM_W80": "2"}), ("glds", {"MOCA_GEMM_W80": "0", "MOCA_GEMM_G4": "0"}),
-                                        ("g4", {"MOCA_GEMM_W80": "0", "MOCA_GEMM_G4": "2"})])
-def test_gemm_random_sweep_forced_kernels(kernel, env, monkeypatch):
-    """30 seeded random shapes per kernel family (forced through the env switches): linear / conv3x3 / temporal conv,
+@pytest.mark.parametrize("kernel,env", [("w80", {L.MOCA_TUNE_GEMM_W80: 2}), ("glds", {L.MOCA_TUNE_GEMM_W80: 0, L.MOCA_TUNE_GEMM_G4: 0}),
+                                        ("g4", {L.MOCA_TUNE_GEMM_W80: 0, L.MOCA_TUNE_GEMM_G4: 2})])
+def test_gemm_random_sweep_forced_kernels(kernel, env, tune):
+    """30 seeded random shapes per kernel family (forced through the MOCA_TUNE_* knobs): linear / conv3x3 / temporal conv,
     M tails, K % 64 != 0 (slow gather path), split-k, residual.  The kernels hand data over through counted vmcnt waits;
     this sweep is there to trip a mis-counted wait, which a handful of fixed shapes can miss."""
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        tune(k, v)
     for ci, (mode, M, N, K, splits, with_res, geo) in enumerate(_sweep_cases(30, {"w80": 1, "glds": 2, "g4": 3}[kernel])):
         res = rnd(M, N) if with_res else None
         b = rnd(N, dtype=torch.float32)
@@ -436,10 +452,10 @@ def test_gemm_gelu_epilogue_and_token_embedding():
 # ---------------------------------------------------------------- GEMM: the 256 x 256 tiling of the wide projections
 @pytest.mark.parametrize("M,K,N,geglu,with_res", [(5000, 640, 2560, True, False), (4500, 1280, 3072, False, True),
                                                   (5120, 384, 5120, True, False), (4100, 1280, 3072, False, False)])
-def test_gemm_sq256(M, K, N, geglu, with_res, monkeypatch):
-    """MOCA_GEMM_SQ256=2 sends every wide linear (N >= 2560, >= 200 tiles) to the 256 x 256 staggered kernel: M tails, an odd
+def test_gemm_sq256(M, K, N, geglu, with_res, tune):
+    """MOCA_TUNE_GEMM_SQ256 = 2 sends every wide linear (N >= 2560, >= 200 tiles) to the 256 x 256 staggered kernel: M tails, an odd
     number of 64-deep k-tiles, the GEGLU and the residual store loops."""
-    monkeypatch.setenv("MOCA_GEMM_SQ256", "2")
+    tune(L.MOCA_TUNE_GEMM_SQ256, 2)
     a = rnd(M, K)
     w = rnd(N, K, scale=K ** -0.5)
     b = rnd(N, dtype=torch.float32, scale=0.1)
@@ -464,14 +480,14 @@ def test_gemm_sq256(M, K, N, geglu, with_res, monkeypatch):
     (20480, 640, 640, True, [("lin", 1920), ("geglu", 2560)]),           # 2 partials
     (5120, 1280, 1280, False, [("lin", 3840), ("lin", 1280), ("geglu", 5120)]),   # 256-row producer (10 partials); staggered, 256-row, sq256
     (33000, 320, 320, True, [("lin", 960)]),                             # M tail
-    (33000, -320, 320, True, [("lin", 960)]),                            # (C < 0: MOCA_GEMM_WIDE=0) 320 x 160 producer, 2 partials
+    (33000, -320, 320, True, [("lin", 960)]),                            # (C < 0: MOCA_TUNE_GEMM_WIDE = 0) 320 x 160 producer, 2 partials
     (4000, 512, 320, False, [("lin", 1536), ("geglu", 2048)])])          # init_attn widths: 256-row producer (4 partials)
-def test_gemm_rowsum_feeds_lnfold(M, C, Kp, with_res, consumers, monkeypatch):
+def test_gemm_rowsum_feeds_lnfold(M, C, Kp, with_res, consumers, tune):
     """MOCA_EP_ROWSUM + MOCA_EP_LNFOLD: the producer linear leaves per-(column tile, row) sums of what it stores; the consumer
     runs on x with W' = W diag(gamma), b' = b + W beta and finishes Linear(LayerNorm(x)) in its epilogue (ref: torch)."""
     if C < 0:
         C = -C
-        monkeypatch.setenv("MOCA_GEMM_WIDE", "0")
+        tune(L.MOCA_TUNE_GEMM_WIDE, 0)
     a, w, b = rnd(M, Kp), rnd(C, Kp, scale=Kp ** -0.5), rnd(C, dtype=torch.float32)
     res = rnd(M, C) * 2 + 0.5 if with_res else None          # (a non-zero row mean: the fold subtracts mean * wsum)
     pw = ops.pack_linear(w, b)
@@ -511,18 +527,48 @@ def test_gemm_rowsum_feeds_lnfold(M, C, Kp, with_res, consumers, monkeypatch):
         check(out, ref, TOL16, f"lnfold consumer {kind} N={n} (C={C}, {nparts} partials)")
 
 
+@pytest.mark.parametrize("offset,C", [(40.0, 320), (100.0, 640), (-60.0, 1280)])
+def test_gemm_lnfold_offset_rows(offset, C):
+    """The LayerNorm fold derives the variance single-pass from fp32 row partials (q / K - mean^2) and the output as
+    rstd * (acc - mean * wsum): rows whose mean is far from zero (|mean| / std = 40 .. 100, as on outlier channels of the residual
+    stream) lose digits to cancellation in both terms.  Bound: log2(100) ~ 7 of fp32's 24 mantissa bits -- the result must still
+    agree with the two-pass torch LayerNorm of the same fp16 rows to the fp16 kernel tolerance."""
+    M = 20480
+    a, w, b = rnd(M, C), rnd(C, C, scale=C ** -0.5), rnd(C, dtype=torch.float32)
+    res = (rnd(M, C).float() + offset).half()
+    pw = ops.pack_linear(w, b)
+    cols = ops.gemm_rowsum_cols(a, pw, M=M, residual=res, rowsum=True)
+    assert cols > 0
+    nparts = C // cols
+    x = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    part = torch.empty(nparts * M, 2, dtype=torch.float32, device=DEV)
+    ops.gemm(a, pw, x, M=M, residual=res, rowsum=part)
+    xf = x.float()
+    assert abs(float(xf.mean()) - offset) < 1.0 and 0.5 < float(xf.std(dim=1).mean()) < 3.0
+    g = rnd(C, dtype=torch.float32) * 0.3 + 1.0
+    be = rnd(C, dtype=torch.float32) * 0.3
+    ln = F.layer_norm(xf, (C,), g, be, 1e-5)
+    wc, bc = rnd(3 * C, C, scale=C ** -0.5), rnd(3 * C, dtype=torch.float32)
+    wf, bf = ops.fold_layernorm(wc, bc, g, be)
+    pwf = ops.finish_lnfold(ops.pack_linear(wf, bf))
+    assert ops.gemm_lnfold_ok(x, pwf, M=M, lnfold=(None, nparts, 1e-5))
+    out = torch.empty(M, 3 * C, dtype=torch.float16, device=DEV)
+    ops.gemm(x, pwf, out, M=M, lnfold=(part, nparts, 1e-5))
+    check(out, ln @ wc.float().t() + bc, TOL16, f"lnfold with row mean {offset}")
+
+
 @pytest.mark.parametrize("Fr,HW,C1,C2", [(4, 100, 320, 320), (2, 2560, 640, 320), (3, 37, 1280, 1280), (2, 160, 1280, 640)])
 def test_concat_with_groupnorm_statistics(Fr, HW, C1, C2):
     """torch.cat(dim=channels) that also accumulates the statistics of the GroupNorm that follows (openaimodel3d.py:571,149)"""
     a, b = rnd(Fr * HW, C1) * 1.3 + 0.2, rnd(Fr * HW, C2) * 0.7 - 0.4
     C = C1 + C2
     out = torch.empty(Fr * HW, C, dtype=torch.float16, device=DEV)
-    gst = torch.zeros(Fr * 64, dtype=torch.float64, device=DEV)
+    gst = torch.zeros(Fr * 64, dtype=torch.int64, device=DEV)
     ops.concat_channels_gstat(a, b, out, gst, F=Fr, HW=HW, C1=C1, C2=C2, frames_per_stat=1)
     ref = torch.cat([a, b], dim=1)
     assert torch.equal(out, ref)
     xg = ref.float().view(Fr, HW, 32, C // 32)
-    gs = gst.view(Fr, 32, 2).float()
+    gs = gst.view(Fr, 32, 2).double() * torch.tensor([2.0 ** -30, 2.0 ** -16], dtype=torch.float64, device=DEV)   # fixed point
     assert relerr(gs[..., 0], xg.sum(dim=(1, 3))) < 1e-3 and relerr(gs[..., 1], (xg * xg).sum(dim=(1, 3))) < 1e-3
     g, be = rnd(C, dtype=torch.float32) * 0.2 + 1.0, rnd(C, dtype=torch.float32) * 0.2
     y = torch.empty_like(out)
@@ -561,50 +607,3 @@ def test_gemm_temporal_attention_fused(B, HW, heads, K, fold):
     att = torch.softmax(torch.einsum("bphid,bphjd->bphij", q, k) * scale, dim=-1)
     ref = torch.einsum("bphij,bphjd->bphid", att, v).permute(0, 3, 1, 2, 4).reshape(M, C)
     check(out, ref, TOL16, f"fused qkv + temporal attention (heads={heads}, K={K}, fold={fold})")
-
-
-# ---------------------------------------------------------------- two blocks per output tile, no reduce launch
-@pytest.mark.parametrize("mode,M,K,N,with_res", [("lin", 5120, 5120, 1280, True), ("conv", 5120, 11520, 1280, False),
-                                                 ("tconv", 5120, 3840, 1280, True), ("lin", 4900, 3072, 1280, False)])
-def test_gemm_two_piece(mode, M, K, N, with_res, monkeypatch):
-    """sk_big > 0: every 256-row tile is computed by two blocks (uneven k ranges); the first to finish leaves fp32 partial sums,
-    the second adds them and runs the epilogue.  Checked against torch, twice on the same sync words (they re-arm themselves),
-    with bit-identical results (a + b == b + a whichever block came second)."""
-    b = rnd(N, dtype=torch.float32)
-    res = rnd(M, N) if with_res else None
-    if mode == "lin":
-        a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
-        pw, kw = ops.pack_linear(w, b), {}
-        ref = a.float() @ w.float().t() + b
-    elif mode == "conv":
-        C, Fr, H, W = K // 9, M // 160, 10, 16
-        x = rnd(Fr, C, H, W)
-        w = rnd(N, C, 3, 3, scale=(9 * C) ** -0.5)
-        pw = ops.pack_conv3x3(w, b)
-        a = nhwc(x).reshape(M, C)
-        kw = dict(mode=L.MOCA_A_CONV3X3, conv=(C, H, W, H, W, 1, 0))
-        ref = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(M, N)
-    else:
-        C, T, HW = K // 3, 16, 160
-        x = rnd(M // (T * HW), C, T, HW, 1)
-        w = rnd(N, C, 3, 1, 1, scale=(3 * C) ** -0.5)
-        pw = ops.pack_tconv3(w, b)
-        a = x.permute(0, 2, 3, 4, 1).reshape(M, C).contiguous()
-        kw = dict(mode=L.MOCA_A_TCONV3, tconv=(C, T, HW))
-        ref = F.conv3d(x.float(), w.float(), b, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(M, N)
-    if res is not None:
-        ref = ref + res.float()
-    monkeypatch.setenv("MOCA_GEMM_TWO_PIECE", "40")       # (the default only takes >= 160 k-tiles: K >= 10240)
-    big, ws_bytes, sync_words = ops.gemm_two_piece(a, pw, M=M, residual=res, **kw)
-    assert big > 0, "this shape is expected to qualify (about 200 tiles of 256 x 128, >= 40 k-tiles)"
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=DEV)
-    sync = torch.zeros(sync_words, dtype=torch.int32, device=DEV)
-    outs = []
-    for _ in range(3):
-        out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
-        ops.gemm(a, pw, out, M=M, residual=res, two_piece=(big, ws, sync), **kw)
-        torch.cuda.synchronize()
-        assert int(sync.abs().sum()) == 0
-        outs.append(out)
-    check(outs[0], ref, TOL16, f"two-piece {mode} M={M} K={K}")
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])

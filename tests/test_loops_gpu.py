@@ -3,7 +3,8 @@ iteration) against goldens of the REAL reference loops (tests/golden/loop_*.npz,
 device-side FIFO kernels of csrc/fifo.hip against the per-window kernel / a numpy Philox.
 
 Tolerances: the loops feed the fp16-storage UNet's output back in under CFG 12 (the guided eps is e_u + 12 (e_c - e_u): the
-UNet's ~2e-3 relative error enters 12-fold) -- 10 base steps: 4e-2 of max|ref| observed ~1.5e-2; 3 FIFO iterations: 3e-2.
+UNet's ~2.7e-3 relative error enters 12-fold).  Observed (gpurun_out/r3_errlog.txt): 10 base steps 1.15e-2 of max|ref| -> bound
+1.7e-2; 3 FIFO iterations 2.2e-2 (DAVIS mode; 2.0e-2 prompt mode) -> bound 3e-2; bounds <= 1.5 x observed.
 A wrong window order, write-back slice, emission index, coefficient or mask index gives O(1)."""
 import types
 
@@ -15,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 from helpers import REDUCED, golden, inp, loop_sam_candidates, relerr, state_dict_for  # noqa: E402
 
-TOL_BASE = 4e-2
+TOL_BASE = 1.7e-2
 TOL_FIFO = 3e-2
 VAE_DD = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2, 4, 4],
               num_res_blocks=2, attn_resolutions=[], dropout=0.0)

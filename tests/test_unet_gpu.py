@@ -1,8 +1,14 @@
 """GPU parity of the HIP UNet (through the drop-in UNetModel / DiffusionWrapper boundary, i.e.
 through the C-ABI) against (a) golden outputs of the real reference and (b) the CPU oracle on
 the same seeded inputs.  fp16 storage / fp32 accumulate vs the fp32 reference:
-tolerances (stated fp16 tolerance): whole-UNet output max|err| <= 6e-3 * max|ref| AND rms(err) <= 5e-3 * rms(ref)
-(observed 2.2e-3 max-norm at the full 1.41 B-parameter width, 3.2e-3 / 2.8e-3 on the reduced UNet); single blocks likewise."""
+the stated fp16 tolerance and where it comes from: every stored activation is rounded to fp16 once (relative rms error
+2^-11 / sqrt(3) = 2.8e-4); the longest residual path of the UNet crosses ~150 such roundings (25 blocks x ~6 stores), GroupNorm /
+LayerNorm keep the relative scale, so the errors add as a random walk: sqrt(150) x 2.8e-4 = 3.4e-3 predicted relative rms at the
+output.  Observed (gpurun_out/r3_errlog.txt, MOCA_ERRLOG): rms 2.74e-3 / max-norm 3.04e-3 on the reduced-width UNet (short K, small
+tensors: the worst case), 2.27e-3 / 2.56e-3 at the full 1.41 B-parameter width, <= 8.1e-4 on single blocks.  Bounds = at most
+1.5 x the largest observed value: whole UNet rms <= 4e-3 x rms(ref) AND max|err| <= 4.5e-3 x max|ref|; single blocks 1.2e-3."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -11,9 +17,9 @@ pytestmark = pytest.mark.gpu
 
 from helpers import REDUCED, golden, inp, relerr, state_dict_for  # noqa: E402
 
-TOL_UNET = 6e-3        # max-norm, 2.7x the observed 2.2e-3
-TOL_BLOCK = 6e-3
-TOL_RMS = 5e-3         # relative RMS (observed 2.8e-3 on the reduced-width UNet, where K is short and every tensor is small): a
+TOL_UNET = 4.5e-3      # max-norm, whole UNet: 1.5 x the observed 3.04e-3
+TOL_BLOCK = 1.2e-3     # max-norm, one block: 1.5 x the observed 8.1e-4
+TOL_RMS = 4e-3         # relative RMS (1.46 x the observed 2.74e-3 on the reduced-width UNet; the random-walk estimate is 3.4e-3): a
                        # wrong epilogue in a low-magnitude region cannot hide under the max-norm bound
 
 
@@ -25,6 +31,9 @@ def rmserr(got, ref):
 def check(got, ref, tol_max, what):
     e, r = relerr(got, ref), rmserr(got, ref)
     print(f"[parity] {what}: max-norm rel err {e:.2e}, rel rms {r:.2e}")
+    if os.environ.get("MOCA_ERRLOG"):
+        with open(os.environ["MOCA_ERRLOG"], "a") as f:
+            f.write(f"{r:.3e} rms {os.environ.get('PYTEST_CURRENT_TEST', '?')} {what}\n")
     assert e < tol_max and r < TOL_RMS, f"{what}: max-norm rel err {e:.3e} (tol {tol_max:.0e}), rel rms {r:.3e} (tol {TOL_RMS:.1e})"
     return e, r
 
@@ -178,11 +187,11 @@ def test_fifo_batched_windows_equal_sequential():
                                     conditioned_image=cimg, masks=mask.clone(), n_iterations=2, batch_windows=batched,
                                     noises=noises, shift_noises=shift)
         outs.append((lat, frames))
-    # B = 8 and B = 1 launches take different tilings / split-k factors (different fp32 summation orders) and the differences
-    # are fed back through two CFG-12 iterations: observed 5e-3; the end-to-end tolerance of test_e2e_gpu.py is 3e-2
-    assert relerr(outs[1][0], outs[0][0]) < 1e-2
+    # B = 16 (the one-graph iteration) and B = 1 launches take different tilings / split-k factors (different fp32 summation orders)
+    # and the differences are fed back through two CFG-12 iterations: observed 5.3e-3 -> bound 8e-3 (1.5 x)
+    assert relerr(outs[1][0], outs[0][0]) < 8e-3
     for a, b in zip(outs[0][1], outs[1][1]):
-        assert relerr(b, a) < 1e-2
+        assert relerr(b, a) < 8e-3
     assert not torch.equal(outs[0][0], q0)
 
 
@@ -233,7 +242,7 @@ def test_unet_full_width_vs_reference_golden():
     single = [m(xs[i], ts[i:i + 1], context=cs[i], fps=fps[i:i + 1]) for i in range(2)]
     both = m(torch.cat(xs), ts, context=torch.cat(cs), fps=fps)
     for i in range(2):      # every op is per sample: a batch of two equals two single launches (other tile counts / split-k: tolerance)
-        assert relerr(both[i:i + 1].cpu(), single[i].cpu()) < 1e-2, f"batch consistency sample {i}"      # fp16 noise level: 2-3e-3
+        assert relerr(both[i:i + 1].cpu(), single[i].cpu()) < TOL_UNET, f"batch consistency sample {i}"      # fp16 noise level: 2-3e-3
     runs = [m(torch.cat(xs), ts, context=torch.cat(cs), fps=fps) for _ in range(3)]      # eager / capture / replay
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[1], runs[2]) and torch.equal(runs[0], both), "replays must be bit-identical"
     # FIFO semantics: a per-frame timestep vector that happens to be constant equals the uniform-timestep call

@@ -1,7 +1,7 @@
 """VAE decoder.  CPU: the oracle (oracle/vae_oracle.py) against goldens captured from the REAL reference
 `AutoencoderKL` (tools/make_golden.py vae_cases); state-dict names/shapes of the drop-in class.  GPU: the HIP decode
 through the drop-in `AutoencoderKL.decode` / `DenoiseModel.decode_first_stage_2DAE` boundary against the same goldens
-and against the oracle on fresh inputs.  Tolerances: oracle fp32 vs reference fp32 2e-5; HIP fp16-storage 2e-2 * max|ref|."""
+and against the oracle on fresh inputs.  Tolerances: oracle fp32 vs reference fp32 2e-5; HIP fp16-storage 3e-3 * max|ref| (1.5 x the largest observed, 1.8e-3: gpurun_out/r3_errlog.txt)."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +12,7 @@ from oracle import vae_oracle as VO
 VAE_DD = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
               num_res_blocks=2, attn_resolutions=[], dropout=0.0)
 CASES = [("vae_reduced", 64), ("vae_full_small", 128)]
-TOL_HIP = 2e-2
+TOL_HIP = 3e-3
 
 
 def _model(ch):

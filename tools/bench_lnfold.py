@@ -39,10 +39,6 @@ def case(M, C, n, geglu, nparts):
     run(tag + " plain", lambda: ops.gemm(x, pw, out, M=M), 2.0 * M * nn * C)
     run(tag + f" lnfold({nparts})", lambda: ops.gemm(x, pwf, out, M=M, lnfold=(part, nparts, 1e-5)), 2.0 * M * nn * C)
     run(tag + " plain, folded W", lambda: ops.gemm(x, pwf, out, M=M), 2.0 * M * nn * C)
-    for d in (1, 2, 3):
-        os.environ["MOCA_LNFOLD_DBG"] = str(d)
-        run(tag + f" lnfold({nparts}) dbg={d} (1: no loads, 2: no epilogue fold)", lambda: ops.gemm(x, pwf, out, M=M, lnfold=(part, nparts, 1e-5)), 2.0 * M * nn * C)
-    os.environ["MOCA_LNFOLD_DBG"] = "0"
 
 
 if __name__ == "__main__":

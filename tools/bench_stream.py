@@ -5,6 +5,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from moca_video_amd import ops
+from moca_video_amd import lib as L
 
 DEV = "cuda"
 
@@ -29,8 +30,8 @@ for F, HW, C, fps in ((32, 2560, 320, 16), (32, 2560, 320, 1), (32, 640, 640, 16
     run(f"torch copy            F={F} HW={HW} C={C}", lambda: y.copy_(x), nb)
     g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
     ws = torch.empty(ops.groupnorm_ws_floats(F, HW, C), dtype=torch.float32, device=DEV)
-    for slab in ("0", "1"):
-        os.environ["MOCA_GN_SLAB"] = slab
+    for slab in (0, 1):
+        L.set_tuning(L.MOCA_TUNE_GN_SLAB, slab)
         run(f"groupnorm slab={slab}      F={F} HW={HW} C={C} fps={fps}", lambda: ops.groupnorm(x, y, g, b, F=F, HW=HW, Cn=C, frames_per_stat=fps, eps=1e-5, silu=True, ws=ws), nb)
     rows = 320 if C < 1280 else 256
     if (fps * HW) % rows == 0:
