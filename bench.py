@@ -408,6 +408,8 @@ def main():
     ap.add_argument("--no-fifo", action="store_true", help="skip the extra batched-FIFO-iteration measurement")
     ap.add_argument("--cfg-mode", default="batched", choices=["batched", "concurrent"],
                     help="cond+uncond as one B=2 launch, or as two concurrent B=1 hipGraphs on two streams")
+    ap.add_argument("--no-shared-prefix", action="store_true",
+                    help="A/B: evaluate the two CFG branches as a plain B=2 batch instead of sharing the layers before the first cross-attention")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--height", type=int, default=40)
@@ -443,6 +445,7 @@ def main():
     unet = dm.model.diffusion_model
     sampler = DDIMSampler(dm)
     sampler.cfg_mode = args.cfg_mode
+    sampler.share_prefix = not args.no_shared_prefix
     S = 50
     sampler.make_schedule(S, ddim_eta=1.0, verbose=False)
 
@@ -574,7 +577,7 @@ def main():
                    "unet_steps_per_step": 2 * n_prompts, "context_tokens": 77, "weights": "random-init, 1.41B params, fp16 packed" +
                    ("" if world == 1 else "; materialised on rank 0 only, RCCL broadcast (C1), checksums all-gathered"),
                    "parallelism": f"dp{world} (independent prompts, no collective in the loop)",
-                   "hipgraph_replay": graph_on, "cfg_mode": args.cfg_mode, "device": name, "compute_units": cus, "output_finite": finite},
+                   "hipgraph_replay": graph_on, "cfg_mode": args.cfg_mode, "cfg_shared_prefix": sampler.share_prefix and args.cfg_mode == "batched", "device": name, "compute_units": cus, "output_finite": finite},
         "achieved_tflops": round(value / world * FLOP_PER_UNET_STEP / 1e12, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic_bytes if not concurrent else None, "traffic_source": traffic_src if not concurrent else None,

@@ -224,6 +224,10 @@ int moca_nhwc_to_ncthw(const void* y, int32_t ld, void* x, int32_t x_is_f32, int
 /* out[r][0:C1] = a[r], out[r][C1:C1+C2] = b[r]  (torch.cat(dim=1), openaimodel3d.py:571) */
 int moca_concat_channels_f16(const void* a, const void* b, void* out, int64_t rows,
                              int32_t C1, int32_t C2, void* stream);
+/* dst = `reps` back-to-back copies of src[0:bytes] (bytes % 16 == 0).  The batch of a classifier-free-guidance forward repeats the
+ * same latents with different contexts (ddim.py:298-299,366-369: two apply_model calls on the same x): everything before the
+ * first cross-attention is computed once, this copy is where the branches start to differ. */
+int moca_repeat_f16(const void* src, void* dst, int64_t bytes, int32_t reps, void* stream);
 /* sinusoidal embedding [n][dim] fp16 = [cos(t f_k), sin(t f_k)] (utils_diffusion.py:8-28);
  * t is int64 on device */
 int moca_timestep_embedding_f16(const int64_t* t, void* out, int32_t n, int32_t dim,

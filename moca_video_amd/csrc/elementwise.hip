@@ -50,6 +50,15 @@ __global__ __launch_bounds__(256) void concat_kernel(const half_t* __restrict__ 
     }
 }
 
+// dst = [src; src; ...] (reps copies of n16 16-byte chunks): the point where a forward whose batch repeats the same latents with
+// different contexts (classifier-free guidance) stops sharing its activations
+__global__ __launch_bounds__(256) void repeat_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16, int reps) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+        const uint4 v = src[i];
+        for (int r = 0; r < reps; ++r) dst[(int64_t)r * n16 + i] = v;
+    }
+}
+
 // utils_diffusion.py:8-28: [cos(t f_k), sin(t f_k)], f_k = exp(-ln(P) k / half)
 __global__ __launch_bounds__(256) void timestep_embedding_kernel(const int64_t* __restrict__ t, half_t* __restrict__ out,
                                                                  int n, int dim, float neg_log_period) {
@@ -189,6 +198,14 @@ extern "C" int moca_concat_channels_f16(const void* a, const void* b, void* out,
     const int g = grid_for(rows * ((C1 + C2) / 8));
     hipLaunchKernelGGL(concat_kernel, dim3(g), dim3(256), 0, moca_stream(stream), reinterpret_cast<const half_t*>(a),
                        reinterpret_cast<const half_t*>(b), reinterpret_cast<half_t*>(out), rows, C1, C2);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_repeat_f16(const void* src, void* dst, int64_t bytes, int32_t reps, void* stream) {
+    if (!src || !dst || bytes <= 0 || bytes % 16 || reps < 1 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return MOCA_E_BADARG;
+    hipLaunchKernelGGL(repeat_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, moca_stream(stream),
+                       reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), bytes / 16, reps);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

@@ -97,12 +97,11 @@ class FifoEngine:
         ctxs = [cc.expand(nW, -1, -1)]
         if guided:
             ctxs.append(torch.cat(uc["c_crossattn"], 1).expand(nW, -1, -1))
-        if len(ctxs) == 2 and ctxs[0].shape == ctxs[1].shape:
-            segs = ((2 * nW, int(cc.shape[1])),)
-        else:
-            segs = tuple((nW, int(c.shape[1])) for c in ctxs)
+        segs = tuple((nW, int(c.shape[1])) for c in ctxs)
         B = self.reps * nW
-        self.plan = plan = _Plan(unet, B, f, H, W, segs, torch.float32, dev)
+        # guided: the unconditional windows are the SAME latents with another context: one plan whose prefix (everything before the
+        # first cross-attention) runs once for both branches
+        self.plan = plan = _Plan(unet, B, f, H, W, segs, torch.float32, dev, shared_x=guided)
 
         def fps_rows(fp):
             if isinstance(fp, int):
@@ -176,7 +175,7 @@ class FifoEngine:
         def pre():
             _l.check(lib.moca_fifo_randn_f32(st_, _l.ptr(self.noise), self.noise.numel(), S()), "moca_fifo_randn_f32")
             _l.check(lib.moca_fifo_gather_windows_f32(st_, q_, _l.ptr(plan.x_in), _l.ptr(self.anchor), _l.ptr(self.win_start),
-                                                      nW, self.reps, Cc, Q, f, HW, S()), "moca_fifo_gather_windows_f32")
+                                                      nW, 1, Cc, Q, f, HW, S()), "moca_fifo_gather_windows_f32")
 
         def post():
             _l.check(lib.moca_fifo_step_windows_f32(C.byref(p), S()), "moca_fifo_step_windows_f32")

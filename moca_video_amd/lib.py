@@ -95,6 +95,7 @@ SIGNATURES = {
     "moca_ncthw_to_nhwc_f16": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "moca_nhwc_to_ncthw": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "moca_concat_channels_f16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "moca_repeat_f16": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "moca_timestep_embedding_f16": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _vp]),
     "moca_silu_add_rows_f16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "moca_channel_mix_f16": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),

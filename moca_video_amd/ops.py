@@ -306,6 +306,14 @@ def concat_channels(a, b, out, *, rows, C1, C2):
     return out
 
 
+def repeat(src, dst, *, reps):
+    """dst = reps back-to-back copies of src"""
+    nb = src.numel() * src.element_size()
+    assert dst.numel() * dst.element_size() == nb * reps
+    _l.check(_l.load().moca_repeat_f16(_l.ptr(src), _l.ptr(dst), nb, reps, _st()), "moca_repeat_f16")
+    return dst
+
+
 def timestep_embedding(t, out, *, n, dim, max_period=10000.0):
     _l.check(_l.load().moca_timestep_embedding_f16(_l.ptr(t), _l.ptr(out), n, dim, max_period, _st()),
              "moca_timestep_embedding_f16")

@@ -79,6 +79,7 @@ class _PlanBase:
         self.n_runs = 0
         self._gstat_buf, self._gstat_used, self._last_gemm_step = None, 0, None
         self._gstat_full = []
+        self.reps = 1            # > 1: the batch is `reps` context variants of the same Bx latents (_Plan: shared prefix)
 
     def close(self):
         """release the instantiated hipGraph (moca_graph_destroy); the plan falls back to eager launches if used again"""
@@ -252,7 +253,11 @@ class _PlanBase:
 
 
 class _Plan(_PlanBase):
-    def __init__(self, model, B, T, H, W, L, in_dtype, device):
+    def __init__(self, model, B, T, H, W, L, in_dtype, device, shared_x=False):
+        """shared_x: the B videos are `len(L)` context variants of the SAME B / len(L) latents (the two `apply_model` calls of
+        classifier-free guidance, ddim.py:298-299,366-369, on one x): `x_in` holds the distinct latents only, everything up to the
+        first cross-attention (conv_in, init_attn, the first ResBlock, the first SpatialTransformer's self-attention and to_q:
+        8 % of the forward) is computed once and repeated where the contexts first enter (`_expand`)."""
         super().__init__(model, device)
         self.B, self.T, self.H, self.W, self.L = B, T, H, W, L
         self.BT = B * T
@@ -263,7 +268,11 @@ class _Plan(_PlanBase):
         assert sum(n for n, _ in self.segs) == B
         self.ctx_rows = sum(n * l for n, l in self.segs)
         m = model
-        self.x_in = torch.empty(B, m.in_channels, T, H, W, dtype=in_dtype, device=device)
+        if shared_x:
+            assert len(self.segs) > 1 and all(n == self.segs[0][0] for n, _ in self.segs)
+            self.reps = len(self.segs)
+        self.Bx = B // self.reps
+        self.x_in = torch.empty(self.Bx, m.in_channels, T, H, W, dtype=in_dtype, device=device)
         self.t_rows = torch.empty(self.BT, dtype=torch.int64, device=device)
         self.fps_rows = torch.empty(self.BT, dtype=torch.int64, device=device)
         self.ctx = torch.empty(self.ctx_rows, m.context_dim, dtype=torch.float16, device=device)
@@ -399,27 +408,35 @@ class _Plan(_PlanBase):
             self._emit(ops.attention, q, k, v, o, Bq=F, heads=heads, Nq=HW, Nk=HW, ldq=3 * Cn, ldk=3 * Cn, ldv=3 * Cn,
                        ldo=Cn, kv_div=1, scale=scale)
         else:
-            self._emit(ops.temporal_attention, q, k, v, o, B=self.B, T=self.T, HW=HW, heads=heads, ld_qkv=3 * Cn, ldo=Cn,
+            self._emit(ops.temporal_attention, q, k, v, o, B=M // (self.T * HW), T=self.T, HW=HW, heads=heads, ld_qkv=3 * Cn, ldo=Cn,
                        scale=scale)
         self._release(qkv)
         return o
 
-    def _attn_cross(self, att, l, M, Cn, heads, F, HW, norm=None):
+    def _attn_cross(self, att, l, M, Cn, heads, F, HW, norm=None, expand=False):
+        """expand: `l` (and so q) still has the rows of the Bx distinct latents; every context segment attends with the SAME q rows
+        and writes its own rows of o, which comes out with reps x M rows"""
         q = self.linear_of_ln(l, M, self.P[id(att)], lambda: self._fold_pw("q", att, norm))
         off, inner = self.model._kv_cols[id(att)]                # one K/V per video (context.repeat_interleave, :547),
         ld = self.kv_all.shape[1]                                # all layers' K|V projected by one GEMM up front
-        o = self.pool.get(M, Cn)
+        o = self.pool.get(M * (self.reps if expand else 1), Cn)
         r0 = k0 = 0
         for nv, Ls in self.segs:                                 # (one launch per context segment: rows of q / o, rows of K|V)
             rows = nv * self.T * HW
             kv = self.kv_all[k0:k0 + nv * Ls]
-            self._emit(ops.attention, q[r0:r0 + rows], kv[:, off:off + inner], kv[:, off + inner:off + 2 * inner], o[r0:r0 + rows],
-                       Bq=nv * self.T, heads=heads, Nq=HW, Nk=Ls, ldq=Cn, ldk=ld, ldv=ld, ldo=Cn, kv_div=self.T,
-                       scale=att.dim_head ** -0.5)
+            self._emit(ops.attention, q[0:rows] if expand else q[r0:r0 + rows], kv[:, off:off + inner],
+                       kv[:, off + inner:off + 2 * inner], o[r0:r0 + rows], Bq=nv * self.T, heads=heads, Nq=HW, Nk=Ls, ldq=Cn, ldk=ld,
+                       ldv=ld, ldo=Cn, kv_div=self.T, scale=att.dim_head ** -0.5)
             r0 += rows
             k0 += nv * Ls
         self._release(q)
         return o
+
+    def _expand(self, buf, rows, cols):
+        """[rows][cols] -> reps copies (the branches of a shared-latents batch separate here)"""
+        out = self.pool.get(rows * self.reps, cols)
+        self._emit(ops.repeat, buf.reshape(-1)[:rows * cols], out, reps=self.reps)
+        return out
 
     def linear_ln(self, a, M, pw, gb, residual=None, consumer=None):
         """`out = linear(a) (+ residual)` and `l = LayerNorm(out)` (eps 1e-5, attention.py:199-201).
@@ -462,7 +479,8 @@ class _Plan(_PlanBase):
 
     def tblock(self, blk, h, l, M, Cn, heads, spatial, F, HW, next_gb=None, next_consumer=None):
         """BasicTransformerBlock._forward, attention.py:216-220.  `l` = norm1(h), already computed by the producer of h;
-        returns (h_out, norm1 of the NEXT block applied to it, or None)."""
+        returns (h_out, norm1 of the NEXT block applied to it or None, rows, frames) -- rows / frames grow by `reps` when this
+        block holds the first cross-attention of a shared-latents plan."""
         P = self.P
         geglu = blk.ff.net[0].proj
         consumers = (self._ln_consumer(blk.attn2, blk.norm2), lambda: self._fold_pw("geglu", geglu, blk.norm3))
@@ -470,7 +488,12 @@ class _Plan(_PlanBase):
             if att.is_self:
                 o = self._attn_self(att, l, M, Cn, heads, spatial, F, HW, norm=cur)
             else:
-                o = self._attn_cross(att, l, M, Cn, heads, F, HW, norm=cur)
+                expand = self.reps > 1 and F == self.Bx * self.T      # first use of the contexts: the shared prefix ends here
+                o = self._attn_cross(att, l, M, Cn, heads, F, HW, norm=cur, expand=expand)
+                if expand:
+                    h2 = self._expand(h, M, Cn)
+                    self._release(h)
+                    h, M, F = h2, M * self.reps, F * self.reps
             self._release_ln(l)
             nh, l = self.linear_ln(o, M, P[id(att.to_out[0])], P[id(nxt)], residual=h, consumer=cons)
             self._release(o, h)
@@ -482,7 +505,7 @@ class _Plan(_PlanBase):
         else:
             nh, l = self.linear(ff, M, P[id(blk.ff.net[2])], residual=h), None
         self._release(ff, h)
-        return nh, l
+        return nh, l, M, F
 
     def _ln_consumer(self, att, norm):
         """the folded weights of the projection that reads `norm` in front of attention `att`"""
@@ -496,14 +519,19 @@ class _Plan(_PlanBase):
         h, l = self.linear_ln(n, x.M, P[id(mod.proj_in)], P[id(blocks[0].norm1)],
                               consumer=self._ln_consumer(blocks[0].attn1, blocks[0].norm1))
         self._release(n)
+        M, Fr, xres = x.M, x.F, x.buf
         for i, blk in enumerate(blocks):
             last = i + 1 >= len(blocks)
             nxt = None if last else P[id(blocks[i + 1].norm1)]
             ncons = None if last else self._ln_consumer(blocks[i + 1].attn1, blocks[i + 1].norm1)
-            h, l = self.tblock(blk, h, l, x.M, mod.inner, mod.heads, spatial, x.F, x.H * x.W, next_gb=nxt, next_consumer=ncons)
-        out, cs = self.linear(h, x.M, P[id(mod.proj_out)], residual=x.buf, want_colsum=True)
+            h, l, M, Fr = self.tblock(blk, h, l, M, mod.inner, mod.heads, spatial, Fr, x.H * x.W, next_gb=nxt, next_consumer=ncons)
+        if Fr != x.F:                                            # the shared prefix ended inside: the outer residual too
+            xres = self._expand(x.buf, x.M, x.C)
+        out, cs = self.linear(h, M, P[id(mod.proj_out)], residual=xres, want_colsum=True)
         self._release(h)
-        return _FMap(out, x.F, x.H, x.W, x.C, cs, src=self._last_gemm_step if cs is not None else None)
+        if xres is not x.buf:
+            self._release(xres)
+        return _FMap(out, Fr, x.H, x.W, x.C, cs, src=self._last_gemm_step if cs is not None else None)
 
     def run_seq(self, seq, h):
         """TimestepEmbedSequential.forward, openaimodel3d.py:36-48"""
@@ -555,9 +583,10 @@ class _Plan(_PlanBase):
             self.kv_all = self.linear(self.ctx, self.ctx_rows, P["ctx_kv_all"])  # [sum B_i L_i][sum 2C]: every cross-attention K|V
             self._pinned.add(self.kv_all.data_ptr())
 
-        x8 = self.pool.get(BT * H * W, 8)
-        self._emit(ops.ncthw_to_nhwc, self.x_in, x8, B=B, Cin=m.in_channels, T=T, HW=H * W, Cpad=8)
-        h = self.conv(_FMap(x8, BT, H, W, 8), P[id(m.input_blocks[0][0])])
+        FT = self.Bx * T                                         # frames of the distinct latents (= BT unless shared_x)
+        x8 = self.pool.get(FT * H * W, 8)
+        self._emit(ops.ncthw_to_nhwc, self.x_in, x8, B=self.Bx, Cin=m.in_channels, T=T, HW=H * W, Cpad=8)
+        h = self.conv(_FMap(x8, FT, H, W, 8), P[id(m.input_blocks[0][0])])
         self._release(x8)
         hs = []
         for i, module in enumerate(m.input_blocks):
@@ -572,8 +601,16 @@ class _Plan(_PlanBase):
             hs.append(h)
             self._pinned.add(h.buf.data_ptr())
         h = self.run_seq(m.middle_block, h)
+        if h.F != BT:                                            # (no cross-attention anywhere: nothing ever separated the branches)
+            h = _FMap(self._expand(h.buf, h.M, h.C), BT, h.H, h.W, h.C)
         for module in m.output_blocks:
             skip = hs.pop()
+            if skip.F != h.F:                                    # a skip connection from the shared prefix
+                self._pinned.discard(skip.buf.data_ptr())
+                wide = self._expand(skip.buf, skip.M, skip.C)
+                self._drop_colsum(skip)
+                self._release(skip.buf)
+                skip = _FMap(wide, h.F, skip.H, skip.W, skip.C)
             cat = self.pool.get(h.M, h.C + skip.C)
             gst = None
             Cc = h.C + skip.C

@@ -67,6 +67,8 @@ class DDIMSampler(object):
         self.cfg_mode = "batched"            # "batched": cond+uncond as one B=2 launch; "concurrent": two B=1
                                              # hipGraphs on two streams (UNetModel.forward_concurrent)
         self.beta = 0.9                      # momentum decay (ddim.py:397)
+        self.share_prefix = True             # the two CFG branches share everything before the first cross-attention (same x, same
+                                             # t): computed once (UNetModel.forward_segments(shared_x=True)); False: plain B = 2 batch
 
     # ---- schedule (host) ---------------------------------------------------------------
     def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
@@ -98,6 +100,12 @@ class DDIMSampler(object):
             f_c, f_u = c.get("fps", 16), uc.get("fps", 16)
             e_c, e_u = unet.forward_concurrent([dict(x=x, timesteps=t, context=cc, fps=f_c),
                                                 dict(x=x, timesteps=t, context=cu, fps=f_u)])
+        elif batched and self.share_prefix and hasattr(unet, "forward_segments") and \
+                getattr(self.model.model, "conditioning_key", None) == "crossattn":
+            # both branches in ONE forward that shares everything before the first cross-attention (same x, same t)
+            B = x.shape[0]
+            e = unet.forward_segments(x, t, [cc, cu], fps=[c.get("fps", 16), uc.get("fps", 16)], shared_x=True)
+            e_c, e_u = e[:B], e[B:]
         elif batched:
             B = x.shape[0]
             cond = {"c_crossattn": [torch.cat([cc, cu], 0)]}
@@ -210,7 +218,11 @@ class DDIMSampler(object):
             return list(e.split(1, 0))
         cu = torch.cat(uc["c_crossattn"], 1).expand(W, -1, -1)
         fps_u = uc.get("fps", fps_c)
-        if cc.shape == cu.shape and isinstance(fps_c, int) == isinstance(fps_u, int):
+        unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+        if self.share_prefix and hasattr(unet, "forward_segments") and getattr(self.model.model, "conditioning_key", None) == "crossattn":
+            e = unet.forward_segments(x, t, [cc, cu], fps=[fps_rows(fps_c, W), fps_rows(fps_u, W)], shared_x=True)
+            e_c, e_u = e[:W], e[W:]
+        elif cc.shape == cu.shape and isinstance(fps_c, int) == isinstance(fps_u, int):
             fps2 = fps_c if isinstance(fps_c, int) else torch.cat([fps_rows(fps_c, W), fps_rows(fps_u, W)], 0)
             e = self.model.apply_model(torch.cat([x, x], 0), torch.cat([t, t], 0),
                                        {"c_crossattn": [torch.cat([cc, cu], 0)], "fps": fps2}, **kwargs)

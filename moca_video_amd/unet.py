@@ -432,13 +432,16 @@ class UNetModel(nn.Module):
             raise ValueError("context batch must equal x batch")
         return t_rows, fps_rows
 
-    def _plan_for(self, x, L, replica=0):
-        """L: context tokens, or a tuple of (videos, tokens) segments (see _Plan.segs)"""
+    def _plan_for(self, x, L, replica=0, shared_x=False):
+        """L: context tokens, or a tuple of (videos, tokens) segments (see _Plan.segs); shared_x: x holds the distinct latents of
+        a batch that repeats them once per segment"""
         B, _, T, H, W = x.shape
-        key = (B, T, H, W, L, x.dtype, x.device.index, replica)
+        if shared_x:
+            B *= len(L)
+        key = (B, T, H, W, L, x.dtype, x.device.index, replica, shared_x)
         plan = self._plans.get(key)
         if plan is None:
-            plan = _Plan(self, B, T, H, W, L, x.dtype, x.device)
+            plan = _Plan(self, B, T, H, W, L, x.dtype, x.device, shared_x=shared_x)
             self._plans[key] = plan
         return plan
 
@@ -451,13 +454,28 @@ class UNetModel(nn.Module):
         return self._plan_for(x, context.shape[1]).run(x, t_rows, fps_rows, context)
 
     @torch.no_grad()
-    def forward_segments(self, x, timesteps, contexts, fps=16):
+    def forward_segments(self, x, timesteps, contexts, fps=16, shared_x=False):
         """One forward over a batch whose videos carry contexts of DIFFERENT lengths: `contexts` = list of [n_i, L_i, D]
         tensors in batch order (sum n_i = B), e.g. the 2n conditional FIFO windows with two prompts (154 tokens) followed
         by their unconditional copies (77 tokens).  Same values as one forward() per segment: every UNet op is per-sample
-        and each cross-attention runs per segment on its own keys (no padding, no masking)."""
+        and each cross-attention runs per segment on its own keys (no padding, no masking).
+
+        shared_x=True: the segments are context variants of the SAME latents -- the two `apply_model` calls of classifier-free
+        guidance (ddim.py:298-299,366-369).  x [n, ...], timesteps and fps describe the n distinct videos, every context is
+        [n, L_i, D]; returns [len(contexts) * n, ...] (segment-major).  Everything before the first cross-attention is computed
+        once (see _Plan); fps may be a list with one entry per segment."""
+        n = x.shape[0]
+        if shared_x:
+            if any(c.shape[0] != n for c in contexts):
+                raise ValueError("shared_x: every context must have one row block per latent video")
+            segs = tuple((n, int(c.shape[1])) for c in contexts)
+            fps_list = list(fps) if isinstance(fps, (list, tuple)) else [fps] * len(contexts)
+            rows = [self._prepare(x, timesteps, contexts[0], None, f, check_context=False) for f in fps_list]
+            t_rows = torch.cat([r[0] for r in rows])
+            fps_rows = torch.cat([r[1] for r in rows])
+            return self._plan_for(x, segs, shared_x=True).run(x, t_rows, fps_rows, list(contexts))
         segs = tuple((int(c.shape[0]), int(c.shape[1])) for c in contexts)
-        if sum(n for n, _ in segs) != x.shape[0]:
+        if sum(nv for nv, _ in segs) != n:
             raise ValueError("contexts must cover the batch of x")
         t_rows, fps_rows = self._prepare(x, timesteps, contexts[0], None, fps, check_context=False)
         return self._plan_for(x, segs).run(x, t_rows, fps_rows, list(contexts))

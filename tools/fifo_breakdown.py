@@ -107,12 +107,12 @@ torch.cuda.synchronize()
 t_wall = time.perf_counter() - t0
 it_ms = elapsed(a, b) / N
 finite = bool(torch.isfinite(eng.latents()).all())
-print(f"\nAFTER   one hipGraph per iteration (fifo_graph.FifoEngine: {eng.n_unet_launches} UNet launches, B = 16 with two context segments, + 12 more):")
+print(f"\nAFTER   one hipGraph per iteration (fifo_graph.FifoEngine: {eng.n_unet_launches} UNet launches, B = 16 = 8 windows x 2 contexts with a shared prefix, + 12 more):")
 print(f"  per iteration, HIP events around {N} replays    {it_ms:8.2f} ms   (wall {t_wall / N * 1e3:.2f} ms; host enqueue {t_host / N * 1e3:.3f} ms per iteration; queue finite: {finite})")
 
 # the UNet launches alone: a second plan of the same signature, replayed as its own graph
-plan = _Plan(unet, eng.plan.B, T, H, W, tuple(eng.plan.segs), torch.float32, dev)
-x = torch.randn(eng.plan.B, 4, T, H, W, device=dev, generator=g)
+plan = _Plan(unet, eng.plan.B, T, H, W, tuple(eng.plan.segs), torch.float32, dev, shared_x=eng.plan.reps > 1)
+x = torch.randn(eng.plan.Bx, 4, T, H, W, device=dev, generator=g)
 for _ in range(3):
     plan.run(x, eng.plan.t_rows, eng.plan.fps_rows, eng.plan.ctx)
 torch.cuda.synchronize()
