@@ -24,12 +24,19 @@ torch.cuda.set_device(dev)
 dm = bench.build_model(dev, seed=321)
 unet = dm.model.diffusion_model
 g = torch.Generator(device=dev).manual_seed(1)
-x = torch.randn(B, 4, 16, 40, 64, device=dev, generator=g)
+# the plan the samplers run: B = 2n videos = n latents x (conditional, unconditional) context with the shared prefix
+# (PP_SHARED=0: a plain batch of B independent videos, the round-2 structure)
+SHARED = os.environ.get("PP_SHARED", "1") != "0" and B % 2 == 0
+n = B // 2 if SHARED else B
+x = torch.randn(n, 4, 16, 40, 64, device=dev, generator=g)
 ctx = torch.randn(B, 77, 1024, device=dev, generator=g)
-ts = torch.full((B,), 500, device=dev, dtype=torch.long)
+ts = torch.full((n,), 500, device=dev, dtype=torch.long)
 with torch.no_grad():
     for _ in range(2):
-        unet(x, ts, ctx, fps=torch.tensor([10] * B, device=dev))
+        if SHARED:
+            unet.forward_segments(x, ts, [ctx[:n], ctx[n:]], fps=torch.tensor([10] * n, device=dev), shared_x=True)
+        else:
+            unet(x, ts, ctx, fps=torch.tensor([10] * B, device=dev))
 torch.cuda.synchronize()
 plan = next(iter(unet._plans.values())) if hasattr(unet, "_plans") else None
 assert plan is not None
@@ -115,7 +122,7 @@ if pending:
         r[0] += 1
         r[1] += us
         tot += us
-print(f"# B={B}, mode {MODE}: {len(plan.steps)} steps, sum of isolated step times {tot / 1e3:.2f} ms")
+print(f"# B={B}{' (shared CFG prefix)' if SHARED else ''}, mode {MODE}: {len(plan.steps)} steps, sum of isolated step times {tot / 1e3:.2f} ms")
 print(f"{'total_us':>9s} {'n':>3s} {'each_us':>8s} {'TF/s':>6s}  step")
 for key, (n, us, flop) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
     tf = flop * n / us / 1e6 if flop else 0.0

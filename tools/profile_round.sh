@@ -6,7 +6,7 @@ set -e
 OUT=$1
 export TMPDIR=/tmp
 mkdir -p $OUT
-BENCH="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fifo --no-video"
+BENCH="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fifo --no-video"   # 6 forwards of the B=2 (shared-prefix) plan
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -- python3 $BENCH > $OUT/ktrace.log 2>&1
 STATS=$(find $OUT/ktrace -name "*kernel_stats.csv" | head -1)
 cp "$STATS" $OUT/kernel_stats.csv
