@@ -335,6 +335,11 @@ int moca_fifo_step_windows_f32(const moca_fifo_step_params* p, void* stream);
  * its last frame (funcs.py:113-116); then head = head + 1 mod Q, iter += 1, ext_noise = 0. */
 int moca_fifo_advance_f32(moca_fifo_state* state, float* queue, const float* newframe, float* emitted, int32_t n_slots,
                           int32_t emit_frame, float* mask, float* mask_sums, int32_t C, int32_t Q, int32_t HW, void* stream);
+/* prepare_latents (funcs.py:53-79): queue[bc][j][p] = coef_z[j] * z[bc][frame_idx[j]][p] + coef_noise[j] * noise[bc][j][p] for the Q queue
+ * frames (lookahead copies first); z [BC][Tz][HW], noise / queue [BC][Q][HW] f32; coef_z[j] = alpha_j ** 0.5 and coef_noise[j] =
+ * (1 - alpha_j) ** 0.5 evaluated by the host as the reference's fp32 tensors are. */
+int moca_fifo_prepare_queue_f32(const float* z, const float* noise, float* queue, const float* coef_z, const float* coef_noise,
+                                const int32_t* frame_idx, int32_t BC, int32_t Tz, int32_t Q, int32_t HW, void* stream);
 /* sums[fr] = sum of mask frame fr, mask [frames][HW] (ddim.py:585) */
 int moca_mask_frame_sums_f32(const float* mask, float* sums, int32_t frames, int32_t HW, void* stream);
 

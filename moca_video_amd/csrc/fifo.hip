@@ -171,6 +171,23 @@ __global__ __launch_bounds__(256) void mask_frame_sums_kernel(const float* __res
     if (threadIdx.x == 0) sums[fm] = red[0] + red[1] + red[2] + red[3];
 }
 
+// funcs.py:53-79: queue frame j = sqrt(a_j) z[frame_idx_j] + sqrt(1 - a_j) noise_j, all B videos; coefficients come from the host,
+// evaluated as the reference's 0-dim fp32 tensors are (alpha ** 0.5, (1 - alpha) ** 0.5); mul, mul, add: no contraction
+__global__ __launch_bounds__(256) void fifo_prepare_kernel(const float* __restrict__ z, const float* __restrict__ noise, float* __restrict__ out,
+                                                           const float* __restrict__ ca, const float* __restrict__ cb,
+                                                           const int32_t* __restrict__ fidx, int BC, int Tz, int Q, int HW) {
+    const int64_t total = (int64_t)BC * Q * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const int64_t r = i / HW;
+        const int j = (int)(r % Q);
+        const int64_t bc = r / Q;
+        const float a = ca[j] * z[(bc * Tz + fidx[j]) * HW + p];
+        const float b = cb[j] * noise[i];
+        out[i] = a + b;
+    }
+}
+
 inline int grid_for(int64_t total) {
     int64_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
@@ -220,6 +237,15 @@ extern "C" int moca_fifo_advance_f32(moca_fifo_state* state, float* queue, const
                        n_slots, emit_frame, mask, mask_sums, C, Q, HW);
     MOCA_CHECK_LAUNCH();
     hipLaunchKernelGGL(fifo_advance_bump_kernel, dim3(1), dim3(1), 0, st, state, Q);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_fifo_prepare_queue_f32(const float* z, const float* noise, float* queue, const float* coef_z, const float* coef_noise,
+                                           const int32_t* frame_idx, int32_t BC, int32_t Tz, int32_t Q, int32_t HW, void* stream) {
+    if (!z || !noise || !queue || !coef_z || !coef_noise || !frame_idx || BC <= 0 || Tz <= 0 || Q <= 0 || HW <= 0) return MOCA_E_BADARG;
+    hipLaunchKernelGGL(fifo_prepare_kernel, dim3(grid_for((int64_t)BC * Q * HW)), dim3(256), 0, moca_stream(stream), z, noise, queue, coef_z,
+                       coef_noise, frame_idx, BC, Tz, Q, HW);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

@@ -5,9 +5,13 @@
 Noise is an optional explicit argument wherever the reference calls torch.randn*."""
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 import torch
 
+from . import lib as _l
+from . import ops
 from .fifo_graph import FifoEngine, fifo_windows
 from .freeinit import freq_mix_3d, get_freq_filter
 from .sampler import DDIMSampler
@@ -25,29 +29,26 @@ def prepare_latents(args, input_path, sampler, model=None, data=None, initial_la
         initial_latents = model.encode_first_stage_2DAE(frames)
     elif initial_latents is None:
         initial_latents = torch.load(input_path + f"/{args.num_inference_steps}.pt")
-    initial_latents = initial_latents.to("cuda")
-    latents_list = []
-    k = 0
-
-    def draw(like):
-        nonlocal k
-        n = torch.randn_like(like) if noises is None else noises[k].to(like.device, like.dtype)
-        k += 1
-        return n
-
-    if args.lookahead_denoising:
-        for i in range(args.video_length // 2):
-            alpha = sampler.ddim_alphas[0]
-            beta = 1 - alpha
-            latents = alpha ** (0.5) * initial_latents[:, :, [0]] + beta ** (0.5) * draw(initial_latents[:, :, [0]])
-            latents_list.append(latents)
-    for i in range(args.num_inference_steps):
-        alpha = sampler.ddim_alphas[i]
-        frame_idx = max(0, i - (args.num_inference_steps - initial_latents.shape[2]))
-        current_latents = initial_latents[:, :, [frame_idx]]
-        noise = draw(current_latents)
-        latents_list.append(alpha ** (0.5) * current_latents + (1 - alpha) ** (0.5) * noise)
-    return torch.cat(latents_list, dim=2)
+    z = initial_latents.to("cuda", torch.float32).contiguous()
+    b, c, tz, h, w = z.shape
+    n_look = args.video_length // 2 if args.lookahead_denoising else 0
+    N = args.num_inference_steps
+    Q = n_look + N
+    # per queue frame: which base frame it starts from and its noise level (:55-77) -- O(Q) host scalars, evaluated like the
+    # reference's 0-dim fp32 tensors (alpha ** 0.5, (1 - alpha) ** 0.5); the arithmetic over the latents is one kernel
+    alphas = torch.as_tensor(np.asarray(sampler.ddim_alphas), dtype=torch.float32)
+    j_alpha = torch.cat([alphas[:1].expand(n_look), alphas[:N]])
+    coef_z, coef_n = j_alpha ** 0.5, (1 - j_alpha) ** 0.5
+    fidx = torch.tensor([0] * n_look + [max(0, i - (N - tz)) for i in range(N)], dtype=torch.int32)
+    if noises is None:
+        noise = torch.randn(b, c, Q, h, w, device=z.device)          # the Q torch.randn_like draws of :62,72, one tensor
+    else:
+        noise = torch.cat([n.to(z.device, torch.float32).reshape(b, c, 1, h, w) for n in noises[:Q]], dim=2).contiguous()
+    out = torch.empty(b, c, Q, h, w, dtype=torch.float32, device=z.device)
+    _l.check(_l.load().moca_fifo_prepare_queue_f32(_l.ptr(z), _l.ptr(noise), _l.ptr(out), _l.ptr(coef_z.to(z.device)), _l.ptr(coef_n.to(z.device)),
+                                                   _l.ptr(fidx.to(z.device)), b * c, tz, Q, h * w, C.c_void_p(ops.current_stream())),
+             "moca_fifo_prepare_queue_f32")
+    return out
 
 
 def shift_latents(latents, davis_data=None, model=None, noise=None, anchor_noise=None):
