@@ -45,9 +45,9 @@ def prepare_latents(args, input_path, sampler, model=None, data=None, initial_la
     else:
         noise = torch.cat([n.to(z.device, torch.float32).reshape(b, c, 1, h, w) for n in noises[:Q]], dim=2).contiguous()
     out = torch.empty(b, c, Q, h, w, dtype=torch.float32, device=z.device)
-    _l.check(_l.load().moca_fifo_prepare_queue_f32(_l.ptr(z), _l.ptr(noise), _l.ptr(out), _l.ptr(coef_z.to(z.device)), _l.ptr(coef_n.to(z.device)),
-                                                   _l.ptr(fidx.to(z.device)), b * c, tz, Q, h * w, C.c_void_p(ops.current_stream())),
-             "moca_fifo_prepare_queue_f32")
+    cz, cn, fi = coef_z.to(z.device), coef_n.to(z.device), fidx.to(z.device)      # (named: a temporary's block would be reused by the next)
+    _l.check(_l.load().moca_fifo_prepare_queue_f32(_l.ptr(z), _l.ptr(noise), _l.ptr(out), _l.ptr(cz), _l.ptr(cn), _l.ptr(fi), b * c, tz, Q, h * w,
+                                                   C.c_void_p(ops.current_stream())), "moca_fifo_prepare_queue_f32")
     return out
 
 
@@ -167,14 +167,24 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
             (masks is None or masks.shape[2] == latents.shape[2])):
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())                # follows torch.manual_seed like the randn draws it replaces
+        moments = None
+        if davis_data is not None:                       # :101-108: the anchor frame never changes -> its posterior moments, once
+            last = davis_data[0][:, :, -1]
+            if last.shape[1] == 4:
+                last = last[:, :3]
+            moments = model.first_stage_model.encode(last.to(latents.device)).parameters
         eng = FifoEngine(args, model, ddim_sampler, cond, uc, cfg_scale, latents, conditioned_image=conditioned_image, masks=masks,
-                         n_slots=decode_batch if decode else max(total, 1), seed=seed)
+                         n_slots=decode_batch if decode else max(total, 1), seed=seed, anchor_moments=moments,
+                         scale_factor=getattr(model, "scale_factor", 1.0))
         try:
             for i in range(total):
-                if noises is not None or shift_noises is not None:
+                if noises is not None or shift_noises is not None or anchor_noises is not None:
                     nz = noises[i] if noises is not None else [torch.randn(noise_shape, device=latents.device) for _ in eng.wins]
                     sn = shift_noises[i] if shift_noises is not None else torch.randn_like(latents[:, :, -1])
-                    eng.step(noise=nz, shift_noise=sn)
+                    an = None
+                    if moments is not None:
+                        an = anchor_noises[i] if anchor_noises is not None else torch.randn_like(latents[:, :, -1])
+                    eng.step(noise=nz, shift_noise=sn, anchor_noise=an)
                 else:
                     eng.step()
                 if decode and ((i + 1) % decode_batch == 0 or i + 1 == total):

@@ -47,17 +47,23 @@ def _ptr(t):
 
 
 class FifoEngine:
-    """Device-resident MoCA-FIFO loop.  `supported(...)` says whether a call can run here; `fifo.fifo_ddim_sampling` falls back to
-    its host-driven loop otherwise (DAVIS-video mode with its per-iteration VAE posterior sample, a mask-producer callback)."""
+    """Device-resident MoCA-FIFO loop, prompt mode and DAVIS-video mode.  `supported(...)` says whether a call can run here;
+    `fifo.fifo_ddim_sampling` falls back to its host-driven loop otherwise (a mask-producer callback, per-call mask lists, a model
+    that is not ours).
+
+    DAVIS mode (`anchor_moments`): the FreeInit anchor of every shift is a fresh posterior sample of the VAE encoding of the LAST
+    DAVIS frame (funcs.py:101-108) -- the frame never changes, so its moments [1, 2z, h, w] are encoded ONCE by the caller and an
+    iteration only draws `scale_factor * (mean + std * noise)` (`moca_gaussian_sample_f32`) in front of the mix."""
 
     @staticmethod
     def supported(model, cond, latents, davis_data=None, sam_masks_fn=None):
         unet = getattr(getattr(model, "model", None), "diffusion_model", None)
-        return (isinstance(unet, UNetModel) and isinstance(cond, dict) and "c_crossattn" in cond and davis_data is None
+        return (isinstance(unet, UNetModel) and isinstance(cond, dict) and "c_crossattn" in cond
+                and (davis_data is None or getattr(model, "first_stage_model", None) is not None)
                 and sam_masks_fn is None and latents is not None and latents.is_cuda and latents.shape[0] == 1)
 
     def __init__(self, args, model, sampler, cond, uc, cfg_scale, latents, conditioned_image=None, masks=None, gamma=0.5,
-                 n_slots=1, seed=0):
+                 n_slots=1, seed=0, anchor_moments=None, scale_factor=1.0):
         self.unet = unet = model.model.diffusion_model
         dev = latents.device
         self.device = dev
@@ -123,7 +129,10 @@ class FifoEngine:
         st = _l.FifoState(0, 0, seed & 0xffffffff, (seed >> 32) & 0xffffffff, 0)
         self.state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.int32).to(dev)
         n_win = nW * Cc * f * HW
-        self.noise = torch.zeros(n_win + Cc * HW, **f32)             # [nW][C][f][HW] window noise | [C][HW] enqueued noise
+        self.noise = torch.zeros(n_win + 2 * Cc * HW, **f32)         # [nW][C][f][HW] window noise | [C][HW] enqueued noise | [C][HW] anchor draw
+        self.moments = None
+        if anchor_moments is not None:
+            self.moments = anchor_moments.to(dev, torch.float32).reshape(2 * Cc, HW).contiguous()
         self.momentum = torch.zeros(nW, Cc, f, HW, **f32)            # ddim.py:395-397
         self.pred_x0 = torch.empty(nW, Cc, f, HW, **f32)
         self.x_prev = torch.empty(nW, Cc, f, HW, **f32)
@@ -174,12 +183,15 @@ class FifoEngine:
 
         def pre():
             _l.check(lib.moca_fifo_randn_f32(st_, _l.ptr(self.noise), self.noise.numel(), S()), "moca_fifo_randn_f32")
-            _l.check(lib.moca_fifo_gather_windows_f32(st_, q_, _l.ptr(plan.x_in), _l.ptr(self.anchor), _l.ptr(self.win_start),
-                                                      nW, 1, Cc, Q, f, HW, S()), "moca_fifo_gather_windows_f32")
+            _l.check(lib.moca_fifo_gather_windows_f32(st_, q_, _l.ptr(plan.x_in), None if self.moments is not None else _l.ptr(self.anchor),
+                                                      _l.ptr(self.win_start), nW, 1, Cc, Q, f, HW, S()), "moca_fifo_gather_windows_f32")
 
         def post():
             _l.check(lib.moca_fifo_step_windows_f32(C.byref(p), S()), "moca_fifo_step_windows_f32")
-            _l.check(lib.moca_freq_mix_3d_f32(_l.ptr(self.anchor), _l.ptr(self.noise[n_win:]), _l.ptr(self.lpf), _l.ptr(self.newframe),
+            if self.moments is not None:                     # anchor = get_first_stage_encoding(posterior of the last DAVIS frame) (:108)
+                _l.check(lib.moca_gaussian_sample_f32(_l.ptr(self.moments), _l.ptr(self.noise[n_win + Cc * HW:]), _l.ptr(self.anchor), 1, Cc, HW,
+                                                      float(scale_factor), S()), "moca_gaussian_sample_f32")
+            _l.check(lib.moca_freq_mix_3d_f32(_l.ptr(self.anchor), _l.ptr(self.noise[n_win:n_win + Cc * HW]), _l.ptr(self.lpf), _l.ptr(self.newframe),
                                               Cc, 1, H, W, _l.ptr(self.mix_ws), S()), "moca_freq_mix_3d_f32")
             _l.check(lib.moca_fifo_advance_f32(st_, q_, _l.ptr(self.newframe), _l.ptr(self.emitted), self.n_slots, self.emit_frame,
                                                _l.ptr(self.mask), _l.ptr(self.mask_sums), Cc, Q, HW, S()), "moca_fifo_advance_f32")
@@ -189,9 +201,9 @@ class FifoEngine:
         sampler.momentum = self.momentum[nW - 1].view(1, Cc, f, H, W)      # what the reference's last call (rank 0) leaves behind
 
     # ------------------------------------------------------------------------------------------------------------------
-    def step(self, noise=None, shift_noise=None):
+    def step(self, noise=None, shift_noise=None, anchor_noise=None):
         """one outer iteration (enqueued, not synchronised).  `noise` = list over windows (reference order: rank 2n-1 .. 0) of
-        [1,C,f,H,W] tensors and `shift_noise` [1,C,H,W] fix the draws (both or neither)."""
+        [1,C,f,H,W] tensors, `shift_noise` [1,C,H,W] and (DAVIS mode) `anchor_noise` [1,C,1,H,W] fix the draws (all or none)."""
         plan = self.plan
         cur = torch.cuda.current_stream(self.device)
         plan.stream.wait_stream(cur)
@@ -199,7 +211,10 @@ class FifoEngine:
             if noise is not None:
                 n_win = self.nW * self.C * self.f * self.HW
                 self.noise[:n_win].view(self.nW, -1).copy_(torch.stack([n.reshape(-1) for n in noise]).to(self.device, torch.float32))
-                self.noise[n_win:].copy_(shift_noise.reshape(-1).to(self.device, torch.float32))
+                chw = self.C * self.HW
+                self.noise[n_win:n_win + chw].copy_(shift_noise.reshape(-1).to(self.device, torch.float32))
+                if anchor_noise is not None:
+                    self.noise[n_win + chw:].copy_(anchor_noise.reshape(-1).to(self.device, torch.float32))
                 self.state[4:5].fill_(1)                                 # ext_noise (the advance clears it)
             handle = plan.stream.cuda_stream
             ops.set_stream(handle)

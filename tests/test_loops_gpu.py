@@ -133,9 +133,11 @@ def test_hip_fifo_loop_prompt_mode_vs_reference_golden(dm, producer):
     assert e < TOL_FIFO, f"queue after 3 iterations: {e:.3e}"
 
 
-def test_hip_fifo_loop_davis_mode_vs_reference_golden(dm):
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_hip_fifo_loop_davis_mode_vs_reference_golden(dm, use_graph):
     """fifo_ddim_sampling with davis_data: queue from the VAE encoding of the frames, DAVIS masks in ddim_step, DAVIS branch of
-    shift_latents (anchor = posterior sample of the last frame's encoding) -- against the REAL loop"""
+    shift_latents (anchor = posterior sample of the last frame's encoding) -- against the REAL loop; host-driven (every ddim_step
+    call compared) and as one hipGraph per iteration (the anchor drawn from the once-encoded posterior moments by a kernel)"""
     from moca_video_amd.fifo import fifo_ddim_sampling, prepare_latents
     from moca_video_amd.sampler import DDIMSampler
     g = golden("loop_fifo")
@@ -154,9 +156,9 @@ def test_hip_fifo_loop_davis_mode_vs_reference_golden(dm):
     calls, _ = _spy_steps(s)
     frames = fifo_ddim_sampling(FIFO_ARGS, dm, cond, (1, 4, 8, 16, 16), s, cfg_scale=12.0, uc_emb=t["uc"], latents=lat,
                                 conditioned_image=cimg, n_iterations=3, noises=noises, shift_noises=shifts, decode=True,
-                                davis_data=(dframes, dmasks), anchor_noises=anchors)
-    assert len(frames) == 3 and len(calls) == 12
-    for c in range(12):
+                                davis_data=(dframes, dmasks), anchor_noises=anchors, use_graph=use_graph)
+    assert len(frames) == 3 and len(calls) == (0 if use_graph else 12)
+    for c in range(len(calls)):
         assert relerr(calls[c][0].cpu(), g["davis_x_prev"][c]) < TOL_FIFO, f"call {c} x_prev"
         assert relerr(calls[c][1].cpu(), g["davis_pred_x0"][c]) < TOL_FIFO, f"call {c} pred_x0"
     for i in range(3):
