@@ -421,7 +421,10 @@ class _Plan(_PlanBase):
         ld = self.kv_all.shape[1]                                # all layers' K|V projected by one GEMM up front
         o = self.pool.get(M * (self.reps if expand else 1), Cn)
         r0 = k0 = 0
-        for nv, Ls in self.segs:                                 # (one launch per context segment: rows of q / o, rows of K|V)
+        segs = self.segs
+        if not expand and len(segs) > 1 and all(Ls == segs[0][1] for _, Ls in segs):
+            segs = [(sum(nv for nv, _ in segs), segs[0][1])]     # equal context lengths: the segments are one contiguous batch
+        for nv, Ls in segs:                                      # (one launch per context segment: rows of q / o, rows of K|V)
             rows = nv * self.T * HW
             kv = self.kv_all[k0:k0 + nv * Ls]
             self._emit(ops.attention, q[0:rows] if expand else q[r0:r0 + rows], kv[:, off:off + inner],

@@ -45,6 +45,28 @@ def test_gemm_params_struct_matches_header():
     assert C.sizeof(lib.GemmParams) == 256   # 7 pointers + 23 int32 padded to 8, + colsum, ln_gamma, ln_beta, ln_out + ld_ln + ln_eps + rowsum, lnf_part, lnf_wsum + lnf_nparts + pad + gstat + gstat_rows + tattn_scale + sk_sync + sk_big + pad
 
 
+def _header_struct_fields(name):
+    src = open(os.path.join(ROOT, "include", "moca_hip.h")).read()
+    body = src[src.index("typedef struct %s {" % name):src.index("} %s;" % name)]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for line in body.splitlines()[1:]:
+        line = line.strip().rstrip(";")
+        if not line:
+            continue
+        decl = re.sub(r"^(const\s+)?(struct\s+)?(void|float|double|int32_t|uint32_t|int64_t|uint64_t|moca_fifo_state)\s*\*?\s*", "", line)
+        names += [re.sub(r"\[\d+\]", "", n.strip().lstrip("*")) for n in decl.split(",") if n.strip()]
+    return names
+
+
+def test_fifo_structs_match_header():
+    from moca_video_amd import lib
+    assert _header_struct_fields("moca_fifo_state") == [f[0] for f in lib.FifoState._fields_]
+    assert C.sizeof(lib.FifoState) == 32
+    assert _header_struct_fields("moca_fifo_step_params") == [f[0] for f in lib.FifoStepParams._fields_]
+    assert C.sizeof(lib.FifoStepParams) == 16 * 8 + 5 * 4 + 6 * 4 + 4          # 16 pointers, 5 floats, 6 ints, tail padding
+
+
 def test_bad_arguments_are_rejected_without_a_gpu():
     from moca_video_amd import lib
     l = lib.load()
@@ -52,6 +74,9 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert l.moca_gemm_f16(C.byref(p), None) == -1                 # null pointers
     assert l.moca_layernorm_f16(None, None, None, None, 4, 64, 1e-5, None) == -1
     assert l.moca_temporal_attention_f16(C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 1, 17, 4, 1, 192, 64, 0.125, None) == -1
+    assert l.moca_fifo_step_windows_f32(C.byref(lib.FifoStepParams()), None) == -1
+    assert l.moca_fifo_randn_f32(None, None, 16, None) == -1 and l.moca_repeat_f16(C.c_void_p(16), C.c_void_p(32), 24, 2, None) == -1
+    assert l.moca_set_tuning(99, 1) == -1 and l.moca_set_tuning(lib.MOCA_TUNE_GEMM_G4, 1) == 1
     assert l.moca_gemm_splitk_ws_bytes(640, 1280, 4) == 4 * 640 * 1280 * 4
     assert l.moca_groupnorm_ws_bytes(16, 2560, 320) > 0
     with pytest.raises(lib.MocaHipError):
