@@ -195,6 +195,26 @@ def test_fifo_batched_windows_equal_sequential():
     assert not torch.equal(outs[0][0], q0)
 
 
+def test_shared_cfg_prefix_equals_separate_forwards(reduced_model):
+    """UNetModel.forward_segments(shared_x=True): the two classifier-free-guidance branches (same latents and timesteps, contexts of
+    DIFFERENT lengths: 154 and 77 tokens) as one forward that computes everything before the first cross-attention once -- against
+    one plain forward per branch (uniform and per-frame FIFO timesteps, eager / capture / replay)."""
+    x = inp("sp.x", (2, 4, 8, 16, 16)).cuda()
+    c154, c77 = inp("sp.c154", (2, 154, 128)).cuda(), inp("sp.c77", (2, 77, 128)).cuda()
+    fps = torch.tensor([10, 24]).cuda()
+    for t in (torch.tensor([981, 20]).cuda(), torch.arange(16).cuda() * 60):          # [B] and [B*T]
+        ref = torch.cat([reduced_model(x, t, context=c154, fps=fps), reduced_model(x, t, context=c77, fps=fps)], 0)
+        for it in range(3):
+            out = reduced_model.forward_segments(x, t, [c154, c77], fps=[fps, fps], shared_x=True)
+            assert out.shape == ref.shape
+            # the prefix runs at half the batch (other tilings / summation orders): fp16 noise level, not bit equality
+            assert relerr(out, ref) < TOL_UNET, f"shared prefix, pass {it}: {relerr(out, ref):.2e}"
+    # equal context lengths: the cross-attentions after the split run as ONE launch over both segments
+    out = reduced_model.forward_segments(x, t, [c77, c77.flip(0)], fps=[fps, fps], shared_x=True)
+    ref = torch.cat([reduced_model(x, t, context=c77, fps=fps), reduced_model(x, t, context=c77.flip(0), fps=fps)], 0)
+    assert relerr(out, ref) < TOL_UNET
+
+
 def test_forward_concurrent_equals_forward(reduced_model):
     """two forwards launched as separate hipGraphs on separate streams return what forward() returns"""
     g = golden("unet_reduced")
