@@ -420,6 +420,9 @@ def main():
                     help="cond+uncond as one B=2 launch, or as two concurrent B=1 hipGraphs on two streams")
     ap.add_argument("--no-shared-prefix", action="store_true",
                     help="A/B: evaluate the two CFG branches as a plain B=2 batch instead of sharing the layers before the first cross-attention")
+    ap.add_argument("--step-mode", default="graph", choices=["graph", "host"],
+                    help="graph: one hipGraph per DDIM step (timestep, UNet, noise, guidance + update: what DDIMSampler.sample runs); "
+                         "host: p_sample_ddim per step (UNet graph + four small launches issued by the host)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--height", type=int, default=40)
@@ -480,7 +483,19 @@ def main():
     x, ctx, cond = batches[0]["x"][:1], batches[0]["cond"]["c_crossattn"][0][:1], None
     cond = {"c_crossattn": [ctx], "fps": torch.tensor([10], device=device)}
 
+    # One bench step = one DDIM step of `DDIMSampler.sample`'s loop (ddim.py:226-252) for every prompt batch of this rank.  With
+    # --step-mode graph (default) the loop body is ONE hipGraph per batch (fifo_graph.BaseEngine, what `sample()` runs): timestep
+    # rows, the shared-prefix UNet forward, device noise, guidance + DDIM update in place; --step-mode host calls p_sample_ddim.
+    engines = None
+    if args.step_mode == "graph" and args.cfg_mode == "batched" and sampler.share_prefix:
+        from moca_video_amd.fifo_graph import BaseEngine
+        engines = [BaseEngine(dm, sampler, b["x"], b["cond"], b["uc"], 12.0, seed=321 + i) for i, b in enumerate(batches)]
+
     def ddim_step(i, imgs):
+        if engines is not None:
+            for e in engines:
+                e.step()
+            return imgs
         index = S - 1 - (i % S)
         out = []
         for b, img in zip(batches, imgs):
@@ -494,7 +509,7 @@ def main():
     for i in range(max(args.warmup, 2)):       # >= 2: eager pass + hipGraph capture pass
         img = ddim_step(i, img)
     torch.cuda.synchronize()
-    plans = list(unet._plans.values())
+    plans = [e.plan for e in engines] if engines is not None else list(unet._plans.values())
     graph_on = all(pl.graph is not None for pl in plans)
 
     # HIP events on the stream(s) the UNet graphs are launched on (torch.cuda.Event would only see
@@ -523,6 +538,8 @@ def main():
     for i in range(args.steps):
         img = ddim_step(i, img)
     torch.cuda.synchronize()
+    if engines is not None:
+        img = [e.latents() for e in engines]
     mdist.barrier()
     dt = time.perf_counter() - t0
     dt = mdist.max_over_ranks(dt, device)
@@ -564,7 +581,7 @@ def main():
         achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
     name, cus = mlib.device_info()
     traffic_bytes, traffic_src = traffic_from_profile()
-    n_launches = max([len(pl.steps) for pl in getattr(unet, "_plans", {}).values()] or [0])
+    n_launches = max([len(pl.steps) for pl in plans] or [0])
     res = {
         "metric": "denoising UNet-steps/sec @16x320x512 fp16",
         "value": round(value, 3),
@@ -587,7 +604,7 @@ def main():
                    "unet_steps_per_step": 2 * n_prompts, "context_tokens": 77, "weights": "random-init, 1.41B params, fp16 packed" +
                    ("" if world == 1 else "; materialised on rank 0 only, RCCL broadcast (C1), checksums all-gathered"),
                    "parallelism": f"dp{world} (independent prompts, no collective in the loop)",
-                   "hipgraph_replay": graph_on, "cfg_mode": args.cfg_mode, "cfg_shared_prefix": sampler.share_prefix and args.cfg_mode == "batched", "device": name, "compute_units": cus, "output_finite": finite},
+                   "hipgraph_replay": graph_on, "cfg_mode": args.cfg_mode, "cfg_shared_prefix": sampler.share_prefix and args.cfg_mode == "batched", "step_mode": "graph" if engines is not None else "host", "device": name, "compute_units": cus, "output_finite": finite},
         "achieved_tflops": round(value / world * FLOP_PER_UNET_STEP / 1e12, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic_bytes if not concurrent else None, "traffic_source": traffic_src if not concurrent else None,

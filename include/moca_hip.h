@@ -340,6 +340,15 @@ int moca_fifo_advance_f32(moca_fifo_state* state, float* queue, const float* new
  * (1 - alpha_j) ** 0.5 evaluated by the host as the reference's fp32 tensors are. */
 int moca_fifo_prepare_queue_f32(const float* z, const float* noise, float* queue, const float* coef_z, const float* coef_noise,
                                 const int32_t* frame_idx, int32_t BC, int32_t Tz, int32_t Q, int32_t HW, void* stream);
+/* ---- one step of base sampling (`ddim_sampling`, ddim.py:226-252) as device-side work: step i = state->iter mod S uses schedule
+ * index S - 1 - i (:238), so the captured launch sequence [timestep rows, UNet, this step] replays for every i.
+ * moca_base_set_timestep: rows[0:n] = table[S - 1 - i] (`ts = torch.full((b,), step)`, :239; table = ddim_timesteps as int64).
+ * moca_base_ddim_step_f32: guidance e_u + s (e_c - e_u) (:304; eps_u NULL: none) + the tail of p_sample_ddim (:328-357) with
+ *   coef[idx][8] = {sqrt(a_t), sqrt(a_prev), sigma_t, sqrt(1-a_t), sqrt(1-a_prev-sigma_t^2), scale_t, scale_prev, -} (host,
+ *   fp32 like the reference's tensors); x [n] is updated IN PLACE to x_prev, pred_x0 optional; then iter += 1, ext_noise = 0. */
+int moca_base_set_timestep(const moca_fifo_state* state, const int64_t* table, int32_t S, int64_t* rows, int32_t n, void* stream);
+int moca_base_ddim_step_f32(moca_fifo_state* state, float* x, const float* eps_c, const float* eps_u, const float* noise,
+                            float* pred_x0, const float* coef, int32_t S, float cfg_scale, int32_t use_scale, int64_t n, void* stream);
 /* sums[fr] = sum of mask frame fr, mask [frames][HW] (ddim.py:585) */
 int moca_mask_frame_sums_f32(const float* mask, float* sums, int32_t frames, int32_t HW, void* stream);
 

@@ -160,6 +160,50 @@ __global__ void fifo_advance_bump_kernel(moca_fifo_state* st, int Q) {
     st->ext_noise = 0;
 }
 
+// ---- base sampling (ddim.py:226-252): one DDIM step of `ddim_sampling` as device-side work.  Step i of the loop uses schedule
+// index S - 1 - i (ddim.py:238); i = state->iter mod S, so a captured step replays for every i.
+// rows[0:n] = table[S - 1 - i]: the timestep rows of the UNet plan (ddim.py:239 `ts = torch.full((b,), step)`)
+__global__ __launch_bounds__(256) void base_set_timestep_kernel(const moca_fifo_state* __restrict__ st, const int64_t* __restrict__ table,
+                                                                int S, int64_t* __restrict__ rows, int n) {
+    const int64_t t = table[S - 1 - st->iter % S];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) rows[i] = t;
+}
+
+// guidance (ddim.py:304) + the tail of p_sample_ddim (ddim.py:328-357, as ddim_update_kernel) with the coefficients of schedule
+// index S - 1 - i: coef[idx] = {sqrt(a_t), sqrt(a_prev), sigma_t, sqrt(1 - a_t), sqrt(1 - a_prev - sigma_t^2), scale_t, scale_prev, -}.
+// x is updated IN PLACE (it is the UNet plan's input buffer: the next step reads it there).
+__global__ __launch_bounds__(256) void base_step_kernel(const moca_fifo_state* __restrict__ st, float* __restrict__ x,
+                                                        const float* __restrict__ eps_c, const float* __restrict__ eps_u,
+                                                        const float* __restrict__ noise, float* __restrict__ pred_x0,
+                                                        const float* __restrict__ coef, int S, float cfg_scale, int use_scale, int64_t n) {
+    const float* cf = coef + (int64_t)(S - 1 - st->iter % S) * 8;
+    const float sqrt_at = cf[0], sqrt_aprev = cf[1], sigma_t = cf[2], s1m = cf[3], dir_coef = cf[4], scale_t = cf[5], scale_prev = cf[6];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float et = eps_c[i];
+        if (eps_u) {
+            const float u = eps_u[i];
+            et = u + cfg_scale * (et - u);                      // :304
+        }
+        float p0 = (x[i] - s1m * et) / sqrt_at;                 // :339
+        const float dir = dir_coef * et;                        // :343
+        const float nz = sigma_t * noise[i];                    // :345
+        float xp;
+        if (use_scale) {
+            p0 = p0 / scale_t;                                  // :353
+            xp = sqrt_aprev * scale_prev * p0 + dir + nz;       // :354
+        } else {
+            xp = sqrt_aprev * p0 + dir + nz;                    // :356
+        }
+        x[i] = xp;
+        if (pred_x0) pred_x0[i] = p0;
+    }
+}
+
+__global__ void state_bump_kernel(moca_fifo_state* st) {
+    st->iter = st->iter + 1;
+    st->ext_noise = 0;
+}
+
 __global__ __launch_bounds__(256) void mask_frame_sums_kernel(const float* __restrict__ mask, float* __restrict__ sums, int HW) {
     __shared__ float red[4];
     const int fm = blockIdx.x;
@@ -246,6 +290,26 @@ extern "C" int moca_fifo_prepare_queue_f32(const float* z, const float* noise, f
     if (!z || !noise || !queue || !coef_z || !coef_noise || !frame_idx || BC <= 0 || Tz <= 0 || Q <= 0 || HW <= 0) return MOCA_E_BADARG;
     hipLaunchKernelGGL(fifo_prepare_kernel, dim3(grid_for((int64_t)BC * Q * HW)), dim3(256), 0, moca_stream(stream), z, noise, queue, coef_z,
                        coef_noise, frame_idx, BC, Tz, Q, HW);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_base_set_timestep(const moca_fifo_state* state, const int64_t* table, int32_t S, int64_t* rows, int32_t n, void* stream) {
+    if (!state || !table || !rows || S <= 0 || n <= 0) return MOCA_E_BADARG;
+    hipLaunchKernelGGL(base_set_timestep_kernel, dim3(grid_for(n)), dim3(256), 0, moca_stream(stream), state, table, S, rows, n);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_base_ddim_step_f32(moca_fifo_state* state, float* x, const float* eps_c, const float* eps_u, const float* noise,
+                                       float* pred_x0, const float* coef, int32_t S, float cfg_scale, int32_t use_scale, int64_t n,
+                                       void* stream) {
+    if (!state || !x || !eps_c || !noise || !coef || S <= 0 || n <= 0) return MOCA_E_BADARG;
+    hipStream_t st = moca_stream(stream);
+    hipLaunchKernelGGL(base_step_kernel, dim3(grid_for(n)), dim3(256), 0, st, state, x, eps_c, eps_u, noise, pred_x0, coef, S, cfg_scale,
+                       use_scale, n);
+    MOCA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(state_bump_kernel, dim3(1), dim3(1), 0, st, state);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

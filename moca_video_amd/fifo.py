@@ -97,11 +97,12 @@ def uncond_embedding(model, c_emb, uc_emb):
 
 
 def base_ddim_sampling(model, cond, noise_shape, ddim_steps=50, ddim_eta=1.0, cfg_scale=1.0, uc_emb=None,
-                       latents_dir=None, x_T=None, noises=None):
+                       latents_dir=None, x_T=None, noises=None, use_graph=True):
     """funcs.py:177-241: returns (batch_images, ddim_sampler, samples) like the reference; batch_images is the VAE
     decode of the samples (:239) when the model was built with `first_stage_config`, else None.  `uc_emb` replaces
     model.get_learned_conditioning([""]) (the text encoder is out of scope)."""
     sampler = DDIMSampler(model)
+    sampler.use_graph = use_graph            # one hipGraph per DDIM step (fifo_graph.BaseEngine) vs host-issued p_sample_ddim
     uc = None
     if cfg_scale != 1.0:
         c_emb = cond["c_crossattn"][0] if isinstance(cond, dict) else cond
@@ -114,6 +115,7 @@ def base_ddim_sampling(model, cond, noise_shape, ddim_steps=50, ddim_eta=1.0, cf
     samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=noise_shape[0], shape=noise_shape[1:],
                                 verbose=False, unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc,
                                 eta=ddim_eta, x_T=x_T, latents_dir=latents_dir, noises=noises)
+    sampler.release()                        # the step graph's buffers: the FIFO stage that follows builds its own plan
     images = model.decode_first_stage_2DAE(samples) if getattr(model, "first_stage_model", None) is not None else None
     return images, sampler, samples
 

@@ -254,3 +254,111 @@ class FifoEngine:
 
     def close(self):
         self.plan.close()
+
+
+class BaseEngine:
+    """One step of base sampling -- `DDIMSampler.ddim_sampling`'s loop body (ddim.py:226-252: two UNet calls on the same latents, guidance,
+    the DDIM update with `use_scale`, fresh noise) -- as ONE hipGraph: [timestep rows of step i] + the shared-prefix UNet forward of
+    the B latents x (conditional, unconditional) + [noise, guidance + update in place, i += 1].  The latents live in the plan's input
+    buffer, the schedule in device tables indexed by the state block's iteration counter; the host only replays."""
+
+    @staticmethod
+    def supported(model, x, cond, uc, scale):
+        unet = getattr(getattr(model, "model", None), "diffusion_model", None)
+        ok = isinstance(unet, UNetModel) and x.is_cuda and isinstance(cond, dict) and isinstance(uc, dict) and scale != 1.0
+        return ok and set(cond.keys()) == set(uc.keys()) <= {"c_crossattn", "fps"} and \
+            getattr(model.model, "conditioning_key", None) == "crossattn" and 2 * x.shape[0] <= 64
+
+    def __init__(self, model, sampler, x, cond, uc, cfg_scale, seed=0, keep_pred_x0=False):
+        self.unet = unet = model.model.diffusion_model
+        dev = x.device
+        self.device = dev
+        if unet._packed is None:
+            unet._pack()
+        B, Cc, T, H, W = x.shape
+        self.shape = (B, Cc, T, H, W)
+        S = len(sampler.ddim_timesteps)
+        self.S = S
+        cc, cu = torch.cat(cond["c_crossattn"], 1), torch.cat(uc["c_crossattn"], 1)
+        segs = ((B, int(cc.shape[1])), (B, int(cu.shape[1])))
+        self.plan = plan = _Plan(unet, 2 * B, T, H, W, segs, torch.float32, dev, shared_x=True)
+
+        def fps_rows(fp):
+            if isinstance(fp, int):
+                return torch.full((B * T,), fp, dtype=torch.int64, device=dev)
+            fp = torch.as_tensor(fp, device=dev).reshape(-1).to(torch.int64)
+            return (fp if fp.shape[0] == B else fp[:1].expand(B)).repeat_interleave(T)
+        f32 = np.float32
+        coef = np.zeros((S, 8), np.float32)
+        use_scale = bool(sampler.use_scale)
+        for i in range(S):                                   # the 0-dim fp32 tensors of ddim.py:331-343, per schedule index
+            a_t, a_prev, sig = f32(sampler.ddim_alphas[i]), f32(sampler.ddim_alphas_prev[i]), f32(sampler.ddim_sigmas[i])
+            coef[i, :5] = (np.sqrt(a_t), np.sqrt(a_prev), sig, f32(sampler.ddim_sqrt_one_minus_alphas[i]), np.sqrt(f32(1.) - a_prev - sig * sig))
+            coef[i, 5] = f32(sampler.ddim_scale_arr[i]) if use_scale else 1.0
+            coef[i, 6] = f32(sampler.ddim_scale_arr_prev[i]) if use_scale else 1.0
+        self.coef = torch.from_numpy(coef).to(dev)
+        self.t_table = torch.from_numpy(np.asarray(sampler.ddim_timesteps, dtype=np.int64)).to(dev)
+        self.state = torch.zeros(8, dtype=torch.int32, device=dev)
+        n = x.numel()
+        self.noise = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.pred_x0 = torch.empty(n, dtype=torch.float32, device=dev) if keep_pred_x0 else None
+        self._fps_rows = fps_rows
+        self.reset(x, cond, uc, seed)
+        lib = _l.load()
+        eps = plan.out.reshape(2 * B, -1)
+        st_ = _l.ptr(self.state)
+        S_ = lambda: C.c_void_p(ops.current_stream())
+
+        def pre():
+            _l.check(lib.moca_base_set_timestep(st_, _l.ptr(self.t_table), S, _l.ptr(plan.t_rows), plan.t_rows.numel(), S_()), "moca_base_set_timestep")
+            _l.check(lib.moca_fifo_randn_f32(st_, _l.ptr(self.noise), n, S_()), "moca_fifo_randn_f32")
+
+        def post():
+            _l.check(lib.moca_base_ddim_step_f32(st_, _l.ptr(plan.x_in), _l.ptr(eps[:B]), _l.ptr(eps[B:]), _l.ptr(self.noise), _l.ptr(self.pred_x0),
+                                                 _l.ptr(self.coef), S, float(cfg_scale), 1 if use_scale else 0, n, S_()), "moca_base_ddim_step_f32")
+        plan.steps = [pre] + plan.steps + [post]
+
+    def reset(self, x, cond, uc, seed=0):
+        """start a new trajectory on the same plan: latents x_T, contexts, fps, iteration 0, a new noise stream"""
+        plan, dev = self.plan, self.device
+        B = self.shape[0]
+        cc, cu = (torch.cat(c["c_crossattn"], 1).expand(B, -1, -1) for c in (cond, uc))
+        st = _l.FifoState(0, 0, seed & 0xffffffff, (seed >> 32) & 0xffffffff, 0)
+        cur = torch.cuda.current_stream(dev)
+        plan.stream.wait_stream(cur)
+        with torch.cuda.stream(plan.stream):
+            self.state.copy_(torch.frombuffer(bytearray(bytes(st)), dtype=torch.int32))
+            plan.x_in.copy_(x.to(torch.float32))
+            plan.fps_rows.copy_(torch.cat([self._fps_rows(cond.get("fps", 16)), self._fps_rows(uc.get("fps", 16))]))
+            plan.set_context([cc, cu])
+        cur.wait_stream(plan.stream)
+        self.n_iter = 0
+
+    def step(self, noise=None):
+        """one DDIM step (enqueued, not synchronised); `noise` [B,C,T,H,W] fixes the draw"""
+        plan = self.plan
+        cur = torch.cuda.current_stream(self.device)
+        plan.stream.wait_stream(cur)
+        with torch.cuda.stream(plan.stream):
+            if noise is not None:
+                self.noise.copy_(noise.reshape(-1).to(self.device, torch.float32))
+                self.state[4:5].fill_(1)
+            handle = plan.stream.cuda_stream
+            ops.set_stream(handle)
+            try:
+                plan._launch(handle)
+            finally:
+                ops.set_stream(None)
+        plan.n_runs += 1
+        self.n_iter += 1
+
+    def latents(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.plan.stream)
+        return self.plan.x_in.clone()
+
+    def last_pred_x0(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.plan.stream)
+        return None if self.pred_x0 is None else self.pred_x0.view(self.shape).clone()
+
+    def close(self):
+        self.plan.close()

@@ -110,6 +110,8 @@ SIGNATURES = {
     "moca_fifo_step_windows_f32": (C.c_int, [C.POINTER(FifoStepParams), _vp]),
     "moca_fifo_advance_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "moca_fifo_prepare_queue_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "moca_base_set_timestep": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
+    "moca_base_ddim_step_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _i32, _i64, _vp]),
     "moca_mask_frame_sums_f32": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "moca_freq_mix_3d_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "moca_freq_mix_ws_bytes": (_i64, [_i32, _i32, _i32, _i32]),

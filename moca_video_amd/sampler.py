@@ -67,6 +67,8 @@ class DDIMSampler(object):
         self.cfg_mode = "batched"            # "batched": cond+uncond as one B=2 launch; "concurrent": two B=1
                                              # hipGraphs on two streams (UNetModel.forward_concurrent)
         self.beta = 0.9                      # momentum decay (ddim.py:397)
+        self._base_engine = None
+        self.use_graph = True                # `sample`: one hipGraph per DDIM step (fifo_graph.BaseEngine) where the call allows it
         self.share_prefix = True             # the two CFG branches share everything before the first cross-attention (same x, same
                                              # t): computed once (UNetModel.forward_segments(shared_x=True)); False: plain B = 2 batch
 
@@ -168,6 +170,12 @@ class DDIMSampler(object):
             x.numel(), _st()), "moca_ddim_update_f32")
         return x_prev, pred_x0
 
+    def release(self):
+        """free the cached step graph of `sample` (plan buffers + hipGraph)"""
+        if self._base_engine is not None:
+            self._base_engine[1].close()
+            self._base_engine = None
+
     @torch.no_grad()
     def sample(self, S, batch_size, shape, conditioning=None, eta=0., x_T=None, verbose=False,
                unconditional_guidance_scale=1., unconditional_conditioning=None, latents_dir=None, noises=None, **kwargs):
@@ -182,6 +190,27 @@ class DDIMSampler(object):
         total_steps = self.ddim_timesteps.shape[0]
         kwargs.pop("temporal_length", None); kwargs.pop("conditional_guidance_scale_temporal", None)
         fps_kwargs = {}
+        from .fifo_graph import BaseEngine
+        if self.use_graph and self.share_prefix and BaseEngine.supported(self.model, img, conditioning, unconditional_conditioning,
+                                                                         unconditional_guidance_scale):
+            # the loop body as one hipGraph per step (fifo_graph.BaseEngine): latents, schedule and noise stay on the device
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())                  # the host generator seeds the device stream
+            cu, cn = conditioning["c_crossattn"], unconditional_conditioning["c_crossattn"]
+            key = (tuple(img.shape), sum(c.shape[1] for c in cu), sum(c.shape[1] for c in cn), float(unconditional_guidance_scale),
+                   self.ddim_timesteps.tobytes(), np.asarray(self.ddim_sigmas).tobytes(), str(img.device))
+            if self._base_engine is not None and self._base_engine[0] != key:
+                self._base_engine[1].close()
+                self._base_engine = None
+            if self._base_engine is None:
+                self._base_engine = (key, BaseEngine(self.model, self, img, conditioning, unconditional_conditioning,
+                                                     unconditional_guidance_scale, seed=seed))
+            else:
+                self._base_engine[1].reset(img, conditioning, unconditional_conditioning, seed)
+            eng = self._base_engine[1]
+            for i in range(total_steps):
+                eng.step(noise=None if noises is None else noises[i])
+            img = eng.latents().to(img.dtype)
+            time_range = []
         for i, step in enumerate(time_range):
             index = total_steps - i - 1
             ts = torch.full((batch_size,), int(step), device=device, dtype=torch.long)

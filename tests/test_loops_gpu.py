@@ -40,9 +40,10 @@ def _text():
     return {k: inp(n, (1, 77, 128)).cuda() for k, n in (("c1", "loop.ctx1"), ("c2", "loop.ctx2"), ("uc", "loop.uctx"))}
 
 
-def test_hip_base_loop_vs_reference_golden(dm, tmp_path):
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_hip_base_loop_vs_reference_golden(dm, tmp_path, use_graph):
     """base_ddim_sampling -> DDIMSampler.sample (funcs.py:177-241, ddim.py:109-252): 10 steps, eta 1, CFG 12, use_scale, latent
-    cache files, decode -- against the REAL loop's outputs"""
+    cache files, decode -- against the REAL loop's outputs; host-issued steps and one hipGraph per step (fifo_graph.BaseEngine)"""
     from moca_video_amd.fifo import base_ddim_sampling
     g = golden("loop_base")
     t = _text()
@@ -51,13 +52,54 @@ def test_hip_base_loop_vs_reference_golden(dm, tmp_path):
     noises = [inp(f"loop.base.noise_like{i}", shape).cuda() for i in range(10)]
     cond = {"c_crossattn": [t["c1"]], "fps": torch.tensor([10]).cuda()}
     images, sampler, samples = base_ddim_sampling(dm, cond, shape, 10, 1.0, 12.0, uc_emb=t["uc"], latents_dir=str(tmp_path), x_T=x_T,
-                                                  noises=noises)
+                                                  noises=noises, use_graph=use_graph)
     assert torch.equal(torch.load(str(tmp_path / "0.pt")).cpu(), torch.from_numpy(g["pt0"]))
     e = relerr(samples.cpu(), g["samples"])
     assert e < TOL_BASE, f"samples rel err {e:.3e}"
     assert relerr(torch.load(str(tmp_path / "10.pt")).cpu(), g["ptN"]) < TOL_BASE
     e = relerr(images.cpu(), g["images"])
     assert e < TOL_BASE, f"decoded images rel err {e:.3e}"
+
+
+def test_base_step_graph_equals_p_sample_ddim(dm):
+    """fifo_graph.BaseEngine (timestep rows + shared-prefix UNet + guidance + DDIM update in one hipGraph, schedule index taken from
+    the device iteration counter) against DDIMSampler.p_sample_ddim step by step on the same latents and draws, B = 2 prompts; then
+    engine reuse (`reset`) and the device noise stream (same seed -> same latents, next seed -> different)"""
+    from moca_video_amd.fifo_graph import BaseEngine
+    from moca_video_amd.sampler import DDIMSampler
+    t = _text()
+    s = DDIMSampler(dm)
+    s.make_schedule(6, ddim_eta=1.0, verbose=False)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x0 = torch.randn(2, 4, 8, 16, 16, device="cuda", generator=g)
+    fps = torch.tensor([10, 12]).cuda()
+    cond = {"c_crossattn": [torch.cat([t["c1"], t["c2"]])], "fps": fps}
+    uc = {"c_crossattn": [t["uc"].expand(2, -1, -1)], "fps": fps}
+    assert BaseEngine.supported(dm, x0, cond, uc, 12.0)
+    eng = BaseEngine(dm, s, x0, cond, uc, 12.0, seed=5, keep_pred_x0=True)
+    x = x0.clone()
+    worst = 0.0
+    for i in range(6):
+        index = 5 - i
+        n = torch.randn(x.shape, device="cuda", generator=g)
+        ts = torch.full((2,), int(s.ddim_timesteps[index]), device="cuda", dtype=torch.long)
+        x_ref, p_ref = s.p_sample_ddim(x, cond, ts, index=index, unconditional_guidance_scale=12.0, unconditional_conditioning=uc, noise=n)
+        eng.step(noise=n)
+        got = eng.latents()
+        worst = max(worst, relerr(got.cpu(), x_ref.cpu()), relerr(eng.last_pred_x0().cpu(), p_ref.cpu()))
+        x = got                                    # same trajectory for both: per-step comparison, no compounding
+    assert worst < 1e-5, f"graph step vs p_sample_ddim {worst:.3e}"   # same UNet plan kernels; the update differs by fp32 rounding order
+
+    def run(seed):
+        eng.reset(x0, cond, uc, seed)
+        for _ in range(6):
+            eng.step()
+        return eng.latents()
+    a, b, c = run(9), run(9), run(10)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert not torch.equal(a, c)
+    assert eng.plan.graph is not None
+    eng.close()
 
 
 def _fifo_noises(mode):
