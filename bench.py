@@ -493,8 +493,10 @@ def main():
 
     def ddim_step(i, imgs):
         if engines is not None:
+            cur = torch.cuda.current_stream(device)
             for e in engines:
-                e.step()
+                e.step()                                  # (enqueued on the engine's own stream, behind `cur`)
+                cur.wait_stream(e.plan.stream)            # one forward at a time: the per-launch HIP events time a launch, not a queue
             return imgs
         index = S - 1 - (i % S)
         out = []
@@ -604,7 +606,8 @@ def main():
                    "unet_steps_per_step": 2 * n_prompts, "context_tokens": 77, "weights": "random-init, 1.41B params, fp16 packed" +
                    ("" if world == 1 else "; materialised on rank 0 only, RCCL broadcast (C1), checksums all-gathered"),
                    "parallelism": f"dp{world} (independent prompts, no collective in the loop)",
-                   "hipgraph_replay": graph_on, "cfg_mode": args.cfg_mode, "cfg_shared_prefix": sampler.share_prefix and args.cfg_mode == "batched", "step_mode": "graph" if engines is not None else "host", "device": name, "compute_units": cus, "output_finite": finite},
+                   "hipgraph_replay": graph_on, "cfg_mode": args.cfg_mode, "cfg_shared_prefix": sampler.share_prefix and args.cfg_mode == "batched", "step_mode": "graph" if engines is not None else "host", "device": name, "compute_units": cus, "output_finite": finite,
+                   "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
         "achieved_tflops": round(value / world * FLOP_PER_UNET_STEP / 1e12, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic_bytes if not concurrent else None, "traffic_source": traffic_src if not concurrent else None,

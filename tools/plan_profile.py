@@ -46,6 +46,7 @@ rows = collections.OrderedDict()
 tot = 0.0
 flush = torch.empty(1 << 28, dtype=torch.float32, device=dev) if MODE == "cold" else None
 pending = []
+seq_steps = []
 with torch.cuda.stream(st):
     for s in plan.steps:
         fn, kw = s.func.__name__, s.keywords
@@ -83,6 +84,10 @@ with torch.cuda.stream(st):
             key = fn
             flop = 0
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if MODE in ("seq", "seqpf"):      # the forward in order, every launch once per pass (operands as cold / warm as inside the graph),
+            # 3 timed passes; "seqpf": the step's weights are read once (torch sum) right before it -> W in L2 / Infinity Cache
+            seq_steps.append((key, flop, s, s.args[1].w if fn == "gemm" else None))
+            continue
         if MODE == "nosync":              # warm-up + 2 timed replays per step, nothing synchronised until the very end: the chip
             s()                           # never idles (like inside the graph) but every timed launch finds its operands hot
             e0.record(st); s(); s(); e1.record(st)
@@ -113,17 +118,30 @@ with torch.cuda.stream(st):
         r[0] += 1
         r[1] += us
         tot += us
+if seq_steps:
+    with torch.cuda.stream(st):
+        for it in range(4):
+            for key, flop, s, w in seq_steps:
+                if MODE == "seqpf" and w is not None:
+                    w.sum()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st); s(); e1.record(st)
+                if it > 0:
+                    pending.append((key, flop / 1.5, e0, e1))     # (3 timed passes; the summary below divides by 2)
+    torch.cuda.synchronize()
+    seq_n = 3
 ops.set_stream(None)
 if pending:
     torch.cuda.synchronize()
     for key, flop, e0, e1 in pending:
-        us = e0.elapsed_time(e1) * 1e3 / 2
-        r = rows.setdefault(key, [0, 0.0, flop])
-        r[0] += 1
+        us = e0.elapsed_time(e1) * 1e3 / (3 if seq_steps else 2)
+        r = rows.setdefault(key, [0, 0.0, flop * (1.5 if seq_steps else 1.0)])
+        r[0] += (1.0 / 3 if seq_steps else 1)
         r[1] += us
         tot += us
 print(f"# B={B}{' (shared CFG prefix)' if SHARED else ''}, mode {MODE}: {len(plan.steps)} steps, sum of isolated step times {tot / 1e3:.2f} ms")
 print(f"{'total_us':>9s} {'n':>3s} {'each_us':>8s} {'TF/s':>6s}  step")
 for key, (n, us, flop) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
     tf = flop * n / us / 1e6 if flop else 0.0
+    n = int(round(n))
     print(f"{us:9.1f} {n:3d} {us / n:8.1f} {tf:6.0f}  {key}")
