@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void attention_short_kernel(
 //   * P is packed with v_cvt_pk_f16_f32 only; LDS fragment addresses are per-lane constants + immediates (key loop
 //     unrolled over the two buffers); the staging pointers advance by one 64-bit add per tile.
 // What is left per element: 0.5 max3 + exp + 0.5 cvt_pk + 0.5 dot2.  121 VGPRs: four waves per SIMD.  Tiles, LDS images and fragment maps are those of attention_kernel.
-constexpr float LAZY_THR = 8.0f;
+[[maybe_unused]] constexpr float LAZY_THR = 8.0f;
 
 // NW wavefronts (32 queries each) share every K/V tile: 4 (128 queries per block), or 8 (256 queries: half the LDS-DMA and L2 -> LDS
 // traffic per query, one piece of K and one of V per wave and tile; the barrier spans 8 waves)

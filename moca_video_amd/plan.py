@@ -13,7 +13,6 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
-import os
 import warnings
 
 import torch
@@ -122,7 +121,7 @@ class _PlanBase:
         if splits > 1:
             ws = self.pool.get(splits * M, pw.N, torch.float32)
         cs = None
-        if want_colsum and os.environ.get("MOCA_GN_COLSUM", "1") != "0":     # (0: A/B runs against the three-launch GroupNorm)
+        if want_colsum:
             rows = ops.gemm_colsum_rows(a, pw, M=M, splits=splits, **kw)
             if rows > 0:
                 cs = (self.pool.get((M + rows - 1) // rows, 2 * pw.N, torch.float32), rows)
@@ -163,7 +162,7 @@ class _PlanBase:
         if fm.gstat is not None and fm.gstat[1] == fps:       # (the concat that produced fm accumulated the statistics)
             self._emit(ops.groupnorm_gstat, fm.buf, y, gb[0], gb[1], fm.gstat[0], F=fm.F, HW=HW, Cn=fm.C, frames_per_stat=fps,
                        eps=eps, silu=silu)
-        elif cs is not None and (fps * HW) % cs[1] == 0 and fm.src is not None and os.environ.get("MOCA_GN_GSTAT", "1") != "0":
+        elif cs is not None and (fps * HW) % cs[1] == 0 and fm.src is not None:
             # the producer is re-targeted: instead of per-tile column sums it accumulates the FINISHED statistics of this
             # GroupNorm (fixed-point atomics per (statistics group, channel group), MOCA_EP_GSTAT) -- no finalize launch
             prod = self.steps[fm.src]
@@ -374,14 +373,10 @@ class _Plan(_PlanBase):
     def _attn_temporal_fused(self, att, l, M, Cn, heads, HW, norm):
         """q|k|v projection + attention over the frame axis in ONE launch (MOCA_EP_TATTN) where its 320-row tiles (16 frames x 20
         pixels, one head) come in whole rounds of the chip; None -> the caller runs projection + temporal_attention.
-        MOCA_TATTN: 0 = never, 1 = only where the tile count is a multiple of 256 or >= 1024, 2 (default) = wherever the kernel applies
-        (same-device A/B of the whole CFG step: 37.2 / 36.4 / 36.0 ms -- the launch and the q|k|v round trip it removes outweigh the
-        partial last round of tiles at the 640- and 1280-channel levels)."""
-        mode = int(os.environ.get("MOCA_TATTN", "2"))
-        if mode == 0 or self.T != 16 or HW % 20:
-            return None
-        tiles = (M // 320) * heads
-        if mode == 1 and not (tiles % 256 == 0 or tiles >= 1024):
+        Used wherever the kernel applies (round-2 same-device A/B of the whole CFG step: never 37.2 ms, only where the tile count is a
+        multiple of 256 or >= 1024 36.4, everywhere 36.0 -- the launch and the q|k|v round trip it removes outweigh the partial last
+        round of tiles at the 640- and 1280-channel levels)."""
+        if self.T != 16 or HW % 20:
             return None
         folded = isinstance(l, _LNRef)
         x = l.x if folded else l
@@ -450,22 +445,16 @@ class _Plan(_PlanBase):
         followed by the LayerNorm kernel."""
         lda = a.stride(-2)
         splits = self._splits(M, pw)
-        ln_epilogue = os.environ.get("MOCA_GEMM_LN", "1") != "0" and \
-            ops.gemm_ln_ok(a, pw, M=M, lda=lda, residual=residual, splits=splits, ln=(gb[0], gb[1], None, 1e-5))
+        ln_epilogue = ops.gemm_ln_ok(a, pw, M=M, lda=lda, residual=residual, splits=splits, ln=(gb[0], gb[1], None, 1e-5))
         # Measured (same device, whole CFG step, tools/ab_run7.sh): fold wherever possible 36.9 ms, fold only where neither the
         # LayerNorm store loop (N = 320) nor more than two row partials apply 37.3, never 37.6.  In isolation the consumers pay
         # 3-12 % for the two FMAs per accumulator and the statistics loads (tools/bench_lnfold.py; worst at K = 320 and with the
         # 10 partials of the 1280-channel level), less than the LayerNorm pass and the second output they replace cost in the
-        # graph.  MOCA_LN_FOLD: 0 = never, 1 = only where there is no LayerNorm store loop and <= 2 partials, 2 (default) = wherever
-        # producer and consumer kernels allow.
-        fold_mode = int(os.environ.get("MOCA_LN_FOLD", "2"))
-        fold_set = os.environ.get("MOCA_LN_FOLD_SET")            # (A/B runs: the channel counts the fold may run at)
-        if fold_set is not None:
-            fold_mode = 2 if str(pw.N) in fold_set.split(",") else 0
-        if consumer is not None and fold_mode != 0 and splits == 1 and (fold_mode == 2 or not ln_epilogue):
+        # graph.  So: fold wherever producer and consumer kernels allow.
+        if consumer is not None and splits == 1:
             cols = ops.gemm_rowsum_cols(a, pw, M=M, lda=lda, residual=residual, splits=1, rowsum=True)
             nparts = pw.N // cols if cols > 0 else 0
-            if cols > 0 and (fold_mode == 2 or nparts <= 2):
+            if cols > 0:
                 pwf = consumer()
                 if ops.gemm_lnfold_ok(a, pwf, M=M, lda=pw.N, splits=self._splits(M, pwf), lnfold=(None, nparts, 1e-5)) and \
                         self._splits(M, pwf) == 1:
@@ -617,8 +606,7 @@ class _Plan(_PlanBase):
             cat = self.pool.get(h.M, h.C + skip.C)
             gst = None
             Cc = h.C + skip.C
-            if os.environ.get("MOCA_GN_GSTAT", "1") != "0" and os.environ.get("MOCA_CAT_GSTAT", "1") != "0" and \
-                    isinstance(module[0], _ResBlock) and Cc % 32 == 0 and \
+            if isinstance(module[0], _ResBlock) and Cc % 32 == 0 and \
                     64 <= (Cc // 8) * max(1, 256 // (Cc // 8)) and Cc // 8 <= 1024:
                 # torch.cat(dim=1), :571, leaving the statistics of ResBlock.in_layers[0] (per-frame GroupNorm) behind
                 gst = (self._gstat_slot(h.F * 64), 1)
