@@ -33,9 +33,11 @@ a2 = torch.zeros(256 * 256, device=DEV)
 print(f"torch add_ on 64 Ki floats (256 blocks)     {per_node(lambda: a2.add_(1.0)):6.2f} us per node")
 a3 = torch.zeros(16 << 20, device=DEV)
 print(f"torch add_ on 16 Mi floats (128 MB traffic) {per_node(lambda: a3.add_(1.0)):6.2f} us per node")
-for M, N_, K in ((256, 128, 64), (5120, 1280, 64), (5120, 1280, 320), (5120, 1280, 1280), (5120, 1280, 2560)):
+for M, N_, K in ((256, 128, 64), (5120, 1280, 64), (5120, 1280, 320), (5120, 1280, 1280), (5120, 1280, 2560), (20480, 640, 640), (81920, 320, 320), (81920, 320, 1280)):
     x = torch.randn(M, K, device=DEV).half()
     pw = ops.pack_linear(torch.randn(N_, K, device=DEV) * K ** -0.5, torch.zeros(N_, device=DEV))
     out = torch.empty(M, pw.N, device=DEV, dtype=torch.float16)
     us = per_node(lambda: ops.gemm(x, pw, out, M=M))
-    print(f"gemm lin M={M} N={N_} K={K}: {us:6.2f} us per node ({2.0 * M * N_ * K / us / 1e6:5.0f} TF/s)")
+    res = torch.randn(M, pw.N, device=DEV).half()
+    us_r = per_node(lambda: ops.gemm(x, pw, out, M=M, residual=res))
+    print(f"gemm lin M={M} N={N_} K={K}: {us:6.2f} us per node ({2.0 * M * N_ * K / us / 1e6:5.0f} TF/s); + residual {us_r:6.2f} us")
