@@ -119,7 +119,11 @@ typedef struct moca_gemm_params {
     int32_t     gstat_rows;/* rows per statistics group (frames_per_stat * H*W of the consumer's GroupNorm)             */
     float       tattn_scale;/* MOCA_EP_TATTN: softmax scale (dim_head ** -0.5); frames / pixels per frame in T / HW     */
     void*       reserved5_;
-    int32_t     reserved6_;
+    int32_t     up_phase;  /* MOCA_A_CONV3X3 only.  0: the 3x3 conv.  1 + 2a + b (a, b in {0, 1}): phase (a, b) of `Upsample` =
+                              F.interpolate(nearest, x2) + conv3x3 (openaimodel3d.py:96-106) as a 2 x 2 conv on the LOW-resolution grid:
+                              out[f][2i+a][2j+b] = bias + sum_{r,s in {0,1}} Wp[r][s] . in[f][i+a-1+r][j+b-1+s], Wp = the 3x3 taps that
+                              land on the same input pixel, summed (ops.pack_upconv_phases); K = 4 C, inH x inW = outH x outW = the
+                              low-resolution grid, `out` = the [F][2H][2W][N] tensor (rows scattered by the kernel); 4/9 of the FLOPs */
     int32_t     reserved4_;
 } moca_gemm_params;
 

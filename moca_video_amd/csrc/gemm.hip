@@ -474,8 +474,8 @@ struct AGather {
                 oy = rem / p.outW; ox = rem - oy * p.outW;
             }
             row_off[g] = (int64_t)f * p.inH * p.inW;
-            row_y[g] = oy * p.stride - 1 + p.nopad_lo;
-            row_x[g] = ox * p.stride - 1 + p.nopad_lo;
+            row_y[g] = oy * p.stride - 1 + p.nopad_lo + (p.up_phase ? (p.up_phase - 1) >> 1 : 0);
+            row_x[g] = ox * p.stride - 1 + p.nopad_lo + (p.up_phase ? (p.up_phase - 1) & 1 : 0);
         } else {
             int frame, pix, vid, t;
             if (p.M < (1 << 24)) {
@@ -496,12 +496,13 @@ struct AGather {
 #pragma unroll
             for (int g = 0; g < NAP; ++g) a_base[g] = row_ok[g] ? Aptr + row_off[g] + lch * 8 : zero;
         } else if (AMODE == MOCA_A_CONV3X3) {
-            const int ky = tap / 3, kx = tap - ky * 3;
+            // (up_phase: one of the four 2 x 2 convs a nearest-x2 upsample + 3 x 3 conv splits into -- tap t = (t >> 1, t & 1))
+            const int ky = p.up_phase ? tap >> 1 : tap / 3, kx = p.up_phase ? tap & 1 : tap - ky * 3;
             const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
 #pragma unroll
             for (int g = 0; g < NAP; ++g) {
                 int iy = row_y[g] + ky, ix = row_x[g] + kx;
-                const bool ok = tap < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+                const bool ok = tap < (p.up_phase ? 4 : 9) && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
                 if (p.up) { iy >>= 1; ix >>= 1; }
                 const half_t* src = Aptr + (row_off[g] + (int64_t)iy * p.inW + ix) * p.C + lch * 8;
                 a_base[g] = ok ? src : zero;
@@ -595,8 +596,8 @@ struct BGather {
                 oy = rem / p.outW; ox = rem - oy * p.outW;
             }
             row_off[g] = (int64_t)f * p.inH * p.inW;
-            row_y[g] = oy * p.stride - 1 + p.nopad_lo;
-            row_x[g] = ox * p.stride - 1 + p.nopad_lo;
+            row_y[g] = oy * p.stride - 1 + p.nopad_lo + (p.up_phase ? (p.up_phase - 1) >> 1 : 0);
+            row_x[g] = ox * p.stride - 1 + p.nopad_lo + (p.up_phase ? (p.up_phase - 1) & 1 : 0);
         } else {
             int frame, pix, vid, t;
             if (p.M < (1 << 24)) {
@@ -617,12 +618,12 @@ struct BGather {
 #pragma unroll
             for (int g = 0; g < NAP; ++g) a_off[g] = row_ok[g] ? (unsigned)((row_off[g] + lch * 8) * 2) : OOB_OFF;
         } else if (AMODE == MOCA_A_CONV3X3) {
-            const int ky = t / 3, kx = t - ky * 3;
+            const int ky = p.up_phase ? t >> 1 : t / 3, kx = p.up_phase ? t & 1 : t - ky * 3;      // (up_phase: see AGather::set_tap)
             const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
 #pragma unroll
             for (int g = 0; g < NAP; ++g) {
                 int iy = row_y[g] + ky, ix = row_x[g] + kx;
-                const bool ok = t < 9 && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
+                const bool ok = t < (p.up_phase ? 4 : 9) && row_ok[g] && iy >= 0 && iy < limH && ix >= 0 && ix < limW;
                 if (p.up) { iy >>= 1; ix >>= 1; }
                 a_off[g] = ok ? (unsigned)(((row_off[g] + (int64_t)iy * p.inW + ix) * p.C + lch * 8) * 2) : OOB_OFF;
             }
@@ -665,11 +666,15 @@ __device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
     const int chunks_per_row = out_bn / 8;
     const int total_chunks = rows * chunks_per_row;
+    // up_phase (a, b): GEMM row m = pixel (f, i, j) of the low-resolution grid is output pixel (f, 2i + a, 2j + b) of the upsampled one:
+    // row 4 m - 2 (m mod W) + 2 W a + b
+    const int upW = p.up_phase ? p.outW : 0, upC = p.up_phase ? 2 * p.outW * ((p.up_phase - 1) >> 1) + ((p.up_phase - 1) & 1) : 0;
     for (int idx = tid; idx < total_chunks; idx += NTHREADS) {
         const int row = idx / chunks_per_row, ch = idx - row * chunks_per_row;
         const int m = m0 + row;
         if (m >= p.M) continue;
         const int col = on0 + ch * 8;
+        const int64_t mo = upW ? 4 * (int64_t)m - 2 * (m % upW) + upC : m;
         half8v h = *reinterpret_cast<const half8v*>(stage + row * pitch + ch * 16);
         if (rowadd || resid) {
             float v[8];
@@ -688,7 +693,7 @@ __device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const
 #pragma unroll
             for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
         }
-        *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
+        *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + mo * p.ldo + col) = h;
     }
 }
 
@@ -2180,12 +2185,19 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     // the plain-GELU epilogue (CLIP text MLP) exists in the 128-row kernel only
     if ((p.flags & MOCA_EP_GELU) && (geglu || p.splits != 1 || !((p.flags & MOCA_FORCE_SMALL_TILE) || p.M <= 128))) return MOCA_E_BADARG;
     normalise_splits(p);
+    if (p.up_phase && p.a_mode != MOCA_A_CONV3X3) return MOCA_E_BADARG;
     switch (p.a_mode) {
         case MOCA_A_LINEAR:
             if (p.lda % 8 || p.lda < p.K) return MOCA_E_BADARG;
             break;
         case MOCA_A_CONV3X3:
-            if (p.C % 8 || p.K != 9 * p.C || p.inH <= 0 || p.inW <= 0 || p.outH <= 0 || p.outW <= 0) return MOCA_E_BADARG;
+            if (p.up_phase < 0 || p.up_phase > 4) return MOCA_E_BADARG;
+            if (p.C % 8 || p.K != (p.up_phase ? 4 : 9) * p.C || p.inH <= 0 || p.inW <= 0 || p.outH <= 0 || p.outW <= 0) return MOCA_E_BADARG;
+            // one phase of upsample + conv: a 2 x 2 conv on the low-resolution grid, rows scattered by the plain store loop of the
+            // 256- / 320-row kernels (fast gather), nothing else in the epilogue
+            if (p.up_phase && (p.stride != 1 || p.up || p.nopad_lo || p.splits != 1 || p.M <= 160 || !fast_gather(p) || p.residual || p.rowadd ||
+                               (p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_GSTAT | MOCA_EP_ROWSUM | MOCA_EP_LN | MOCA_EP_LNFOLD |
+                                          MOCA_EP_TATTN | MOCA_EP_GELU | MOCA_FORCE_SMALL_TILE)) || (p.N % 128 && p.N % 160))) return MOCA_E_BADARG;
             if (p.stride != 1 && p.stride != 2) return MOCA_E_BADARG;
             if (p.nopad_lo != 0 && (p.nopad_lo != 1 || p.stride != 2 || p.up || (p.inH | p.inW) & 1)) return MOCA_E_BADARG;
             if (p.up && (p.stride != 1 || p.outH != 2 * p.inH || p.outW != 2 * p.inW)) return MOCA_E_BADARG;

@@ -48,7 +48,7 @@ class GemmParams(C.Structure):
         ("rowsum", C.c_void_p), ("lnf_part", C.c_void_p), ("lnf_wsum", C.c_void_p),
         ("lnf_nparts", C.c_int32), ("reserved2_", C.c_int32),
         ("gstat", C.c_void_p), ("gstat_rows", C.c_int32), ("tattn_scale", C.c_float),
-        ("reserved5_", C.c_void_p), ("reserved6_", C.c_int32), ("reserved4_", C.c_int32),
+        ("reserved5_", C.c_void_p), ("up_phase", C.c_int32), ("reserved4_", C.c_int32),
     ]
 
 

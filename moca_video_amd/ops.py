@@ -85,6 +85,29 @@ def pack_conv3x3(weight, bias=None, cpad=None, device="cuda"):
     return _finish(w.reshape(n, 9 * cpad), bias, device)
 
 
+def pack_upconv_phases(weight, bias=None, device="cuda"):
+    """`Upsample` = nearest x2 + conv3x3 (openaimodel3d.py:96-106) as four 2 x 2 convs on the low-resolution grid, one per output
+    parity (a, b): output pixel (2i+a, 2j+b) reads upsampled rows 2i+a-1 .. 2i+a+1 = input rows {i-1, i, i} (a = 0) or {i, i, i+1}
+    (a = 1), so the 3x3 taps that fall on the same input pixel are SUMMED (in fp32, then rounded to fp16 like every weight): tap r of
+    phase a covers ky in ((0,), (1, 2)) for a = 0 and ((0, 1), (2,)) for a = 1, the same along x.  The zero padding of the upsampled
+    image coincides with the zero padding of the input (a summed pair never straddles the border).  Returns the four PackedWeights
+    [N][(r, s, c)] in phase order 1 + 2a + b; 4/9 of the multiply-adds of the 3x3 conv on the upsampled image."""
+    n, c = weight.shape[0], weight.shape[1]
+    w32 = weight.detach().to(torch.float32)
+    rows = (((0,), (1, 2)), ((0, 1), (2,)))
+    out = []
+    for a in range(2):
+        for b in range(2):
+            w = torch.zeros(n, 2, 2, c, dtype=torch.float32, device=weight.device)
+            for r in range(2):
+                for s_ in range(2):
+                    for ky in rows[a][r]:
+                        for kx in rows[b][s_]:
+                            w[:, r, s_, :] += w32[:, :, ky, kx]
+            out.append(_finish(w.reshape(n, 4 * c), bias, device))
+    return out
+
+
 def pack_conv1x1(weight, bias=None, device="cuda"):
     return _finish(weight.reshape(weight.shape[0], weight.shape[1]), bias, device)
 
@@ -132,8 +155,9 @@ def finish_lnfold(pw: PackedWeight) -> PackedWeight:
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
                  residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None,
-                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None):
+                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, up_phase=0):
     p = _l.GemmParams()
+    p.up_phase = up_phase
     p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), (out.data_ptr() if out is not None else None)
     p.bias = pw.bias.data_ptr() if pw.bias is not None else None
     p.rowadd = rowadd.data_ptr() if rowadd is not None else None

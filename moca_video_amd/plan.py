@@ -147,6 +147,21 @@ class _PlanBase:
                              rowadd=rowadd, rowadd_div=rowadd_div, residual=residual, want_colsum=True)
         return _FMap(out, fm.F, oH, oW, pw.N, cs, src=self._last_gemm_step if cs is not None else None)
 
+    def upconv(self, fm, conv):
+        """`Upsample` (openaimodel3d.py:96-106: nearest x2, then conv3x3).  With enough low-resolution rows to fill the chip per
+        launch: four 2 x 2 convs on the low-resolution grid, one per output parity, each writing its quarter of the pixels (4/9 of
+        the FLOPs: the 3x3 taps that read the same input pixel are summed at pack time).  Otherwise the 3x3 conv whose gather
+        reads in[y // 2][x // 2]."""
+        phases = self.P.get(("up_phases", id(conv)))
+        M = fm.F * fm.H * fm.W
+        if phases is None or M < 5120 or self._splits(M, phases[0]) != 1:       # (below: split-k per phase costs more than it saves)
+            return self.conv(fm, self.P[id(conv)], up=1)
+        out = self.pool.get(4 * M, phases[0].N)
+        for ph, pw in enumerate(phases):
+            self._emit(ops.gemm, fm.buf, pw, out, M=M, mode=_l.MOCA_A_CONV3X3, conv=(fm.C, fm.H, fm.W, fm.H, fm.W, 1, 0), splits=1,
+                       up_phase=ph + 1)
+        return _FMap(out, fm.F, fm.H * 2, fm.W * 2, phases[0].N, None)
+
     def tconv(self, fm, pw, residual=None):
         out, cs = self._gemm(fm.buf, pw, fm.M, mode=_l.MOCA_A_TCONV3, tconv=(fm.C, self.T, fm.H * fm.W), residual=residual,
                              want_colsum=True)
@@ -537,7 +552,7 @@ class _Plan(_PlanBase):
             elif isinstance(layer, _Downsample):
                 nh = self.conv(h, self.P[id(layer.op)], stride=2)
             elif isinstance(layer, _Upsample):
-                nh = self.conv(h, self.P[id(layer.conv)], up=1)
+                nh = self.upconv(h, layer.conv)
             else:
                 raise TypeError(type(layer))
             self._release(h.buf)

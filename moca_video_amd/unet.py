@@ -241,6 +241,8 @@ def pack_tree(root, dev):
             P[id(mod.op)] = ops.pack_conv3x3(mod.op.weight.detach(), mod.op.bias.detach(), device=dev)
         elif isinstance(mod, _Upsample):
             P[id(mod.conv)] = ops.pack_conv3x3(mod.conv.weight.detach(), mod.conv.bias.detach(), device=dev)
+            if mod.conv.weight.shape[1] % 64 == 0:          # the four 2 x 2 phase convs (ops.pack_upconv_phases), used where they pay
+                P[("up_phases", id(mod.conv))] = ops.pack_upconv_phases(mod.conv.weight.detach(), mod.conv.bias.detach(), device=dev)
     res = [m for m in root.modules() if isinstance(m, _ResBlock)]
     emb_cols, off = {}, 0
     for m in res:

@@ -416,6 +416,29 @@ def test_gemm_random_sweep_forced_kernels(kernel, env, tune):
         check(out[:, :N], ref, TOL16, f"{kernel} case {ci}: {mode} M={M} N={N} K={K} splits={splits} res={with_res}")
 
 
+# ---------------------------------------------------------------- Upsample as four 2x2 phase convs
+@pytest.mark.parametrize("Fr,H,W,C,N", [(32, 10, 16, 1280, 1280),      # the 1280-channel Upsample of the B=2 forward (256-row kernel)
+                                        (8, 20, 32, 640, 640),         # 640 channels (320 x 160 tiles)
+                                        (3, 7, 9, 64, 320), (5, 6, 11, 128, 256)])   # odd grids, M tails
+def test_gemm_upconv_phases(Fr, H, W, C, N):
+    """nearest x2 + conv3x3 (openaimodel3d.py:96-106) as four 2x2 convs on the low-resolution grid with pre-summed taps
+    (ops.pack_upconv_phases, moca_gemm_params.up_phase): against F.interpolate + F.conv2d in fp32 AND against the 3x3 kernel with
+    the `up` gather (same sums in another order: the weight pairs are rounded to fp16 after the addition instead of before)"""
+    x = rnd(Fr, C, H, W)
+    w, b = rnd(N, C, 3, 3, scale=(9 * C) ** -0.5), rnd(N, dtype=torch.float32)
+    a = nhwc(x).reshape(Fr * H * W, C)
+    M = Fr * H * W
+    out = torch.full((4 * M, N), float("nan"), dtype=torch.float16, device=DEV)
+    for ph, pw in enumerate(ops.pack_upconv_phases(w, b)):
+        ops.gemm(a, pw, out, M=M, mode=L.MOCA_A_CONV3X3, conv=(C, H, W, H, W, 1, 0), up_phase=ph + 1)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2, mode="nearest"), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(4 * M, N)
+    assert torch.isfinite(out).all(), "a phase left output pixels unwritten"
+    check(out, ref, TOL16, f"upsample phases {Fr}x{H}x{W} C={C} N={N}")
+    one = torch.empty_like(out)
+    ops.gemm(a, ops.pack_conv3x3(w, b), one, M=4 * M, mode=L.MOCA_A_CONV3X3, conv=(C, H, W, 2 * H, 2 * W, 1, 1))
+    check(out, one.float(), TOL16, "phases vs the 3x3 conv with the upsampling gather")
+
+
 # ---------------------------------------------------------------- CLIP text tower kernels
 @pytest.mark.parametrize("B,heads,N", [(1, 16, 77), (2, 2, 77), (1, 4, 200)])
 def test_attention_causal(B, heads, N):
