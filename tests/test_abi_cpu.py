@@ -170,3 +170,25 @@ def test_split_k_factors_cpu():
     assert gemm_splits(1280, pw(1280, 11520)) == 5         # the 3x3 convs want every CU
     assert gemm_splits(81920, pw(320, 320)) == 1
     assert gemm_splits(5120, pw(1280, 1280)) == 1
+
+
+def test_upsample_phase_algebra_cpu():
+    """ops.pack_upconv_phases (host side of moca_gemm_params.up_phase): nearest x2 + conv3x3 (openaimodel3d.py:96-106) == four 2 x 2
+    convs on the low-resolution grid, phase (a, b) producing output pixels (2i + a, 2j + b) from input pixels (i + a - 1 + r,
+    j + b - 1 + s), r, s in {0, 1}, with zero padding -- restated with F.conv2d on the CPU from the PACKED rows [N][(r, s, c)]."""
+    import torch.nn.functional as F
+    from moca_video_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 8, 5, 7, generator=g)
+    w = (torch.randn(64, 8, 3, 3, generator=g) * 0.2).half().float()      # fp16-representable weights, fp32 sums stay exact enough
+    b = torch.randn(64, generator=g)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+    phases = ops.pack_upconv_phases(w, b, device="cpu")
+    assert len(phases) == 4 and all(p.K == 32 and p.N == 64 for p in phases)
+    out = torch.zeros_like(ref)
+    for ph, pw in enumerate(phases):
+        a, bb = ph >> 1, ph & 1
+        k = pw.w[:64, :32].float().view(64, 2, 2, 8).permute(0, 3, 1, 2)   # [N][C][r][s]
+        xp = F.pad(x, (1 - bb, bb, 1 - a, a))                              # input rows i + a - 1 .. i + a, columns j + b - 1 .. j + b
+        out[:, :, a::2, bb::2] = F.conv2d(xp, k, pw.bias[:64])
+    assert (out - ref).abs().max() < 2e-3 * ref.abs().max()                # (the summed weight pairs are rounded to fp16 once)
