@@ -95,6 +95,9 @@ def broadcast_and_verify(module, device, world, rank):
     raises (non-zero exit on every rank) when a rank's weights differ."""
     import torch.distributed as tdist
     from moca_video_amd import dist as mdist
+    if not tdist.is_initialized():                                # (one process, no launcher: nothing to prove)
+        return {"rccl_ranks": 1, "backend": None, "broadcast_bytes": 0, "broadcast_s": 0.0, "broadcast_GBps_per_receiver": None,
+                "param_checksums_equal": True, "param_checksum_rank0": [float(v) for v in param_checksum(module)]}
     sync = (lambda: torch.cuda.synchronize(device)) if device.type == "cuda" else (lambda: None)
     mdist.barrier(); sync()
     t0 = time.perf_counter()
