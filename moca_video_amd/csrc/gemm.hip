@@ -659,6 +659,13 @@ struct BGather {
 
 // ---- epilogue stage 2 of the direct-to-LDS kernels: the fp16 tile staged in LDS (`rows` x `out_bn`, row pitch `pitch` bytes)
 //      leaves as 16-byte coalesced stores; the time-embedding row add and the residual are added in fp32 on the way ----
+// Row-add / residual operands of the store loops are fetched several chunks AHEAD of the stores.  `out` may alias `residual`, so the
+// compiler keeps every load behind the previous iteration's store, and each 16-byte chunk paid a global-load round trip plus the store
+// drain (`s_waitcnt vmcnt(0)`).  With operands served by the Infinity Cache (B = 2 forward) that costs nothing measurable; from HBM
+// (B = 16: the FIFO iteration, configs[4]) the +residual linears run 3.5-9 % faster with the operands in flight together
+// (tools/bench_gemm.py "linear+res", BG_B=16).  A thread only ever reads the addresses it writes itself.
+constexpr int EPI_U = 8;
+
 template <int NTHREADS>
 __device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const char* stage, int pitch, int rows, int out_bn,
                                                 int m0, int on0, int tid) {
@@ -666,34 +673,53 @@ __device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
     const int chunks_per_row = out_bn / 8;
     const int total_chunks = rows * chunks_per_row;
-    // up_phase (a, b): GEMM row m = pixel (f, i, j) of the low-resolution grid is output pixel (f, 2i + a, 2j + b) of the upsampled one:
-    // row 4 m - 2 (m mod W) + 2 W a + b
-    const int upW = p.up_phase ? p.outW : 0, upC = p.up_phase ? 2 * p.outW * ((p.up_phase - 1) >> 1) + ((p.up_phase - 1) & 1) : 0;
-    for (int idx = tid; idx < total_chunks; idx += NTHREADS) {
-        const int row = idx / chunks_per_row, ch = idx - row * chunks_per_row;
-        const int m = m0 + row;
-        if (m >= p.M) continue;
-        const int col = on0 + ch * 8;
-        const int64_t mo = upW ? 4 * (int64_t)m - 2 * (m % upW) + upC : m;
-        half8v h = *reinterpret_cast<const half8v*>(stage + row * pitch + ch * 16);
-        if (rowadd || resid) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
-            if (rowadd) {
-                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-            }
-            if (resid) {
-                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+    if (!rowadd && !resid) {
+        // up_phase (a, b): GEMM row m = pixel (f, i, j) of the low-resolution grid is output pixel (f, 2i + a, 2j + b) of the upsampled
+        // one: row 4 m - 2 (m mod W) + 2 W a + b
+        const int upW = p.up_phase ? p.outW : 0, upC = p.up_phase ? 2 * p.outW * ((p.up_phase - 1) >> 1) + ((p.up_phase - 1) & 1) : 0;
+        for (int idx = tid; idx < total_chunks; idx += NTHREADS) {
+            const int row = idx / chunks_per_row, ch = idx - row * chunks_per_row;
+            const int m = m0 + row;
+            if (m >= p.M) continue;
+            const int64_t mo = upW ? 4 * (int64_t)m - 2 * (m % upW) + upC : m;
+            *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + mo * p.ldo + on0 + ch * 8) =
+                *reinterpret_cast<const half8v*>(stage + row * pitch + ch * 16);
         }
-        *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + mo * p.ldo + col) = h;
+        return;
+    }
+    const half8v zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int base = tid; base < total_chunks; base += EPI_U * NTHREADS) {
+        half8v ea[EPI_U], er[EPI_U];
+        int soff[EPI_U];
+        int64_t ooff[EPI_U];
+        bool ok[EPI_U];
+#pragma unroll
+        for (int u = 0; u < EPI_U; ++u) {
+            const int idx = base + u * NTHREADS;
+            const int row = idx / chunks_per_row, ch = idx - row * chunks_per_row;
+            const int m = m0 + row, col = on0 + ch * 8;
+            ok[u] = idx < total_chunks && m < p.M;
+            soff[u] = row * pitch + ch * 16;
+            ooff[u] = (int64_t)m * p.ldo + col;
+            ea[u] = zero8; er[u] = zero8;
+            if (ok[u]) {
+                if (rowadd) ea[u] = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+                if (resid) er[u] = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EPI_U; ++u) {
+            if (!ok[u]) continue;
+            half8v h = *reinterpret_cast<const half8v*>(stage + soff[u]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                     // (same order as ever: + row add, then + residual, in fp32)
+                float v = (float)h[j];
+                if (rowadd) v += (float)ea[u][j];
+                if (resid) v += (float)er[u][j];
+                h[j] = (half_t)v;
+            }
+            *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + ooff[u]) = h;
+        }
     }
 }
 
@@ -715,27 +741,36 @@ __device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
     if (rs < RS) {
         const int col = n0 + ch * 8;
-        for (int row = rs; row < ROWS; row += RS) {
-            const int m = m0 + row;
-            if (m >= p.M) break;
-            const half8v h = *reinterpret_cast<const half8v*>(stage + row * pitch + ch * 16);
-            float v[8];
+        const half8v zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        constexpr int U = 4;                                       // operands fetched U rows ahead of the stores (see store_fp16_tile)
+        for (int row0 = rs; row0 < ROWS && m0 + row0 < p.M; row0 += U * RS) {
+            half8v ea[U], er[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
-            if (rowadd) {
-                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            for (int u = 0; u < U; ++u) {
+                const int row = row0 + u * RS, m = m0 + row;
+                ea[u] = zero8; er[u] = zero8;
+                if (row < ROWS && m < p.M) {
+                    if (rowadd) ea[u] = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+                    if (resid) er[u] = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+                }
             }
-            if (resid) {
-                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            for (int u = 0; u < U; ++u) {
+                const int row = row0 + u * RS, m = m0 + row;
+                if (row >= ROWS || m >= p.M) break;
+                const half8v h = *reinterpret_cast<const half8v*>(stage + row * pitch + ch * 16);
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = (float)h[j];
+                    if (rowadd) v[j] += (float)ea[u][j];
+                    if (resid) v[j] += (float)er[u][j];
+                }
+                half8v o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o[j] = (half_t)v[j]; s[j] += v[j]; q[j] += v[j] * v[j]; }
+                *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = o;
             }
-            half8v o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { o[j] = (half_t)v[j]; s[j] += v[j]; q[j] += v[j] * v[j]; }
-            *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = o;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) { red[(rs * BNC + ch * 8 + j) * 2] = s[j]; red[(rs * BNC + ch * 8 + j) * 2 + 1] = q[j]; }
@@ -860,30 +895,39 @@ __device__ __forceinline__ void store_fp16_tile_rowsum(const moca_gemm_params& p
     const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
     const int l = tid % LPR, rsub = tid / LPR;
     float* dst = p.rowsum + (int64_t)(n0 / BNC) * p.M * 2;
-    for (int row = rsub; row < rows; row += NTHREADS / LPR) {
+    const half8v zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int RSTEP = NTHREADS / LPR;
+    half8v ea[CPL], er[CPL], na[CPL], nr[CPL];           // operands of this row pass / of the next one, fetched a pass ahead of the
+    auto fetch = [&](int row, half8v* fa, half8v* fr) {  // stores (see store_fp16_tile)
+        const int m = m0 + row;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int col = (l + LPR * c) * 8;
+            fa[c] = zero8; fr[c] = zero8;
+            if (row < rows && m < p.M) {
+                if (rowadd) fa[c] = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + n0 + col);
+                if (resid) fr[c] = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + n0 + col);
+            }
+        }
+    };
+    if (rowadd || resid) fetch(rsub, ea, er);
+    for (int row = rsub; row < rows; row += RSTEP) {
         const int m = m0 + row;
         const bool ok = m < p.M;                         // (all lanes of a row agree; the shuffles below need every lane)
         float s = 0.f, q = 0.f;
+        if (rowadd || resid) fetch(row + RSTEP, na, nr);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const int col = (l + LPR * c) * 8;
             half8v h = *reinterpret_cast<const half8v*>(stage + row * pitch + col * 2);
             if ((rowadd || resid) && ok) {
-                float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
-                if (rowadd) {
-                    const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + n0 + col);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+                for (int j = 0; j < 8; ++j) {
+                    float v = (float)h[j];
+                    if (rowadd) v += (float)ea[c][j];
+                    if (resid) v += (float)er[c][j];
+                    h[j] = (half_t)v;
                 }
-                if (resid) {
-                    const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + n0 + col);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float a = (float)h[j]; s += a; q += a * a; }
@@ -892,6 +936,8 @@ __device__ __forceinline__ void store_fp16_tile_rowsum(const moca_gemm_params& p
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
         if (l == 0 && ok) *reinterpret_cast<float2*>(dst + (int64_t)m * 2) = float2{s, q};
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { ea[c] = na[c]; er[c] = nr[c]; }
     }
 }
 

@@ -11,7 +11,10 @@ ZERO = os.environ.get("BG_ZERO") == "1"      # all-zero operands: how much of a 
 if ZERO:
     _randn = torch.randn
     torch.randn = lambda *a, **k: torch.zeros(*a, **k)
-B, T = 2, 16
+B, T = int(os.environ.get("BG_B", "2")), 16
+for kv in os.environ.get("BG_TUNE", "").split(","):      # e.g. BG_TUNE=2:2,1:0  (MOCA_TUNE_* knob:value)
+    if kv:
+        L.set_tuning(int(kv.split(":")[0]), int(kv.split(":")[1]))
 F = B * T
 LV = {0: (40, 64), 1: (20, 32), 2: (10, 16), 3: (5, 8)}
 
