@@ -2008,6 +2008,12 @@ static inline bool buffer_addressable(const moca_gemm_params& p) {
 
 static inline int sq256_mode() { return moca_tuning_get(MOCA_TUNE_GEMM_SQ256); }
 static inline bool fast_gather(const moca_gemm_params& p);
+// g4 (4 waves, two blocks per CU): the GEGLU projections with K <= 640 -- but not the very tall ones (M >= 2^17: B = 16 forwards), where
+// the 256 x 256 staggered kernel is 4-5 % ahead (tools/bench_gemm.py geglu, BG_B=16 BG_TUNE=2:2).  MOCA_TUNE_GEMM_G4 = 0 / 2: never / always.
+static inline bool wants_g4(const moca_gemm_params& p) {
+    const int g4_mode = moca_tuning_get(MOCA_TUNE_GEMM_G4);
+    return g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640 && p.M < (1 << 17));
+}
 static inline bool buffer_addressable(const moca_gemm_params& p);
 // the staggered kernel on 256 x 256 tiles for the wide projections (MOCA_TUNE_GEMM_SQ256 = 0: never, 1: not where g4 is preferred,
 // 2: every wide linear -- A/B runs); asked after takes_w80()
@@ -2126,8 +2132,7 @@ static int takes_glds_bn(const moca_gemm_params& p) {
     if (takes_w80(p)) return 0;
     const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
     if (!(big_bn != 0 && p.M > 128 && !(p.flags & MOCA_FORCE_SMALL_TILE))) return 0;
-    const int g4_mode = moca_tuning_get(MOCA_TUNE_GEMM_G4);
-    const bool use_g4 = !(p.flags & MOCA_EP_OUT_F32) && (g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640));
+    const bool use_g4 = !(p.flags & MOCA_EP_OUT_F32) && wants_g4(p);
     if (takes_sq256(p, use_g4)) return 0;
     if (big_bn == 128 && use_g4) return 0;
     return big_bn;
@@ -2154,8 +2159,7 @@ static bool lnfold_ok(const moca_gemm_params& p) {
     if (takes_w80(p)) return !(p.flags & MOCA_EP_GEGLU) && takes_w80s(p);
     const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
     if (!(big_bn != 0 && p.M > 128)) return false;
-    const int g4_mode = moca_tuning_get(MOCA_TUNE_GEMM_G4);
-    const bool use_g4 = g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640);
+    const bool use_g4 = wants_g4(p);
     if (takes_sq256(p, use_g4)) return true;
     if (big_bn == 128 && use_g4) return true;
     return !(p.flags & MOCA_EP_GEGLU);                  // the 256-row kernel: plain epilogue only
@@ -2267,8 +2271,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     // g4 (4 waves, two blocks per CU) wins where the epilogue is VALU-heavy and K is short (GEGLU at C = 320 / 640:
     // one block's erf-GELU epilogue runs under the other block's MFMAs, -5 % on the same device); the 8-wave kernel's
     // deeper pipeline wins everywhere else (K >= 1280: 1137 vs 880 TFLOP/s).  MOCA_TUNE_GEMM_G4 = 0 / 2 forces never / always (tests).
-    const int g4_mode = moca_tuning_get(MOCA_TUNE_GEMM_G4);
-    const bool use_g4 = !(p.flags & MOCA_EP_OUT_F32) && (g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640));
+    const bool use_g4 = !(p.flags & MOCA_EP_OUT_F32) && wants_g4(p);
     // w80 (320 x 160 tiles, 80 x 80 wave tiles): every non-GEGLU contraction whose N is a multiple of 160 and whose
     // 320-row tiles fill the chip.  (MOCA_TUNE_GEMM_W80: 0 never, 2 drops the tile-count rule -- tests.)
     const bool use_w80 = takes_w80(p);
