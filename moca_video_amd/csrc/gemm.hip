@@ -16,7 +16,6 @@
 // fp32 LDS tile so that bias / time-embedding / residual are applied in fp32 and the
 // result leaves as full 16-byte coalesced stores.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -659,6 +658,20 @@ struct BGather {
 
 // ---- epilogue stage 2 of the direct-to-LDS kernels: the fp16 tile staged in LDS (`rows` x `out_bn`, row pitch `pitch` bytes)
 //      leaves as 16-byte coalesced stores; the time-embedding row add and the residual are added in fp32 on the way ----
+// Output rows of a launch whose output is at least half the 256 MiB Infinity Cache leave with non-temporal stores: the consumer could
+// re-read little of them from a cache anyway, and they stop evicting the operands the running blocks share.  Same box, alternating
+// (threshold sweep 0 / 64 / 128 / 256 MiB / never): the B = 16 FIFO iteration 220.7 -> 218.2 ms at every threshold <= 256 MiB; the
+// B = 2 step 61.85 UNet-steps/s with plain stores, 62.1-62.2 at 64-128 MiB (the 320-channel GEGLU / q|k|v outputs stream), 60.7 with
+// `nt` on every output (the consumers of the small outputs find them in the Infinity Cache).
+__device__ __forceinline__ bool out_streams(const moca_gemm_params& p) { return p.reserved4_ & 1; }   // (decided by moca_gemm_f16)
+__device__ __forceinline__ void st_out8(half_t* ptr, const half8v v, bool nt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (an `nt` store in one arm of a branch is merged with the plain one and loses the hint: the streaming arm is an instruction of its own)
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(ptr), "v"(v) : "memory");
+    else *reinterpret_cast<half8v*>(ptr) = v;
+#endif
+}
+
 // Row-add / residual operands of the store loops are fetched several chunks AHEAD of the stores.  `out` may alias `residual`, so the
 // compiler keeps every load behind the previous iteration's store, and each 16-byte chunk paid a global-load round trip plus the store
 // drain (`s_waitcnt vmcnt(0)`).  With operands served by the Infinity Cache (B = 2 forward) that costs nothing measurable; from HBM
@@ -671,6 +684,7 @@ __device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const
                                                 int m0, int on0, int tid) {
     const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    const bool nt_out = out_streams(p);
     const int chunks_per_row = out_bn / 8;
     const int total_chunks = rows * chunks_per_row;
     if (!rowadd && !resid) {
@@ -682,8 +696,7 @@ __device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const
             const int m = m0 + row;
             if (m >= p.M) continue;
             const int64_t mo = upW ? 4 * (int64_t)m - 2 * (m % upW) + upC : m;
-            *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + mo * p.ldo + on0 + ch * 8) =
-                *reinterpret_cast<const half8v*>(stage + row * pitch + ch * 16);
+            st_out8(reinterpret_cast<half_t*>(p.out) + mo * p.ldo + on0 + ch * 8, *reinterpret_cast<const half8v*>(stage + row * pitch + ch * 16), nt_out);
         }
         return;
     }
@@ -718,7 +731,7 @@ __device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const
                 if (resid) v += (float)er[u][j];
                 h[j] = (half_t)v;
             }
-            *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + ooff[u]) = h;
+            st_out8(reinterpret_cast<half_t*>(p.out) + ooff[u], h, nt_out);
         }
     }
 }
@@ -735,6 +748,7 @@ __device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p
     constexpr int CPR = BNC / 8, RS = 512 / CPR;          // 320 x 160: 20 chunks per row, 25 row subsets; 160 x 320: 40 and 12
     const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    const bool nt_out = out_streams(p);
     const int ch = tid % CPR, rs = tid / CPR;
     float s[8], q[8];
 #pragma unroll
@@ -769,7 +783,7 @@ __device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p
                 half8v o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { o[j] = (half_t)v[j]; s[j] += v[j]; q[j] += v[j] * v[j]; }
-                *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = o;
+                st_out8(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col, o, nt_out);
             }
         }
 #pragma unroll
@@ -824,6 +838,7 @@ __device__ __forceinline__ void store_fp16_tile_ln(const moca_gemm_params& p, co
     constexpr int ROWS = 160, NC = 320, CPL = 5;
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
     const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    const bool nt_out = out_streams(p);
     const int l8 = tid & 7, rsub = tid >> 3;
     // gamma / beta go through LDS (`gb` = 2 x 320 floats behind the staged tile): 80 more live registers per thread would not
     // fit beside the row
@@ -875,7 +890,7 @@ __device__ __forceinline__ void store_fp16_tile_ln(const moca_gemm_params& p, co
                     n[j] = (half_t)((v[c][j] - mean) * rstd * g0[j] + b0[j]);
                     n[4 + j] = (half_t)((v[c][4 + j] - mean) * rstd * g1[j] + b1[j]);
                 }
-                *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = o;
+                st_out8(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col, o, nt_out);
                 *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.ln_out) + (int64_t)m * p.ld_ln + col) = n;
             }
         }
@@ -893,6 +908,7 @@ __device__ __forceinline__ void store_fp16_tile_rowsum(const moca_gemm_params& p
     static_assert(CPL * LPR * 8 == BNC, "column tile = LPR lanes x CPL chunks of 8");
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
     const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    const bool nt_out = out_streams(p);
     const int l = tid % LPR, rsub = tid / LPR;
     float* dst = p.rowsum + (int64_t)(n0 / BNC) * p.M * 2;
     const half8v zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -931,7 +947,7 @@ __device__ __forceinline__ void store_fp16_tile_rowsum(const moca_gemm_params& p
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float a = (float)h[j]; s += a; q += a * a; }
-            if (ok) *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + n0 + col) = h;
+            if (ok) st_out8(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + n0 + col, h, nt_out);
         }
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
@@ -2284,6 +2300,8 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     }
     if ((p.flags & MOCA_EP_ROWSUM) && !(p.rowsum && rowsum_cols(p) != 0)) return MOCA_E_BADARG;             // ask moca_gemm_rowsum_cols() first
     p.reserved4_ = 0;                                 // (bits 8.. carry the XCD partition chosen by the launcher)
+    // bit 0: output rows leave with non-temporal stores when the output is at least half the 256 MiB Infinity Cache (see out_streams)
+    if ((int64_t)p.M * (geglu ? p.N / 2 : p.N) * 2 >= (128ll << 20)) p.reserved4_ |= 1;
     if (p.flags & MOCA_EP_TATTN) {                    // ask moca_gemm_tattn_ok() first
         if (!tattn_ok(p) || ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1))) return MOCA_E_BADARG;
         return launch_gemm_w80s<MOCA_A_LINEAR, 3>(p, st);

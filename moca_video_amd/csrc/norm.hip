@@ -185,6 +185,14 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict
 // ---- K3': apply with the statistics a MOCA_EP_GSTAT producer accumulated: gstat i64 fixed point [statistics group][32][2] = (sum, sum of
 // squares), finished.  The first 32 threads of a block turn its statistics group's 32 pairs into (mean, rstd) in fp64 while the
 // block's first batch of x loads is in flight; no finalize launch exists.
+// STREAM: the output is at least half the Infinity Cache (B = 16 forwards at the 320- / 640-channel levels) and leaves with non-temporal
+// stores, as the GEMM outputs of that size do (gemm.hip, out_streams)
+template <bool STREAM>
+__device__ __forceinline__ void gn_st8(half_t* ptr, const half8v v) {
+    if constexpr (STREAM) __builtin_nontemporal_store(v, reinterpret_cast<half8v*>(ptr));
+    else *reinterpret_cast<half8v*>(ptr) = v;
+}
+template <bool STREAM>
 __global__ void gn_apply_gstat_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const int64_t* __restrict__ gstat, int HW, int C, int nchunk,
@@ -238,7 +246,7 @@ __global__ void gn_apply_gstat_kernel(const half_t* __restrict__ x, half_t* __re
         if (more) load4(nxt, pp + 4 * ppb);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (pp + u * ppb < p_end) *reinterpret_cast<half8v*>(y + off + (int64_t)(pp + u * ppb) * C) = norm8(cur[u]);
+            if (pp + u * ppb < p_end) gn_st8<STREAM>(y + off + (int64_t)(pp + u * ppb) * C, norm8(cur[u]));
         if (more) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
@@ -251,6 +259,7 @@ __global__ void gn_apply_gstat_kernel(const half_t* __restrict__ x, half_t* __re
 // the concatenated row, accumulates their sums / sums of squares over its pixels, the block combines them per channel group
 // through LDS and adds them to gstat (fixed-point atomics, as MOCA_EP_GSTAT) -- the consumer GroupNorm is then one apply launch instead
 // of partial + finalize + apply.  blockDim = (C/8, ppb), grid (F, nchunk) as the GroupNorm passes. ----
+template <bool STREAM>
 __global__ void concat_gstat_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, half_t* __restrict__ out,
                                     int64_t* __restrict__ gstat, int HW, int C1, int C2, int nchunk, int frames_per_stat) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -275,14 +284,14 @@ __global__ void concat_gstat_kernel(const half_t* __restrict__ a, const half_t* 
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8v*>(src + (int64_t)(pp + u * ppb) * ld);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            *reinterpret_cast<half8v*>(dst + (int64_t)(pp + u * ppb) * C) = v[u];
+            gn_st8<STREAM>(dst + (int64_t)(pp + u * ppb) * C, v[u]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float t = (float)v[u][j]; s[j] += t; q[j] += t * t; }
         }
     }
     for (; pp < p_end; pp += ppb) {
         const half8v v = *reinterpret_cast<const half8v*>(src + (int64_t)pp * ld);
-        *reinterpret_cast<half8v*>(dst + (int64_t)pp * C) = v;
+        gn_st8<STREAM>(dst + (int64_t)pp * C, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float t = (float)v[j]; s[j] += t; q[j] += t * t; }
     }
@@ -627,8 +636,10 @@ extern "C" int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gam
     const int nchunk = gn_nchunk(F, HW);
     const double inv_count = 1.0 / ((double)frames_per_stat * HW * (C / GN_GROUPS));
     const dim3 grid(F, nchunk), block(nch8, ppb);
-    hipLaunchKernelGGL(gn_apply_gstat_kernel, grid, block, 0, moca_stream(stream), reinterpret_cast<const half_t*>(x),
-                       reinterpret_cast<half_t*>(y), gamma, beta, gstat, HW, C, nchunk, frames_per_stat, inv_count, eps, silu);
+    const bool streams = (int64_t)F * HW * C * 2 >= (128ll << 20);
+    hipLaunchKernelGGL(streams ? gn_apply_gstat_kernel<true> : gn_apply_gstat_kernel<false>, grid, block, 0, moca_stream(stream),
+                       reinterpret_cast<const half_t*>(x), reinterpret_cast<half_t*>(y), gamma, beta, gstat, HW, C, nchunk, frames_per_stat,
+                       inv_count, eps, silu);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
@@ -646,8 +657,10 @@ extern "C" int moca_concat_channels_gstat_f16(const void* a, const void* b, void
     const int nchunk = gn_nchunk(F, HW);
     const size_t lds = (size_t)ppb * C * 2 * sizeof(float);
     if (lds > 64 * 1024) return MOCA_E_BADARG;
-    hipLaunchKernelGGL(concat_gstat_kernel, dim3(F, nchunk), dim3(nch8, ppb), lds, moca_stream(stream), reinterpret_cast<const half_t*>(a),
-                       reinterpret_cast<const half_t*>(b), reinterpret_cast<half_t*>(out), gstat, HW, C1, C2, nchunk, frames_per_stat);
+    const bool streams = (int64_t)F * HW * C * 2 >= (128ll << 20);
+    hipLaunchKernelGGL(streams ? concat_gstat_kernel<true> : concat_gstat_kernel<false>, dim3(F, nchunk), dim3(nch8, ppb), lds, moca_stream(stream),
+                       reinterpret_cast<const half_t*>(a), reinterpret_cast<const half_t*>(b), reinterpret_cast<half_t*>(out), gstat, HW, C1, C2,
+                       nchunk, frames_per_stat);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
