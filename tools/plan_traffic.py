@@ -60,12 +60,13 @@ def run(out):
     dm = bench.build_model(dev, seed=321)
     unet = dm.model.diffusion_model
     g = torch.Generator(device=dev).manual_seed(1)
-    x = torch.randn(1, 4, 16, 40, 64, device=dev, generator=g)
-    ctx = torch.randn(2, 77, 1024, device=dev, generator=g)
-    ts = torch.full((1,), 500, device=dev, dtype=torch.long)
+    n = int(os.environ.get("PT_N", "1"))            # latents: B = 2 n videos with the shared CFG prefix (PT_N=8: the FIFO / configs[4] batch)
+    x = torch.randn(n, 4, 16, 40, 64, device=dev, generator=g)
+    ctx = torch.randn(2 * n, 77, 1024, device=dev, generator=g)
+    ts = torch.full((n,), 500, device=dev, dtype=torch.long)
     with torch.no_grad():
         for _ in range(3):
-            unet.forward_segments(x, ts, [ctx[:1], ctx[1:]], fps=torch.tensor([10], device=dev), shared_x=True)
+            unet.forward_segments(x, ts, [ctx[:n], ctx[n:]], fps=torch.tensor([10] * n, device=dev), shared_x=True)
     torch.cuda.synchronize()
     plan = next(iter(unet._plans.values()))
     st = plan.stream
@@ -121,7 +122,7 @@ def join(root):
         a = agg.setdefault(key, [0, 0.0, 0.0, 0, 0, set()])
         a[0] += 1; a[1] += 2 * f * 1024; a[2] += wv * 1024; a[3] += rd; a[4] += w; a[5].update(names)
     tf, tw, ta = sum(a[1] for a in agg.values()), sum(a[2] for a in agg.values()), sum(a[3] + a[4] for a in agg.values())
-    print(f"# one B=2 shared-prefix forward, every launch once, eager: fetched {tf / 1e9:.2f} GB (FETCH_SIZE x2) + written {tw / 1e9:.2f} GB;"
+    print(f"# one B={2 * int(os.environ.get('PT_N', '1'))} shared-prefix forward, every launch once, eager: fetched {tf / 1e9:.2f} GB (FETCH_SIZE x2) + written {tw / 1e9:.2f} GB;"
           f" algorithmic (operands once) {ta / 1e9:.2f} GB")
     print(f"{'n':>3s} {'fetch MB':>9s} {'alg rd MB':>9s} {'x':>5s} {'write MB':>9s} {'alg wr MB':>9s} {'x':>5s} {'excess MB':>9s}  step")
     for key, (n, f, w, rd, aw, names) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2] - kv[1][3] - kv[1][4])):
