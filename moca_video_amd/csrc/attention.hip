@@ -395,6 +395,11 @@ __global__ __launch_bounds__(256, 2) void attention_short_kernel(
 //     unrolled over the two buffers); the staging pointers advance by one 64-bit add per tile.
 // What is left per element: 0.5 max3 + exp + 0.5 cvt_pk + 0.5 dot2.  121 VGPRs: four waves per SIMD.  Tiles, LDS images and fragment maps are those of attention_kernel.
 [[maybe_unused]] constexpr float LAZY_THR = 8.0f;
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // NW wavefronts (32 queries each) share every K/V tile: 4 (128 queries per block), or 8 (256 queries: half the LDS-DMA and L2 -> LDS
 // traffic per query, one piece of K and one of V per wave and tile; the barrier spans 8 waves)
@@ -506,14 +511,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void attention_v4_kernel(
                     if (key >= Nk) sc[sub][r] = -INFINITY;
                 }
         }
-        float t4[4];                                  // tile maximum as four independent chains
+        // tile maximum as four independent chains of v_max3_f32.  As instructions, not fmaxf: on accumulator outputs the compiler puts a
+        // canonicalising v_max_f32 x, x in front of every fmaxf operand (47 vector instructions for these 32 values instead of 18 -- a
+        // fifth of the key tile's vector issue, which is the longer pole of this kernel).  Scores are finite or -inf, never NaN.
+        float t4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            t4[c] = fmaxf(sc[0][c], sc[1][c]);
-#pragma unroll
-            for (int r = 4 + c; r < 16; r += 4) t4[c] = fmaxf(t4[c], fmaxf(sc[0][r], sc[1][r]));
+            t4[c] = vmax3(sc[0][c], sc[1][c], sc[0][4 + c]);
+            t4[c] = vmax3(t4[c], sc[1][4 + c], sc[0][8 + c]);
+            t4[c] = vmax3(t4[c], sc[1][8 + c], sc[0][12 + c]);
+            t4[c] = vmax3(t4[c], sc[1][12 + c], sc[1][12 + c]);
         }
-        float tmax = fmaxf(fmaxf(t4[0], t4[1]), fmaxf(t4[2], t4[3]));
+        float tmax = vmax3(vmax3(t4[0], t4[1], t4[2]), t4[3], t4[3]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));      // both key halves of this query: the two lanes agree from here on
         if (kt == 0 || __any(tmax > LAZY_THR)) {      // move the reference (always on the first tile)
             const float delta = kt == 0 ? tmax : fmaxf(tmax, 0.f);
