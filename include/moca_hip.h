@@ -306,7 +306,9 @@ typedef struct moca_fifo_state {
  * torch.randn draws of ddim.py:561 (`noise_like`, per frame) and funcs.py:92 (`new_noise`); no-op when ext_noise. */
 int moca_fifo_randn_f32(const moca_fifo_state* state, float* out, int64_t n, void* stream);
 /* x[(r nW + w)][c][j][p] = queue frame win_start[w] + j, r < reps (`latents[:,:,start:end].clone()`, funcs.py:315, repeated
- * for the unconditional branch of ddim.py:366-369); anchor[c][p] = queue frame 0 (funcs.py:88), may be NULL. */
+ * for the unconditional branch of ddim.py:366-369); anchor[c][p] = queue frame 0 (funcs.py:88), may be NULL.  x == NULL (then
+ * nW, win_start are ignored): the anchor only -- the call placed BEHIND the step kernel when the windows rewrite frame 0 (no lookahead,
+ * funcs.py:353-354: the reference reads latents[:,:,0] after the write-backs). */
 int moca_fifo_gather_windows_f32(const moca_fifo_state* state, const float* queue, float* x, float* anchor,
                                  const int32_t* win_start, int32_t nW, int32_t reps, int32_t C, int32_t Q, int32_t f,
                                  int32_t HW, void* stream);
@@ -327,6 +329,8 @@ typedef struct moca_fifo_step_params {
     const int32_t* mask_frame; /* [nW][f] queue frame consulted for window frame j (-1: none; ddim.py:565-567 incl. the clobbered index) */
     const float* enh;          /* [nW][f] factor on cond (ddim.py:582) */
     const float* cond;         /* [C][HW] conditioning image or NULL (zeros, ddim.py:573-574) */
+    const float* sam_eff;      /* [nW][f][HW] effective segmentation mask per window frame (moca_sam_select_masks_f32) or NULL; excludes `mask` */
+    const int32_t* sam_idx;    /* [nW][f] >= 0: inject cond * 2 where sam_eff > 0.5 (ddim.py:592-606,847,897-901); -1: leave pred_x0 alone */
     float cfg_scale, beta, one_minus_beta, gamma, one_minus_gamma;
     int32_t nW, C, Q, f, HW, wb_from;
 } moca_fifo_step_params;
@@ -334,6 +338,16 @@ typedef struct moca_fifo_step_params {
  * iteration (they are independent: funcs.py:305-355 walks ranks in reverse so every window reads pre-iteration frames) +
  * the write-back of their second halves into the ring. */
 int moca_fifo_step_windows_f32(const moca_fifo_step_params* p, void* stream);
+/* The mask bookkeeping of `DDIMSampler._apply_segmentation` (ddim.py:739-903) for all windows of an iteration, on candidate masks
+ * computed beforehand (the Grounded-SAM-2 producer, ddim.py:745-801, is outside the path).  cand: pool of [HW] f32 masks; window frame
+ * (w, i) has ncand[w f + i] candidates starting at pool index cand_off[w f + i] (0 = no box detected, ddim.py:788).  Per window -- one
+ * `ddim_step` call, `pre_masks = None` at its start (:391) -- and frame in order: only t_rows[w f + i] <= 300 (:592); no detection ->
+ * previous masks, or nothing when there are none (:788-793); mean IoU over zip(new, previous) of the masks binarised at 0.5 (both
+ * empty -> 1) < 0.5 -> previous masks (:804-807,905-943); masks applied in order, one whose sum exceeds 0.8 HW resets the frame
+ * (:820-822).  eff [nW][f][HW] = the resulting 0/1 mask, eff_idx [nW][f] = i or -1 (no injection); consumed by
+ * moca_fifo_step_windows_f32 (sam_eff / sam_idx). */
+int moca_sam_select_masks_f32(const float* cand, const int32_t* cand_off, const int32_t* ncand, const int64_t* t_rows, float* eff,
+                              int32_t* eff_idx, int32_t nW, int32_t f, int32_t HW, void* stream);
 /* funcs.py:357-371 minus the decode: emitted[iter mod n_slots][C][HW] = queue frame emit_frame (may be NULL); the slot of
  * the dequeued frame receives `newframe` [C][HW] (the FreeInit mix, funcs.py:97) and becomes the tail; the mask ring keeps
  * its last frame (funcs.py:113-116); then head = head + 1 mod Q, iter += 1, ext_noise = 0. */

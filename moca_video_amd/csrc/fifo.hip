@@ -54,13 +54,15 @@ __global__ __launch_bounds__(256) void fifo_randn_kernel(const moca_fifo_state* 
 }
 
 // window w, repeat r: x[(r nW + w)][c][j][p] = queue[c][(head + win_start[w] + j) mod Q][p] (funcs.py:315, the .clone() of
-// the window); anchor[c][p] = queue[c][head][p] (funcs.py:88: the frame the shift dequeues; no write-back touches it)
+// the window); anchor[c][p] = queue[c][head][p] (funcs.py:88: the frame the shift dequeues, read AFTER the iteration's write-backs.
+// With lookahead no write-back touches frame 0, so the pre-UNet gather may fetch it; without lookahead the rank-0 window rewrites
+// frame 0 (funcs.py:353-354) and the host asks for the anchor in a second call behind the step kernel: x == NULL, nW == 0)
 __global__ __launch_bounds__(256) void fifo_gather_kernel(const moca_fifo_state* __restrict__ st, const float* __restrict__ queue,
                                                           float* __restrict__ x, float* __restrict__ anchor,
                                                           const int32_t* __restrict__ win_start, int nW, int reps, int C, int Q,
                                                           int f, int HW) {
     const int head = st->head;
-    const int64_t per_rep = (int64_t)nW * C * f * HW;
+    const int64_t per_rep = x ? (int64_t)nW * C * f * HW : 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_rep; i += (int64_t)gridDim.x * 256) {
         const int p = (int)(i % HW);
         int64_t r = i / HW;
@@ -129,6 +131,8 @@ __global__ __launch_bounds__(256) void fifo_step_windows_kernel(moca_fifo_step_p
                 if (mf >= 0) {                                 // :565-590
                     const int ms = (head + mf) % Q;
                     if (P.mask_sums[ms] != 0.f && P.mask[(int64_t)ms * HW + p] > 0.5f) p0 = cnd * P.enh[w * f + j];
+                } else if (P.sam_eff && P.sam_idx[w * f + j] >= 0) {    // :592-606 -> _apply_segmentation :847,897-901 (factor 2)
+                    if (P.sam_eff[((int64_t)w * f + j) * HW + p] > 0.5f) p0 = cnd * 2.0f;
                 }
                 P.pred_x0[o] = P.one_minus_gamma * p0 + P.gamma * nz;   // :609
             }
@@ -232,6 +236,97 @@ __global__ __launch_bounds__(256) void fifo_prepare_kernel(const float* __restri
     }
 }
 
+// ---- the mask bookkeeping of `_apply_segmentation` (ddim.py:739-903) for the windows of one iteration, candidates precomputed ----
+// counts of (a > 0.5 && b > 0.5), (a > 0.5 || b > 0.5) over a frame, every thread gets both (calculate_iou, ddim.py:919-930)
+__device__ __forceinline__ void sam_block_count2(const float* __restrict__ a, const float* __restrict__ b, int HW, int* sh, int& inter,
+                                                 int& uni) {
+    int ci = 0, cu = 0;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        const bool x = a[p] > 0.5f, y = b[p] > 0.5f;
+        ci += (x && y) ? 1 : 0;
+        cu += (x || y) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ci += __shfl_xor(ci, o, 64);
+        cu += __shfl_xor(cu, o, 64);
+    }
+    __syncthreads();                                   // (the previous reduction's readers are done with sh)
+    if ((threadIdx.x & 63) == 0) {
+        sh[2 * (threadIdx.x >> 6)] = ci;
+        sh[2 * (threadIdx.x >> 6) + 1] = cu;
+    }
+    __syncthreads();
+    inter = sh[0] + sh[2] + sh[4] + sh[6];
+    uni = sh[1] + sh[3] + sh[5] + sh[7];
+}
+
+__device__ __forceinline__ float sam_block_sum(const float* __restrict__ a, int HW, float* sh) {
+    float s = 0.f;
+    for (int p = threadIdx.x; p < HW; p += 256) s += a[p];
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// One block per window (= one `ddim_step` call: `pre_masks = None` at its start, ddim.py:391), frames in order.  Per frame with
+// t <= 300 (:592): no detection -> the previous masks, or no injection if there are none (:788-793); IoU(new, previous) < 0.5 ->
+// the previous masks (:804-807, mean over zip() pairs :905-943); then the masks are applied in order, one that covers > 80 % of
+// the frame resets what the earlier ones injected (:820-822).  "previous masks" is always some earlier frame's candidate set, so
+// it is carried as (offset, count) into the candidate pool.  Every branch condition is block-uniform.
+__global__ __launch_bounds__(256) void sam_select_kernel(const float* __restrict__ cand, const int32_t* __restrict__ cand_off,
+                                                         const int32_t* __restrict__ ncand, const int64_t* __restrict__ t_rows,
+                                                         float* __restrict__ eff, int32_t* __restrict__ eff_idx, int f, int HW) {
+    __shared__ int sh_i[8];
+    __shared__ float sh_f[4];
+    const int w = blockIdx.x;
+    int pre_off = -1, pre_n = 0;
+    const float big = (float)(0.8 * (double)HW);       // `mask.sum() > 0.8 * mask.numel()`: a python float against an fp32 sum
+    for (int i = 0; i < f; ++i) {
+        const int wf = w * f + i;
+        int use_off = -1, use_n = 0;
+        if (t_rows[wf] <= 300) {
+            const int n = ncand[wf];
+            if (n > 0) {
+                use_off = cand_off[wf];
+                use_n = n;
+                if (pre_off >= 0) {
+                    const int pairs = n < pre_n ? n : pre_n;
+                    float acc = 0.f;
+                    for (int k = 0; k < pairs; ++k) {
+                        int inter, uni;
+                        sam_block_count2(cand + (int64_t)(use_off + k) * HW, cand + (int64_t)(pre_off + k) * HW, HW, sh_i, inter, uni);
+                        acc += uni == 0 ? 1.0f : (float)inter / (float)uni;
+                    }
+                    if (acc / (float)pairs < 0.5f) {
+                        use_off = pre_off;
+                        use_n = pre_n;
+                    }
+                }
+            } else if (pre_off >= 0) {
+                use_off = pre_off;
+                use_n = pre_n;
+            }
+        }
+        if (use_off < 0) {                             // t > 300, or nothing detected yet: pred_x0 is left alone
+            if (threadIdx.x == 0) eff_idx[wf] = -1;
+            continue;
+        }
+        pre_off = use_off;
+        pre_n = use_n;
+        float* e = eff + (int64_t)wf * HW;
+        for (int p = threadIdx.x; p < HW; p += 256) e[p] = 0.f;
+        for (int m = 0; m < use_n; ++m) {
+            const float* mk = cand + (int64_t)(use_off + m) * HW;
+            const bool reset = sam_block_sum(mk, HW, sh_f) > big;
+            for (int p = threadIdx.x; p < HW; p += 256) e[p] = reset ? 0.f : ((mk[p] > 0.5f) ? 1.0f : e[p]);
+        }
+        if (threadIdx.x == 0) eff_idx[wf] = i;
+    }
+}
+
 inline int grid_for(int64_t total) {
     int64_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
@@ -251,10 +346,10 @@ extern "C" int moca_fifo_randn_f32(const moca_fifo_state* state, float* out, int
 extern "C" int moca_fifo_gather_windows_f32(const moca_fifo_state* state, const float* queue, float* x, float* anchor,
                                             const int32_t* win_start, int32_t nW, int32_t reps, int32_t C, int32_t Q, int32_t f,
                                             int32_t HW, void* stream) {
-    if (!state || !queue || !x || !win_start || nW <= 0 || reps <= 0 || C <= 0 || Q <= 0 || f <= 0 || f > Q || HW <= 0)
-        return MOCA_E_BADARG;
-    hipLaunchKernelGGL(fifo_gather_kernel, dim3(grid_for((int64_t)nW * C * f * HW)), dim3(256), 0, moca_stream(stream), state, queue,
-                       x, anchor, win_start, nW, reps, C, Q, f, HW);
+    if (!state || !queue || C <= 0 || Q <= 0 || HW <= 0) return MOCA_E_BADARG;
+    if (x ? (!win_start || nW <= 0 || reps <= 0 || f <= 0 || f > Q) : !anchor) return MOCA_E_BADARG;     // x == NULL: the anchor only
+    hipLaunchKernelGGL(fifo_gather_kernel, dim3(grid_for(x ? (int64_t)nW * C * f * HW : (int64_t)C * HW)), dim3(256), 0, moca_stream(stream),
+                       state, queue, x, anchor, win_start, nW, reps, C, Q, f, HW);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
@@ -264,8 +359,17 @@ extern "C" int moca_fifo_step_windows_f32(const moca_fifo_step_params* p, void* 
     if (p->nW <= 0 || p->C <= 0 || p->f <= 0 || p->HW <= 0 || p->wb_from < 0) return MOCA_E_BADARG;
     if (p->queue && (p->Q < p->f)) return MOCA_E_BADARG;
     if (p->mask && (!p->mask_sums || !p->mask_frame || !p->enh || p->Q <= 0)) return MOCA_E_BADARG;
+    if (p->sam_eff && (!p->sam_idx || p->mask)) return MOCA_E_BADARG;      // one branch of ddim.py:565-606 per call
     if (!p->queue && !p->x_prev && !p->pred_x0) return MOCA_E_BADARG;
     hipLaunchKernelGGL(fifo_step_windows_kernel, dim3(grid_for((int64_t)p->nW * p->C * p->HW)), dim3(256), 0, moca_stream(stream), *p);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_sam_select_masks_f32(const float* cand, const int32_t* cand_off, const int32_t* ncand, const int64_t* t_rows,
+                                         float* eff, int32_t* eff_idx, int32_t nW, int32_t f, int32_t HW, void* stream) {
+    if (!cand || !cand_off || !ncand || !t_rows || !eff || !eff_idx || nW <= 0 || f <= 0 || HW <= 0) return MOCA_E_BADARG;
+    hipLaunchKernelGGL(sam_select_kernel, dim3(nW), dim3(256), 0, moca_stream(stream), cand, cand_off, ncand, t_rows, eff, eff_idx, f, HW);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

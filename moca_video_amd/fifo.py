@@ -124,7 +124,7 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
                        latents=None, latents_dir=None, conditioned_image=None, masks=None, gamma=0.5, emit=None,
                        n_iterations=None, batch_windows=True, noises=None, shift_noises=None, decode=False, decode_batch=8,
                        davis_data=None, anchor_noises=None, sam_masks=None, sam_masks_fn=None, targets=None, use_graph=True,
-                       seed=None, **kwargs):
+                       seed=None, sam_capacity=None, **kwargs):
     """funcs.py:243-373: returns the list of emitted latent frames [B,4,1,h,w]; with decode=True (and a model built with
     `first_stage_config`) the list of decoded frames [B,3,1,8h,8w] instead -- `model.decode_first_stage_2DAE` of funcs.py:360,
     run on `decode_batch` emitted frames at a time rather than once per iteration.
@@ -135,7 +135,10 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
     takes its segmentation branch (ddim.py:592-606: only frames with t <= 300, IoU fallback, > 80 % reset, factor 2) and asks
     Grounded-SAM-2 for masks -- out of scope here, so they come in as `sam_masks[i][w]` (iteration i, window w in the reference's
     call order: the list over frames of [n,h,w] candidate masks; or a callable (i, w) -> that list) or from `sam_masks_fn(pred_x0_frame, targets, frame) -> [n,h,w]`
-    (see DDIMSampler.ddim_step); with neither, nothing is injected.
+    (see DDIMSampler.ddim_step); with neither, nothing is injected.  Candidate LISTS run inside the iteration graph
+    (`moca_sam_select_masks_f32`; `sam_capacity` = the most candidate masks one iteration may hold, default: counted when
+    `sam_masks` is a list, else 4 per window frame); a producer CALLBACK needs pred_x0 on the host frame by frame and stays on the
+    host-driven loop.
 
     batch_windows=True evaluates the 2n windows of an iteration as one batched UNet launch; with `use_graph` (and a
     call `FifoEngine.supported` accepts) the WHOLE iteration -- gather, UNet, guidance, ddim_step of all windows, write-back,
@@ -164,8 +167,8 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
     total = args.new_video_length + args.num_inference_steps - f if n_iterations is None else n_iterations
     frames, pending = [], []
 
-    if (batch_windows and use_graph and sam_masks is None and
-            FifoEngine.supported(model, cond, latents, davis_data=davis_data, sam_masks_fn=sam_masks_fn) and
+    sam_in_graph = sam_masks is not None and masks is None                      # (with masks the DAVIS branch wins, ddim.py:565)
+    if (batch_windows and use_graph and FifoEngine.supported(model, cond, latents, davis_data=davis_data, sam_masks_fn=sam_masks_fn) and
             (masks is None or masks.shape[2] == latents.shape[2])):
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())                # follows torch.manual_seed like the randn draws it replaces
@@ -175,20 +178,28 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
             if last.shape[1] == 4:
                 last = last[:, :3]
             moments = model.first_stage_model.encode(last.to(latents.device)).parameters
+        sam_of = (lambda i: None) if not sam_in_graph else \
+            (lambda i: [sam_masks(i, w) for w in range(len(list(fifo_windows(args))))]) if callable(sam_masks) else (lambda i: sam_masks[i])
+        if sam_in_graph and sam_capacity is None:
+            n_wf = len(list(fifo_windows(args))) * f
+            sam_capacity = 4 * n_wf if callable(sam_masks) else max(
+                [1] + [sum(0 if c is None else int(torch.as_tensor(c).reshape(-1, latents.shape[-2], latents.shape[-1]).shape[0])
+                           for cw in it if cw is not None for c in cw) for it in sam_masks[:total]])
         eng = FifoEngine(args, model, ddim_sampler, cond, uc, cfg_scale, latents, conditioned_image=conditioned_image, masks=masks,
                          n_slots=decode_batch if decode else max(total, 1), seed=seed, anchor_moments=moments,
-                         scale_factor=getattr(model, "scale_factor", 1.0))
+                         scale_factor=getattr(model, "scale_factor", 1.0), sam_capacity=sam_capacity if sam_in_graph else 0)
         try:
             for i in range(total):
+                sm = sam_of(i)
                 if noises is not None or shift_noises is not None or anchor_noises is not None:
                     nz = noises[i] if noises is not None else [torch.randn(noise_shape, device=latents.device) for _ in eng.wins]
                     sn = shift_noises[i] if shift_noises is not None else torch.randn_like(latents[:, :, -1])
                     an = None
                     if moments is not None:
                         an = anchor_noises[i] if anchor_noises is not None else torch.randn_like(latents[:, :, -1])
-                    eng.step(noise=nz, shift_noise=sn, anchor_noise=an)
+                    eng.step(noise=nz, shift_noise=sn, anchor_noise=an, sam_masks=sm)
                 else:
-                    eng.step()
+                    eng.step(sam_masks=sm)
                 if decode and ((i + 1) % decode_batch == 0 or i + 1 == total):
                     i0 = (i // decode_batch) * decode_batch
                     img = model.decode_first_stage_2DAE(eng.emitted_frames(i0, i + 1))

@@ -29,7 +29,7 @@ from . import lib as _l
 from . import ops
 from .freeinit import get_freq_filter
 from .plan import _Plan
-from .unet import UNetModel
+from .unet import UNetModel, same_fps
 
 
 def fifo_windows(args):
@@ -63,7 +63,10 @@ class FifoEngine:
                 and sam_masks_fn is None and latents is not None and latents.is_cuda and latents.shape[0] == 1)
 
     def __init__(self, args, model, sampler, cond, uc, cfg_scale, latents, conditioned_image=None, masks=None, gamma=0.5,
-                 n_slots=1, seed=0, anchor_moments=None, scale_factor=1.0):
+                 n_slots=1, seed=0, anchor_moments=None, scale_factor=1.0, sam_capacity=0):
+        """sam_capacity > 0 (and no `masks`): prompt mode with precomputed Grounded-SAM-2 candidates -- `ddim_step`'s segmentation
+        branch (ddim.py:592-606 -> `_apply_segmentation` :739-903) runs inside the iteration graph on at most `sam_capacity`
+        candidate masks per iteration, handed to `step(sam_masks=...)`."""
         self.unet = unet = model.model.diffusion_model
         dev = latents.device
         self.device = dev
@@ -107,13 +110,16 @@ class FifoEngine:
         B = self.reps * nW
         # guided: the unconditional windows are the SAME latents with another context: one plan whose prefix (everything before the
         # first cross-attention) runs once for both branches
-        self.plan = plan = _Plan(unet, B, f, H, W, segs, torch.float32, dev, shared_x=guided)
+        # (the prefix adds ONE fps embedding: branches with different fps run as a plain batch of 2 nW videos instead)
+        fps_c = cond.get("fps", 16)
+        shared = guided and same_fps([fps_c, uc.get("fps", fps_c)])
+        self.gather_reps = 1 if shared or not guided else 2
+        self.plan = plan = _Plan(unet, B, f, H, W, segs, torch.float32, dev, shared_x=shared)
 
         def fps_rows(fp):
             if isinstance(fp, int):
                 return torch.full((nW * f,), fp, dtype=torch.int64, device=dev)
             return torch.as_tensor(fp, device=dev).reshape(-1)[:1].to(torch.int64).expand(nW * f)
-        fps_c = cond.get("fps", 16)
         fr = [fps_rows(fps_c)] + ([fps_rows(uc.get("fps", fps_c))] if guided else [])
         with torch.cuda.stream(plan.stream):
             plan.t_rows.copy_(to_dev(t_rows).reshape(-1).repeat(self.reps))
@@ -144,6 +150,17 @@ class FifoEngine:
         lib = _l.load()
         self.mix_ws = torch.empty(int(lib.moca_freq_mix_ws_bytes(Cc, 1, H, W)) // 4, **f32)
         self.mask = self.mask_sums = self.cond = None
+        self.sam_capacity = int(sam_capacity) if masks is None else 0
+        self._t_host = t_rows                                     # [nW][f] timesteps (host copy: which frames take the <= 300 branch)
+        if self.sam_capacity > 0:
+            self.sam_cand = torch.zeros(self.sam_capacity, HW, **f32)
+            self.sam_tab = torch.zeros(2, nW * f, dtype=torch.int32, device=dev)          # [0] pool offset, [1] candidate count
+            self.sam_eff = torch.zeros(nW, f, HW, **f32)
+            self.sam_idx = torch.full((nW * f,), -1, dtype=torch.int32, device=dev)
+            self._sam_stage = [(torch.empty(self.sam_capacity, HW, dtype=torch.float32).pin_memory(),
+                                torch.zeros(2, nW * f, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+            self._sam_turn = 0
+            self.cond = self._cond_image(conditioned_image, Cc, HW, dev)
         if masks is not None:
             if masks.shape[2] != Q:
                 raise ValueError("the device-resident loop wants one mask frame per queue frame")
@@ -151,15 +168,7 @@ class FifoEngine:
             self.mask_sums = torch.empty(Q, **f32)
             _l.check(lib.moca_mask_frame_sums_f32(_l.ptr(self.mask), _l.ptr(self.mask_sums), Q, HW,
                                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "moca_mask_frame_sums_f32")
-            if conditioned_image is None:
-                self.cond = torch.zeros(Cc, HW, **f32)                                       # ddim.py:573-574
-            else:
-                ci = conditioned_image.to(dev)
-                if ci.shape[1] != Cc:
-                    if ci.shape[1] != 3:
-                        raise ValueError(f"Conditional image must have 3 or 4 channels, got {ci.shape[1]}")
-                    ci = torch.cat([ci, torch.ones_like(ci[:, :1])], dim=1)                  # :575-578
-                self.cond = ci.to(torch.float32).reshape(-1, Cc, HW)[0].contiguous()
+            self.cond = self._cond_image(conditioned_image, Cc, HW, dev)
         torch.cuda.current_stream(dev).synchronize()
         # ---- the launch sequence of one iteration = [noise, gather] + UNet + [guidance + step + write-back, FreeInit mix, advance]
         p = _l.FifoStepParams()
@@ -172,6 +181,8 @@ class FifoEngine:
         p.coef, p.win_start = self.coef.data_ptr(), self.win_start.data_ptr()
         p.mask, p.mask_sums = _ptr(self.mask), _ptr(self.mask_sums)
         p.mask_frame, p.enh, p.cond = self.mframe.data_ptr(), self.enh.data_ptr(), _ptr(self.cond)
+        if self.sam_capacity > 0:
+            p.sam_eff, p.sam_idx = self.sam_eff.data_ptr(), self.sam_idx.data_ptr()
         p.cfg_scale = float(cfg_scale)
         p.beta, p.one_minus_beta = float(np.float32(sampler.beta)), float(np.float32(1 - sampler.beta))
         p.gamma, p.one_minus_gamma = float(np.float32(gamma)), float(np.float32(1 - gamma))
@@ -183,11 +194,20 @@ class FifoEngine:
 
         def pre():
             _l.check(lib.moca_fifo_randn_f32(st_, _l.ptr(self.noise), self.noise.numel(), S()), "moca_fifo_randn_f32")
-            _l.check(lib.moca_fifo_gather_windows_f32(st_, q_, _l.ptr(plan.x_in), None if self.moments is not None else _l.ptr(self.anchor),
-                                                      _l.ptr(self.win_start), nW, 1, Cc, Q, f, HW, S()), "moca_fifo_gather_windows_f32")
+            # the FreeInit anchor is frame 0 AFTER the write-backs (funcs.py:88): only with lookahead is it untouched by them
+            early_anchor = self.moments is None and self.lookahead
+            _l.check(lib.moca_fifo_gather_windows_f32(st_, q_, _l.ptr(plan.x_in), _l.ptr(self.anchor) if early_anchor else None,
+                                                      _l.ptr(self.win_start), nW, self.gather_reps, Cc, Q, f, HW, S()), "moca_fifo_gather_windows_f32")
 
         def post():
+            if self.sam_capacity > 0:      # which candidate masks each window frame injects (pre_masks / IoU / > 80 % bookkeeping)
+                _l.check(lib.moca_sam_select_masks_f32(_l.ptr(self.sam_cand), _l.ptr(self.sam_tab[0]), _l.ptr(self.sam_tab[1]),
+                                                       _l.ptr(plan.t_rows), _l.ptr(self.sam_eff), _l.ptr(self.sam_idx), nW, f, HW, S()),
+                         "moca_sam_select_masks_f32")
             _l.check(lib.moca_fifo_step_windows_f32(C.byref(p), S()), "moca_fifo_step_windows_f32")
+            if self.moments is None and not self.lookahead:  # rank 0 rewrote frame 0 (funcs.py:353-354): read the anchor now
+                _l.check(lib.moca_fifo_gather_windows_f32(st_, q_, None, _l.ptr(self.anchor), None, 0, 1, Cc, Q, f, HW, S()),
+                         "moca_fifo_gather_windows_f32")
             if self.moments is not None:                     # anchor = get_first_stage_encoding(posterior of the last DAVIS frame) (:108)
                 _l.check(lib.moca_gaussian_sample_f32(_l.ptr(self.moments), _l.ptr(self.noise[n_win + Cc * HW:]), _l.ptr(self.anchor), 1, Cc, HW,
                                                       float(scale_factor), S()), "moca_gaussian_sample_f32")
@@ -200,14 +220,60 @@ class FifoEngine:
         self.n_iter = 0
         sampler.momentum = self.momentum[nW - 1].view(1, Cc, f, H, W)      # what the reference's last call (rank 0) leaves behind
 
+    @staticmethod
+    def _cond_image(conditioned_image, Cc, HW, dev):
+        if conditioned_image is None:
+            return torch.zeros(Cc, HW, dtype=torch.float32, device=dev)                      # ddim.py:573-574
+        ci = conditioned_image.to(dev)
+        if ci.shape[1] != Cc:
+            if ci.shape[1] != 3:
+                raise ValueError(f"Conditional image must have 3 or 4 channels, got {ci.shape[1]}")
+            ci = torch.cat([ci, torch.ones_like(ci[:, :1])], dim=1)                          # :575-578
+        return ci.to(torch.float32).reshape(-1, Cc, HW)[0].contiguous()
+
+    def _upload_sam(self, sam_masks):
+        """pack the candidates of this iteration -- `sam_masks[w][i]` = [n,H,W] masks Grounded-SAM-2 returns for frame i of window w
+        (reference call order), None / empty = no box -- into the pool and enqueue the copy on the plan's stream.  Frames with
+        t > 300 never reach the producer (ddim.py:592) and are not uploaded.  Pinned double buffer: no host synchronisation unless
+        the copy of two iterations ago is still in flight."""
+        pool, tab, ev = self._sam_stage[self._sam_turn]
+        self._sam_turn ^= 1
+        ev.synchronize()
+        tab.zero_()
+        used = 0
+        if sam_masks is not None:
+            for w in range(self.nW):
+                cw = sam_masks[w]
+                for i in range(self.f):
+                    if self._t_host[w, i] > 300 or cw is None or i >= len(cw) or cw[i] is None:
+                        continue
+                    m = torch.as_tensor(cw[i]).detach().to("cpu", torch.float32).reshape(-1, self.HW)
+                    n = m.shape[0]
+                    if n == 0:
+                        continue
+                    if used + n > self.sam_capacity:
+                        raise ValueError(f"more than sam_capacity = {self.sam_capacity} candidate masks in one iteration")
+                    pool[used:used + n].copy_(m)
+                    tab[0, w * self.f + i], tab[1, w * self.f + i] = used, n
+                    used += n
+        if used:
+            self.sam_cand[:used].copy_(pool[:used], non_blocking=True)
+        self.sam_tab.copy_(tab, non_blocking=True)
+        ev.record(self.plan.stream)
+
     # ------------------------------------------------------------------------------------------------------------------
-    def step(self, noise=None, shift_noise=None, anchor_noise=None):
+    def step(self, noise=None, shift_noise=None, anchor_noise=None, sam_masks=None):
         """one outer iteration (enqueued, not synchronised).  `noise` = list over windows (reference order: rank 2n-1 .. 0) of
-        [1,C,f,H,W] tensors, `shift_noise` [1,C,H,W] and (DAVIS mode) `anchor_noise` [1,C,1,H,W] fix the draws (all or none)."""
+        [1,C,f,H,W] tensors, `shift_noise` [1,C,H,W] and (DAVIS mode) `anchor_noise` [1,C,1,H,W] fix the draws (all or none);
+        `sam_masks` (engines built with sam_capacity): this iteration's candidate masks, see `_upload_sam`."""
         plan = self.plan
         cur = torch.cuda.current_stream(self.device)
         plan.stream.wait_stream(cur)
         with torch.cuda.stream(plan.stream):
+            if self.sam_capacity > 0:
+                self._upload_sam(sam_masks)
+            elif sam_masks is not None:
+                raise ValueError("this engine was built without sam_capacity")
             if noise is not None:
                 n_win = self.nW * self.C * self.f * self.HW
                 self.noise[:n_win].view(self.nW, -1).copy_(torch.stack([n.reshape(-1) for n in noise]).to(self.device, torch.float32))
@@ -267,7 +333,8 @@ class BaseEngine:
         unet = getattr(getattr(model, "model", None), "diffusion_model", None)
         ok = isinstance(unet, UNetModel) and x.is_cuda and isinstance(cond, dict) and isinstance(uc, dict) and scale != 1.0
         return ok and set(cond.keys()) == set(uc.keys()) <= {"c_crossattn", "fps"} and \
-            getattr(model.model, "conditioning_key", None) == "crossattn" and 2 * x.shape[0] <= 64
+            getattr(model.model, "conditioning_key", None) == "crossattn" and 2 * x.shape[0] <= 64 and \
+            same_fps([cond.get("fps", 16), uc.get("fps", 16)])      # (the shared prefix adds ONE fps embedding)
 
     def __init__(self, model, sampler, x, cond, uc, cfg_scale, seed=0, keep_pred_x0=False):
         self.unet = unet = model.model.diffusion_model
@@ -322,6 +389,8 @@ class BaseEngine:
         """start a new trajectory on the same plan: latents x_T, contexts, fps, iteration 0, a new noise stream"""
         plan, dev = self.plan, self.device
         B = self.shape[0]
+        if not same_fps([cond.get("fps", 16), uc.get("fps", 16)]):
+            raise ValueError("BaseEngine shares the UNet prefix between the two guidance branches: their fps must be equal")
         cc, cu = (torch.cat(c["c_crossattn"], 1).expand(B, -1, -1) for c in (cond, uc))
         st = _l.FifoState(0, 0, seed & 0xffffffff, (seed >> 32) & 0xffffffff, 0)
         cur = torch.cuda.current_stream(dev)

@@ -64,7 +64,7 @@ class FifoStepParams(C.Structure):
         ("state", C.c_void_p), ("x", C.c_void_p), ("eps_c", C.c_void_p), ("eps_u", C.c_void_p), ("noise", C.c_void_p),
         ("momentum", C.c_void_p), ("queue", C.c_void_p), ("x_prev", C.c_void_p), ("pred_x0", C.c_void_p), ("coef", C.c_void_p),
         ("win_start", C.c_void_p), ("mask", C.c_void_p), ("mask_sums", C.c_void_p), ("mask_frame", C.c_void_p),
-        ("enh", C.c_void_p), ("cond", C.c_void_p),
+        ("enh", C.c_void_p), ("cond", C.c_void_p), ("sam_eff", C.c_void_p), ("sam_idx", C.c_void_p),
         ("cfg_scale", C.c_float), ("beta", C.c_float), ("one_minus_beta", C.c_float), ("gamma", C.c_float),
         ("one_minus_gamma", C.c_float),
         ("nW", C.c_int32), ("C", C.c_int32), ("Q", C.c_int32), ("f", C.c_int32), ("HW", C.c_int32), ("wb_from", C.c_int32),
@@ -108,6 +108,7 @@ SIGNATURES = {
     "moca_fifo_randn_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "moca_fifo_gather_windows_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "moca_fifo_step_windows_f32": (C.c_int, [C.POINTER(FifoStepParams), _vp]),
+    "moca_sam_select_masks_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "moca_fifo_advance_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "moca_fifo_prepare_queue_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "moca_base_set_timestep": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),

@@ -23,6 +23,7 @@ import torch
 
 from . import lib as _l
 from . import ops
+from .unet import same_fps
 
 
 def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
@@ -103,7 +104,7 @@ class DDIMSampler(object):
             e_c, e_u = unet.forward_concurrent([dict(x=x, timesteps=t, context=cc, fps=f_c),
                                                 dict(x=x, timesteps=t, context=cu, fps=f_u)])
         elif batched and self.share_prefix and hasattr(unet, "forward_segments") and \
-                getattr(self.model.model, "conditioning_key", None) == "crossattn":
+                getattr(self.model.model, "conditioning_key", None) == "crossattn" and same_fps([c.get("fps", 16), uc.get("fps", 16)]):
             # both branches in ONE forward that shares everything before the first cross-attention (same x, same t)
             B = x.shape[0]
             e = unet.forward_segments(x, t, [cc, cu], fps=[c.get("fps", 16), uc.get("fps", 16)], shared_x=True)
@@ -248,7 +249,8 @@ class DDIMSampler(object):
         cu = torch.cat(uc["c_crossattn"], 1).expand(W, -1, -1)
         fps_u = uc.get("fps", fps_c)
         unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
-        if self.share_prefix and hasattr(unet, "forward_segments") and getattr(self.model.model, "conditioning_key", None) == "crossattn":
+        if self.share_prefix and hasattr(unet, "forward_segments") and getattr(self.model.model, "conditioning_key", None) == "crossattn" \
+                and same_fps([fps_c, fps_u]):
             e = unet.forward_segments(x, t, [cc, cu], fps=[fps_rows(fps_c, W), fps_rows(fps_u, W)], shared_x=True)
             e_c, e_u = e[:W], e[W:]
         elif cc.shape == cu.shape and isinstance(fps_c, int) == isinstance(fps_u, int):

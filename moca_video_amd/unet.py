@@ -267,6 +267,28 @@ def pack_tree(root, dev):
 # --------------------------------------------------------------------------------------
 # the model
 # --------------------------------------------------------------------------------------
+def same_fps(fps_list):
+    """True when every entry of a per-segment fps list describes the same frame rates (ints, or tensors with equal values).
+    The tensor comparison reads the device once; callers on a replayed-graph path do it at construction time only."""
+    first = fps_list[0]
+    for f in fps_list[1:]:
+        if f is first:
+            continue
+        if isinstance(first, int) and isinstance(f, int):
+            if f != first:
+                return False
+            continue
+        a = torch.as_tensor(first).reshape(-1).to(torch.int64).cpu()
+        b = torch.as_tensor(f).reshape(-1).to(torch.int64).cpu()
+        if a.shape != b.shape:
+            if a.numel() != 1 and b.numel() != 1:
+                return False
+            a, b = torch.broadcast_tensors(a, b)
+        if not torch.equal(a, b):
+            return False
+    return True
+
+
 class UNetModel(nn.Module):
     def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  dropout=0.0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, context_dim=None,
@@ -465,7 +487,8 @@ class UNetModel(nn.Module):
         shared_x=True: the segments are context variants of the SAME latents -- the two `apply_model` calls of classifier-free
         guidance (ddim.py:298-299,366-369).  x [n, ...], timesteps and fps describe the n distinct videos, every context is
         [n, L_i, D]; returns [len(contexts) * n, ...] (segment-major).  Everything before the first cross-attention is computed
-        once (see _Plan); fps may be a list with one entry per segment."""
+        once (see _Plan) with the fps embedding of the first segment, so a per-segment fps list must hold EQUAL entries
+        (ValueError otherwise: `same_fps`)."""
         n = x.shape[0]
         if shared_x:
             if any(c.shape[0] != n for c in contexts):
@@ -473,6 +496,10 @@ class UNetModel(nn.Module):
             segs = tuple((n, int(c.shape[1])) for c in contexts)
             fps_list = list(fps) if isinstance(fps, (list, tuple)) else [fps] * len(contexts)
             rows = [self._prepare(x, timesteps, contexts[0], None, f, check_context=False) for f in fps_list]
+            if not same_fps(fps_list):
+                # the shared prefix (conv_in .. the first ResBlock) adds ONE fps embedding to the rows both branches read
+                raise ValueError("shared_x: the segments share everything before the first cross-attention, so their fps must be "
+                                 "equal (use shared_x=False for branches with different fps)")
             t_rows = torch.cat([r[0] for r in rows])
             fps_rows = torch.cat([r[1] for r in rows])
             return self._plan_for(x, segs, shared_x=True).run(x, t_rows, fps_rows, list(contexts))

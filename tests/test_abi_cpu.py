@@ -64,7 +64,7 @@ def test_fifo_structs_match_header():
     assert _header_struct_fields("moca_fifo_state") == [f[0] for f in lib.FifoState._fields_]
     assert C.sizeof(lib.FifoState) == 32
     assert _header_struct_fields("moca_fifo_step_params") == [f[0] for f in lib.FifoStepParams._fields_]
-    assert C.sizeof(lib.FifoStepParams) == 16 * 8 + 5 * 4 + 6 * 4 + 4          # 16 pointers, 5 floats, 6 ints, tail padding
+    assert C.sizeof(lib.FifoStepParams) == 18 * 8 + 5 * 4 + 6 * 4 + 4          # 18 pointers, 5 floats, 6 ints, tail padding
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
@@ -75,6 +75,8 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert l.moca_layernorm_f16(None, None, None, None, 4, 64, 1e-5, None) == -1
     assert l.moca_temporal_attention_f16(C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 1, 17, 4, 1, 192, 64, 0.125, None) == -1
     assert l.moca_fifo_step_windows_f32(C.byref(lib.FifoStepParams()), None) == -1
+    assert l.moca_sam_select_masks_f32(None, None, None, None, None, None, 4, 8, 256, None) == -1
+    assert l.moca_fifo_gather_windows_f32(C.c_void_p(8), C.c_void_p(8), None, None, None, 0, 1, 4, 20, 8, 256, None) == -1   # neither x nor anchor
     assert l.moca_fifo_randn_f32(None, None, 16, None) == -1 and l.moca_repeat_f16(C.c_void_p(16), C.c_void_p(32), 24, 2, None) == -1
     assert l.moca_set_tuning(99, 1) == -1 and l.moca_set_tuning(lib.MOCA_TUNE_GEMM_G4, 1) == 1
     assert l.moca_gemm_splitk_ws_bytes(640, 1280, 4) == 4 * 640 * 1280 * 4

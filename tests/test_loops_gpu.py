@@ -137,11 +137,13 @@ def _spy_steps(sampler):
     return calls, state
 
 
-@pytest.mark.parametrize("producer", ["lists", "callback"])
+@pytest.mark.parametrize("producer", ["lists", "callback", "lists_graph"])
 def test_hip_fifo_loop_prompt_mode_vs_reference_golden(dm, producer):
     """fifo_ddim_sampling (funcs.py:243-373) without DAVIS data: queue from the cached latents (prepare_latents), the
     segmentation branch of ddim_step with the scripted Grounded-SAM-2 masks (as per-call lists, and through the mask-producer
-    callback that is shown pred_x0 frame by frame), decode of every emitted frame, FreeInit shift -- against the REAL loop"""
+    callback that is shown pred_x0 frame by frame), decode of every emitted frame, FreeInit shift -- against the REAL loop.
+    "lists_graph": the same candidate lists with the whole iteration, segmentation bookkeeping included, as one hipGraph (no
+    ddim_step call reaches the host: the per-call comparison of that path is test_fifo_graph_prompt_mode_calls_vs_reference_golden)"""
     from moca_video_amd.fifo import fifo_ddim_sampling, prepare_latents
     from moca_video_amd.sampler import DDIMSampler
     g = golden("loop_fifo")
@@ -154,8 +156,10 @@ def test_hip_fifo_loop_prompt_mode_vs_reference_golden(dm, producer):
     cimg = (inp("loop.cimg", (1, 4, 1, 16, 16)) * 0.25 + 0.5).clamp(0, 1).cuda()
     calls, state = _spy_steps(s)
     kw = {}
-    if producer == "lists":
+    graph = producer == "lists_graph"
+    if producer.startswith("lists"):
         kw["sam_masks"] = lambda i, wi: loop_sam_candidates(4 * i + wi, 8, 16, 16)
+        kw["use_graph"] = graph
     else:
         def fn(pred_x0_frame, target, frame):
             assert pred_x0_frame.shape == (1, 4, 1, 16, 16) and target == "object."
@@ -164,8 +168,8 @@ def test_hip_fifo_loop_prompt_mode_vs_reference_golden(dm, producer):
     frames = fifo_ddim_sampling(FIFO_ARGS, dm, cond, (1, 4, 8, 16, 16), s, cfg_scale=12.0, uc_emb=t["uc"], latents=lat,
                                 conditioned_image=cimg, n_iterations=3, noises=noises, shift_noises=shifts, decode=True,
                                 targets="object.", **kw)
-    assert len(frames) == 3 and len(calls) == 12
-    for c in range(12):
+    assert len(frames) == 3 and len(calls) == (0 if graph else 12)
+    for c in range(len(calls)):
         assert relerr(calls[c][0].cpu(), g["prompt_x_prev"][c]) < TOL_FIFO, f"call {c} x_prev"
         assert relerr(calls[c][1].cpu(), g["prompt_pred_x0"][c]) < TOL_FIFO, f"call {c} pred_x0"
     for i in range(3):
@@ -173,6 +177,146 @@ def test_hip_fifo_loop_prompt_mode_vs_reference_golden(dm, producer):
         assert e < TOL_FIFO, f"decoded frame {i}: {e:.3e}"
     e = relerr(lat.cpu(), g["prompt_queue"][2])
     assert e < TOL_FIFO, f"queue after 3 iterations: {e:.3e}"
+
+
+def test_fifo_graph_prompt_mode_calls_vs_reference_golden(dm):
+    """The one-hipGraph iteration in PROMPT mode (ddim.py:592-606 -> `_apply_segmentation`: only t <= 300, previous-mask and IoU
+    fallbacks, > 80 % reset, factor 2 -- `moca_sam_select_masks_f32` + the sam branch of the step kernel): x_prev / pred_x0 of every
+    window of 3 iterations (eager, capture, replay) against the REAL loop's 12 `ddim_step` calls with the scripted producer; the
+    candidate lists are uploaded per iteration, nothing is read back inside the loop.  pred_x0 is where the branch shows (the
+    reference's caller discards it: the injection never reaches x_prev / the queue)."""
+    from moca_video_amd.fifo import prepare_latents
+    from moca_video_amd.fifo_graph import FifoEngine
+    from moca_video_amd.sampler import DDIMSampler
+    g = golden("loop_fifo")
+    t = _text()
+    _, prep, noises, shifts, _ = _fifo_noises("prompt")
+    s = DDIMSampler(dm)
+    s.make_schedule(16, ddim_eta=1.0, verbose=False)
+    lat = prepare_latents(FIFO_ARGS, None, s, initial_latents=inp("loop.z16", (1, 4, 8, 16, 16)).cuda(), noises=prep)
+    cond = {"c_crossattn": [t["c1"], t["c2"]], "fps": torch.tensor([10]).cuda()}
+    uc = {"c_crossattn": [t["uc"]], "fps": cond["fps"]}
+    cimg = (inp("loop.cimg", (1, 4, 1, 16, 16)) * 0.25 + 0.5).clamp(0, 1).cuda()
+    eng = FifoEngine(FIFO_ARGS, dm, s, cond, uc, 12.0, lat, conditioned_image=cimg, n_slots=3, sam_capacity=64)
+    injected = 0
+    for i in range(3):
+        eng.step(noise=noises[i], shift_noise=shifts[i], sam_masks=[loop_sam_candidates(4 * i + w, 8, 16, 16) for w in range(4)])
+        xp, p0 = eng.window_outputs()
+        idx = eng.sam_idx.cpu().reshape(4, 8)
+        for w in range(4):
+            c = 4 * i + w
+            assert relerr(xp[w].cpu(), g["prompt_x_prev"][c]) < TOL_FIFO, f"call {c} x_prev"
+            assert relerr(p0[w].cpu(), g["prompt_pred_x0"][c]) < TOL_FIFO, f"call {c} pred_x0"
+            # the device bookkeeping against the host one (DDIMSampler.select_sam_masks), bit for bit
+            eff_h, idx_h = s.select_sam_masks(loop_sam_candidates(c, 8, 16, 16), eng._t_host[w], 16, 16, "cuda")
+            assert np.array_equal(np.where(idx[w].numpy() >= 0, np.arange(8), -1), idx_h)
+            sel = idx_h >= 0
+            assert torch.equal(eng.sam_eff[w][torch.from_numpy(sel)].cpu(), eff_h[torch.from_numpy(sel)].cpu())
+            injected += int(sel.sum())
+    assert injected > 0 and eng.plan.graph is not None
+    assert relerr(eng.latents().cpu(), g["prompt_queue"][2]) < TOL_FIFO
+    eng.close()
+
+
+def test_sam_select_kernel_equals_host_bookkeeping():
+    """moca_sam_select_masks_f32 against DDIMSampler.select_sam_masks (the statement-by-statement restatement of ddim.py:739-903 the
+    host loop uses, itself pinned by tests/golden/sampler_sam*.npz) on random candidate sets: overlapping blobs around a drifting
+    centre (IoU on both sides of 0.5), missing detections, several masks per frame of unequal count, > 80 % masks, empty masks
+    (union 0 -> IoU 1), timesteps on both sides of 300, HW not a multiple of the block -- effective masks and frame flags bit for bit"""
+    import ctypes as C
+    from moca_video_amd import lib as L
+    from moca_video_amd.sampler import DDIMSampler
+    lib = L.load()
+    H, W, f, nW = 13, 21, 8, 6
+    HW = H * W
+    rng = np.random.default_rng(5)
+    s = DDIMSampler(types.SimpleNamespace(num_timesteps=1000))
+    yy, xx = np.mgrid[0:H, 0:W]
+    ts = rng.choice([100, 250, 300, 301, 700], size=(nW, f), p=[0.3, 0.3, 0.2, 0.1, 0.1]).astype(np.int64)
+    cands = []
+    for w in range(nW):
+        cy, cx, row = rng.uniform(3, H - 3), rng.uniform(3, W - 3), []
+        for i in range(f):
+            k = rng.integers(0, 8)
+            if k == 0:
+                row.append(None)
+                continue
+            n = int(rng.integers(1, 4))
+            ms = []
+            for j in range(n):
+                kind = rng.integers(0, 10)
+                if kind == 0:
+                    ms.append(np.ones((H, W), np.float32))                       # > 80 %: resets the frame
+                elif kind == 1:
+                    ms.append(np.zeros((H, W), np.float32))                      # empty: union 0 against an empty previous mask
+                else:
+                    cy += rng.uniform(-1.5, 1.5); cx += rng.uniform(-2.5, 2.5)
+                    r = rng.uniform(2.0, 4.5)
+                    ms.append((((yy - cy) ** 2 + (xx - cx) ** 2) < r * r).astype(np.float32) * rng.choice([1.0, 0.75]))
+            row.append(torch.from_numpy(np.stack(ms).astype(np.float32)))      # (float32 * np.float64 scalar promotes)
+        cands.append(row)
+    pool, off, cnt = [], np.zeros(nW * f, np.int32), np.zeros(nW * f, np.int32)
+    for w in range(nW):
+        for i in range(f):
+            if cands[w][i] is not None:
+                off[w * f + i], cnt[w * f + i] = len(pool), cands[w][i].shape[0]
+                pool.extend(cands[w][i].reshape(-1, HW))
+    pool_d = torch.stack(pool).cuda()
+    eff = torch.full((nW, f, HW), 7.0, device="cuda")
+    idx = torch.full((nW * f,), 99, dtype=torch.int32, device="cuda")
+    off_d, cnt_d, ts_d = (torch.from_numpy(a).cuda() for a in (off, cnt, ts.reshape(-1).copy()))   # named: a temporary's block is reused by the next
+    assert int((off + cnt).max()) <= pool_d.shape[0] and pool_d.dtype == torch.float32 and pool_d.is_contiguous()
+    L.check(lib.moca_sam_select_masks_f32(L.ptr(pool_d), L.ptr(off_d), L.ptr(cnt_d), L.ptr(ts_d), L.ptr(eff), L.ptr(idx), nW, f, HW,
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    idx = idx.cpu().numpy().reshape(nW, f)
+    n_fallback = n_inject = 0
+    for w in range(nW):
+        eff_h, idx_h = s.select_sam_masks(cands[w], ts[w], H, W, "cuda")
+        assert np.array_equal(idx[w], idx_h), f"window {w}: {idx[w]} vs {idx_h}"
+        for i in range(f):
+            if idx_h[i] >= 0:
+                assert torch.equal(eff[w, i], eff_h[i]), f"window {w} frame {i}"
+                n_inject += 1
+                if cands[w][i] is None or not torch.equal(((cands[w][i].reshape(-1, HW) > 0.5).any(0)).float().cuda(), eff_h[i]):
+                    n_fallback += 1
+    assert n_inject >= 10 and n_fallback >= 3          # both the plain and the fallback / reset paths were taken
+
+
+def test_fifo_graph_without_lookahead_reads_anchor_after_write_back(dm):
+    """lookahead_denoising=False: the rank-0 window rewrites queue frame 0 (funcs.py:353-354) before `shift_latents` reads it as the
+    FreeInit anchor (funcs.py:88) -- the engine must fetch the anchor BEHIND the step kernel (with lookahead frame 0 is never
+    rewritten and the pre-UNet gather may fetch it).  Anchor bit-exact, graph loop == host-driven loop."""
+    from moca_video_amd.fifo import fifo_ddim_sampling
+    from moca_video_amd.fifo_graph import FifoEngine
+    from moca_video_amd.sampler import DDIMSampler
+    t = _text()
+    s = DDIMSampler(dm)
+    s.make_schedule(16, ddim_eta=1.0, verbose=False)
+    cond = {"c_crossattn": [t["c1"], t["c2"]], "fps": torch.tensor([10]).cuda()}
+    uc = {"c_crossattn": [t["uc"]], "fps": cond["fps"]}
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    rnd = lambda *shape: torch.randn(*shape, device="cuda", generator=gen)
+    for look, Q in ((False, 16), (True, 20)):
+        args = types.SimpleNamespace(num_inference_steps=16, video_length=8, lookahead_denoising=look, num_partitions=2, new_video_length=10)
+        lat0 = rnd(1, 4, Q, 16, 16)
+        nW = 4 if look else 2
+        noises = [[rnd(1, 4, 8, 16, 16) for _ in range(nW)] for _ in range(3)]
+        shifts = [rnd(1, 4, 16, 16) for _ in range(3)]
+        eng = FifoEngine(args, dm, s, cond, uc, 12.0, lat0.clone(), n_slots=3)
+        for i in range(3):
+            before = eng.latents().clone()
+            eng.step(noise=noises[i], shift_noise=shifts[i])
+            xp, _ = eng.window_outputs()
+            want = before[0, :, 0] if look else xp[-1][0, :, 0]               # rank 0 is the last window in call order
+            assert torch.equal(eng.anchor.view(4, 16, 16), want), f"lookahead={look} iteration {i}: FreeInit anchor"
+        q_graph, em = eng.latents().clone(), eng.emitted_frames(0, 3).clone()
+        eng.close()
+        lat_h = lat0.clone()
+        fr_h = fifo_ddim_sampling(args, dm, cond, (1, 4, 8, 16, 16), s, cfg_scale=12.0, uc_emb=t["uc"], latents=lat_h, n_iterations=3,
+                                  noises=noises, shift_noises=shifts, use_graph=False)
+        assert relerr(q_graph, lat_h) < 2e-2
+        for i in range(3):
+            assert relerr(em[:, :, [i]], fr_h[i]) < 2e-2
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

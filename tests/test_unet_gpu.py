@@ -215,6 +215,32 @@ def test_shared_cfg_prefix_equals_separate_forwards(reduced_model):
     assert relerr(out, ref) < TOL_UNET
 
 
+def test_shared_cfg_prefix_refuses_different_fps(reduced_model):
+    """the shared prefix adds ONE fps embedding to the rows both branches read (conv_in .. the first ResBlock): a per-segment fps
+    list with different entries is refused, and the sampler's guidance falls back to the plain batch, which gives each branch its
+    own fps (== two separate apply_model calls)"""
+    import types
+    from moca_video_amd.sampler import DDIMSampler
+    from moca_video_amd.unet import same_fps
+    x = inp("sp.x", (2, 4, 8, 16, 16)).cuda()
+    c1, c2 = inp("sp.c77", (2, 77, 128)).cuda(), inp("sp.c77", (2, 77, 128)).cuda().flip(0)
+    f1, f2 = torch.tensor([10, 24]).cuda(), torch.tensor([10, 12]).cuda()
+    t = torch.tensor([981, 20]).cuda()
+    assert same_fps([f1, f1.clone()]) and same_fps([16, 16]) and same_fps([8, torch.tensor([8])]) and not same_fps([f1, f2]) and not same_fps([8, 16])
+    with pytest.raises(ValueError):
+        reduced_model.forward_segments(x, t, [c1, c2], fps=[f1, f2], shared_x=True)
+    wrap = types.SimpleNamespace(diffusion_model=reduced_model, conditioning_key="crossattn")
+    model = types.SimpleNamespace(model=wrap, num_timesteps=1000,
+                                  apply_model=lambda x_, t_, c_, **kw: reduced_model(x_, t_, context=torch.cat(c_["c_crossattn"], 1), fps=c_["fps"]))
+    s = DDIMSampler(model)
+    got = s._cfg_eps(x, t, {"c_crossattn": [c1], "fps": f1}, {"c_crossattn": [c2], "fps": f2}, 3.0)
+    e_c, e_u = reduced_model(x, t, context=c1, fps=f1).float(), reduced_model(x, t, context=c2, fps=f2).float()
+    right = e_u + 3.0 * (e_c - e_u)
+    assert relerr(got, right) < 4 * TOL_UNET
+    wrong = reduced_model(x, t, context=c2, fps=f1).float()                         # the unconditional branch with the OTHER fps
+    assert relerr(got, wrong + 3.0 * (e_c - wrong)) > relerr(got, right)
+
+
 def test_forward_concurrent_equals_forward(reduced_model):
     """two forwards launched as separate hipGraphs on separate streams return what forward() returns"""
     g = golden("unet_reduced")
