@@ -38,7 +38,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X dense fp16 MFMA (MI355X_MICROARCH.m
 # doubled per the gfx950 correction in MI355X_MICROARCH.md; Infinity-Cache hits are included in these counters).  The
 # figure is READ from the committed summary of the current kernels -- never a constant in this file -- and the JSON
 # names the file; it is null when no summary for this round exists.
-TRAFFIC_PROFILES = ("profiles/r03_pmc_traffic_per_forward.txt", "profiles/r02_pmc_traffic_per_forward.txt")
+TRAFFIC_PROFILES = ("profiles/r04_pmc_traffic_per_forward.txt", "profiles/r03_pmc_traffic_per_forward.txt")
 
 
 def traffic_from_profile():
@@ -120,21 +120,54 @@ def broadcast_and_verify(module, device, world, rank):
     return info
 
 
-def cpu_baseline(dm, x, ctx, ts, threads, runs=2):
-    """The CPU oracle (fp32 restatement of the reference UNet, oracle/unet_oracle.py) on the host
-    cores: ONE UNet-step at the full [1,4,16,40,64] shape per run (bounded sample, ~20 s each); `runs` timed runs,
-    the minimum is reported (the first run also pages the weights in)."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(dm, x, ctx, ts, threads, runs=3):
+    """The CPU oracle (fp32 restatement of the reference UNet, oracle/unet_oracle.py) on the host cores, SURVEY 8(d) protocol:
+    ONE UNet-step at the full [1,4,16,40,64] shape per run (bounded sample, 15-20 s each), 1 untimed warm-up run (it also pages the
+    weights in) + `runs` timed runs, the MEDIAN is reported."""
     from oracle import unet_oracle as UO
     torch.set_num_threads(threads)
     sd = {k: v.detach().float().cpu() for k, v in dm.model.diffusion_model.state_dict().items()}
     xc, cc, tc = x.float().cpu(), ctx.float().cpu(), ts.cpu()
     times = []
     with torch.no_grad():
+        y = UO.unet_forward(sd, xc, tc, cc, fps=torch.tensor([10]))          # warm-up
         for _ in range(runs):
             t0 = time.perf_counter()
             y = UO.unet_forward(sd, xc, tc, cc, fps=torch.tensor([10]))
             times.append(time.perf_counter() - t0)
-    return min(times), y, times
+    return sorted(times)[len(times) // 2], y, times
+
+
+def plan_flops(plan):
+    """FLOPs the recorded launch sequence of a plan actually EXECUTES (2 M N K of every GEMM / implicit-GEMM launch with its packed,
+    i.e. zero-padded, N and the K it really walks -- 4 C per `Upsample` phase, the shared guidance prefix at half batch -- plus
+    4 Nq Nk d per attention head): what the matrix pipe is busy with, as opposed to the reference's algorithmic count."""
+    from moca_video_amd import ops
+    total = 0.0
+    for st in plan.steps:
+        fn, kw = getattr(st, "func", None), getattr(st, "keywords", {})
+        if fn is ops.gemm:
+            pw = st.args[1]
+            total += 2.0 * kw["M"] * pw.N * pw.K
+            if kw.get("tattn") is not None:                       # + the temporal attention finished in the epilogue
+                T, HW, _ = kw["tattn"]
+                total += 4.0 * kw["M"] * T * 64 * (pw.N // 192)
+        elif fn is ops.attention:
+            total += 4.0 * kw["Bq"] * kw["heads"] * kw["Nq"] * kw["Nk"] * 64
+        elif fn is ops.temporal_attention:
+            total += 4.0 * kw["B"] * kw["HW"] * kw["heads"] * kw["T"] * kw["T"] * 64
+    return total
 
 
 class ZeroDataDenoiser:
@@ -188,7 +221,35 @@ class ZeroDataDenoiser:
         self.u._invalidate()
 
 
-def fifo_leg(dm, device, T, H, W, iters=10):
+def synthetic_sam_candidates(T, H, W):
+    """What a Grounded-SAM-2 producer could return for the frames of window `w` in iteration `i` (the producer is outside the path,
+    SURVEY 8c: masks are synthetic inputs): a box drifting with the queue position, every 7th frame no detection (-> previous
+    masks), every 5th a jump (IoU < 0.5 -> previous masks), every 11th a second small mask.  Built on the host once per shape."""
+    import functools
+
+    @functools.lru_cache(maxsize=None)
+    def box(y0, x0, h, w_):
+        m = torch.zeros(H, W)
+        m[y0 % (H - h):y0 % (H - h) + h, x0 % (W - w_):x0 % (W - w_) + w_] = 1.0
+        return m
+
+    def cands(i, w):
+        out = []
+        for j in range(T):
+            k = i + 8 * w + j                       # ~ the frame's age in the queue
+            if k % 7 == 3:
+                out.append(None)
+            elif k % 5 == 4:
+                out.append(box(k, 3 * k, H // 2, W // 2)[None])
+            elif k % 11 == 0:
+                out.append(torch.stack([box(H // 4 + k // 16, W // 4 + k // 8, H // 2, W // 2), box(2, 2 + k, H // 8, W // 8)]))
+            else:
+                out.append(box(H // 4 + k // 16, W // 4 + k // 8, H // 2, W // 2)[None])
+        return out
+    return cands
+
+
+def fifo_leg(dm, device, T, H, W, iters=10, mode="masks"):
     """Extra (not the headline value): one outer iteration of the MoCA FIFO loop (configs[2-3]) at full size --
     8 diagonal windows x {cond (2 prompts = 154 tokens), uncond (77)} = 16 UNet-steps as ONE batched forward with two context
     segments, + noise, window gather, guidance, the MoCA ddim_step of the 8 windows with mask injection, write-back, emission,
@@ -213,9 +274,20 @@ def fifo_leg(dm, device, T, H, W, iters=10):
     mask = torch.zeros(1, 1, Q, H, W, device=device)
     mask[..., H // 4: 3 * H // 4, W // 4: 3 * W // 4] = 1.0
     cimg = torch.rand(1, 4, 1, H, W, device=device, generator=g)
-    eng = FifoEngine(args, dm, s, cond, uc, 12.0, lat, conditioned_image=cimg, masks=mask, n_slots=8, seed=7)
+    # mode "masks": injection masks handed in (`davis_masks` branch of ddim_step, ddim.py:565-590: factor 1.5 / 1.0, every timestep);
+    # mode "prompt": no masks -> the segmentation branch (ddim.py:592-606 -> :739-903: t <= 300 only, previous-mask / IoU fallbacks,
+    # > 80 % reset, factor 2) on per-iteration candidate masks, bookkeeping on the device inside the same graph
+    sam = synthetic_sam_candidates(T, H, W) if mode == "prompt" else None
+    eng = FifoEngine(args, dm, s, cond, uc, 12.0, lat, conditioned_image=cimg, masks=None if sam else mask, n_slots=8, seed=7,
+                     sam_capacity=2 * 8 * T if sam else 0)
+    nW = eng.nW
+    it = [0]
+
+    def step():
+        eng.step(sam_masks=[sam(it[0], w) for w in range(nW)] if sam else None)
+        it[0] += 1
     for _ in range(3):          # eager, hipGraph capture, first replay
-        eng.step()
+        step()
     torch.cuda.synchronize()
     a, b = C.c_void_p(), C.c_void_p()
     lib.moca_event_create(C.byref(a)); lib.moca_event_create(C.byref(b))
@@ -223,7 +295,7 @@ def fifo_leg(dm, device, T, H, W, iters=10):
     t0 = time.perf_counter()
     lib.moca_event_record(a, h)
     for _ in range(iters):
-        eng.step()
+        step()
     lib.moca_event_record(b, h)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / iters
@@ -233,13 +305,22 @@ def fifo_leg(dm, device, T, H, W, iters=10):
     dt = ms.value * 1e-3 / iters
     finite = bool(torch.isfinite(eng.latents()).all())
     graph_on = eng.plan.graph is not None
-    n_launch = len(eng.plan.steps) - 2 + 12
+    n_launch = len(eng.plan.steps) - 2 + 12 + (1 if sam else 0)
+    injected = int((eng.sam_idx >= 0).sum()) if sam else None
     eng.close()
+    if sam:
+        return {"iteration_ms": round(dt * 1e3, 2), "iteration_wall_ms": round(wall * 1e3, 2), "unet_steps_per_s": round(16 / dt, 2),
+                "one_hipgraph_per_iteration": graph_on, "launches_per_iteration": n_launch, "queue_finite": finite,
+                "window_frames_injected_last_iteration": injected,
+                "note": "PROMPT mode (the reference's default driver mode): no masks handed in, ddim_step takes its segmentation branch "
+                        "(t <= 300 only, previous-mask / IoU < 0.5 fallbacks, > 80 % reset, factor 2) on synthetic per-iteration candidate "
+                        "masks uploaded by the host (pinned double buffer, no sync); bookkeeping + injection inside the same hipGraph"}
     return {"iteration_ms": round(dt * 1e3, 2), "iteration_wall_ms": round(wall * 1e3, 2), "unet_steps_per_iteration": 16,
             "unet_steps_per_s": round(16 / dt, 2), "projected_s_per_video_148_iterations": round(148 * dt, 1),
             "one_hipgraph_per_iteration": graph_on, "launches_per_iteration": n_launch, "queue_finite": finite,
-            "note": "8 windows x (154-token cond + 77-token uncond) as ONE B=16 forward with two context segments; noise, gather, guidance, "
-                    "MoCA ddim_step x 8, write-back, emission, FreeInit mix, shift in the same hipGraph; VAE decode excluded"}
+            "note": "synthetic zero-data weights (ZeroDataDenoiser); injection masks handed in (`masks=`: the davis_masks branch of "
+                    "ddim_step); 8 windows x (154-token cond + 77-token uncond) as ONE B=16 forward with two context segments; noise, "
+                    "gather, guidance, MoCA ddim_step x 8, write-back, emission, FreeInit mix, shift in the same hipGraph; VAE decode excluded"}
 
 
 def video_leg(dm, ae, device, T, H, W):
@@ -263,9 +344,6 @@ def video_leg(dm, ae, device, T, H, W):
     g = torch.Generator(device=device).manual_seed(9)
     c1, c2, uc_emb = (torch.randn(1, 77, 1024, device=device, generator=g) for _ in range(3))
     fps = torch.tensor([10], device=device)
-    Q = 64 + T // 2
-    mask = torch.zeros(1, 1, Q, H, W, device=device)
-    mask[..., H // 4: 3 * H // 4, W // 4: 3 * W // 4] = 1.0
     cimg = torch.rand(1, 4, 1, H, W, device=device, generator=g)
     shape = [1, 4, T, H, W]
     torch.cuda.synchronize()
@@ -274,8 +352,11 @@ def video_leg(dm, ae, device, T, H, W):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     lat = prepare_latents(args, None, sampler, initial_latents=samples)
+    # prompt mode, as videocrafter_main.py drives it: no masks -> ddim_step's segmentation branch on candidate masks (synthetic: the
+    # Grounded-SAM-2 producer is outside the path), inside the iteration graph
     frames = fifo_ddim_sampling(args, dm, {"c_crossattn": [c1, c2], "fps": fps}, shape, sampler, cfg_scale=12.0, uc_emb=uc_emb,
-                                latents=lat, conditioned_image=cimg, masks=mask, decode=True, batch_windows=True, seed=9)
+                                latents=lat, conditioned_image=cimg, sam_masks=synthetic_sam_candidates(T, H, W), sam_capacity=2 * 8 * T,
+                                decode=True, batch_windows=True, seed=9)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     n_finite = sum(int(bool(torch.isfinite(f).all())) for f in frames)
@@ -286,10 +367,11 @@ def video_leg(dm, ae, device, T, H, W):
     res = {"video_s": round(t2 - t0, 2), "base_sampling_s": round(t1 - t0, 2), "fifo_148_iterations_incl_decode_s": round(t2 - t1, 2),
            "unet_steps": 2 * 64 + 148 * 16, "frames_decoded": 16 + 148, "frames_emitted": len(frames),
            "frame_shape": list(frames[0].shape), "frames_finite": n_finite, "base_latents_finite": bool(torch.isfinite(samples).all()),
-           "note": "measured, one prompt, 1 GPU: 64 CFG base steps + prepare_latents + 148 FIFO iterations (one hipGraph each: 8 batched "
-                   "windows, 154-token cond / 77-token uncond, mask injection, FreeInit shift; engine construction + capture included) + "
-                   "VAE decode of every emitted frame; random-init weights with 9 tensors set so that the UNet is the exact denoiser of "
-                   "an all-zero dataset (bounded MoCA momentum dynamics: see ZeroDataDenoiser)"}
+           "note": "synthetic zero-data weights (random-init with 9 tensors set so that the UNet is the exact denoiser of an all-zero "
+                   "dataset: bounded MoCA momentum dynamics, see ZeroDataDenoiser; operand statistics, hence clocks, are not those of a "
+                   "trained model); measured, one prompt, 1 GPU, PROMPT mode: 64 CFG base steps + prepare_latents + 148 FIFO iterations "
+                   "(one hipGraph each: 8 batched windows, 154-token cond / 77-token uncond, segmentation-branch injection on synthetic "
+                   "candidate masks, FreeInit shift; engine construction + capture included) + VAE decode of every emitted frame"}
     assert n_finite == len(frames) and res["base_latents_finite"], f"non-finite frames in the measured video: {res}"
     return res
 
@@ -587,6 +669,8 @@ def main():
     name, cus = mlib.device_info()
     traffic_bytes, traffic_src = traffic_from_profile()
     n_launches = max([len(pl.steps) for pl in plans] or [0])
+    executed = plan_flops(plans[0]) if plans else 0.0
+    executed_rate = executed / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 and not concurrent else 0.0
     res = {
         "metric": "denoising UNet-steps/sec @16x320x512 fp16",
         "value": round(value, 3),
@@ -614,11 +698,16 @@ def main():
         "achieved_tflops": round(value / world * FLOP_PER_UNET_STEP / 1e12, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic_bytes if not concurrent else None, "traffic_source": traffic_src if not concurrent else None,
-                     "kernel": "UNet forward launch sequence (hipGraph of %d launches; the implicit-GEMM conv/linear kernels "
-                               "gemm_w80s/gemm_glds/gemm_g4 are 80%% of its kernel time, "
-                               "profiles/r03_bench_kernel_stats_summary.txt)" % n_launches +
+                     "kernel": ("the whole DDIM-step hipGraph (%d launches: timestep rows + device noise + the UNet forward + guidance / "
+                                "DDIM update; the implicit-GEMM conv/linear kernels gemm_w80s/gemm_glds/gemm_g4 are 80%% of its kernel "
+                                "time, profiles/r04_bench_kernel_stats_summary.txt)" if engines is not None else
+                                "UNet forward launch sequence (hipGraph of %d launches)") % n_launches +
                                (", two B=1 graphs on two streams" if concurrent else ", batch %d" % (2 * batches[0]["n"])),
-                     "flop_per_launch": flop_per_launch, "avg_launch_ms": round(avg_launch_ms, 3), "launches": len(unet_ms)},
+                     "flop_per_launch": flop_per_launch, "avg_launch_ms": round(avg_launch_ms, 3), "launches": len(unet_ms),
+                     # `achieved` / `frac` price the reference's ALGORITHMIC FLOPs.  The launch sequence executes fewer: the
+                     # two guidance branches share everything before the first cross-attention and `Upsample` runs as four 2x2 convs
+                     "executed_flop_per_launch": executed, "executed_tflops": round(executed_rate, 2),
+                     "frac_executed": round(executed_rate / PEAK_F16_MFMA_TFLOPS, 4)},
     }
     if multi is not None:
         res["multi_gpu"] = multi
@@ -631,6 +720,7 @@ def main():
     if world == 1 and not args.no_fifo:
         zdd = ZeroDataDenoiser(dm)
         res["fifo"] = fifo_leg(dm, device, T, H, W)
+        res["fifo_prompt_mode"] = fifo_leg(dm, device, T, H, W, mode="prompt")
         res["vae_decode"], ae = vae_leg(device, H, W)
         res["fifo"]["projected_s_per_video_incl_vae_decode"] = round(
             res["fifo"]["projected_s_per_video_148_iterations"] + res["vae_decode"]["s_per_video_148_frames"], 1)
@@ -645,8 +735,9 @@ def main():
         y_gpu = dm.apply_model(x, ts, cond).float().cpu()
         err = ((y_gpu - y_cpu).abs().max() / y_cpu.abs().max()).item()
         res["cpu_baseline"] = {"value": round(1.0 / cdt, 5), "unit": "UNet-steps/s", "cores": threads, "kind": "port",
-                               "sample": "1 UNet-step (fp32 oracle of the reference UNet, [1,4,%d,%d,%d], same weights/inputs), "
-                                         "min of %d runs (%s s); HIP-vs-oracle max rel err %.2e" % (T, H, W, len(ctimes), "/".join("%.1f" % c for c in ctimes), err)}
+                               "cpu_model": cpu_model_name(), "cpus_online": os.cpu_count(),
+                               "sample": "1 UNet-step (fp32 oracle of the reference UNet, [1,4,%d,%d,%d], same weights/inputs) per run; "
+                                         "1 warm-up + %d timed runs (%s s), median; HIP-vs-oracle max rel err %.2e" % (T, H, W, len(ctimes), "/".join("%.1f" % c for c in ctimes), err)}
     print(json.dumps(res))
 
 

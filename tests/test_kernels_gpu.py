@@ -598,6 +598,23 @@ def test_concat_with_groupnorm_statistics(Fr, HW, C1, C2):
     ops.groupnorm_gstat(out, y, g, be, gst, F=Fr, HW=HW, Cn=C, frames_per_stat=1, eps=1e-5, silu=True)
     gref = F.silu(F.group_norm(ref.float().view(Fr, HW, C).permute(0, 2, 1), 32, g, be, 1e-5)).permute(0, 2, 1).reshape(Fr * HW, C)
     check(y, gref, TOL16, "groupnorm of the concatenation")
+    # non-finite activations must poison their statistics group (the fixed-point accumulators cannot hold NaN / Inf: a poison bit
+    # does): one NaN and, separately, one Inf in frame 1 / channel group of column 5 -> that group's outputs are all NaN, every
+    # other (frame, group) is untouched
+    cpg = C // 32
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        a2 = a.clone()
+        a2[HW + 3, 5] = bad
+        gst.zero_()
+        ops.concat_channels_gstat(a2, b, out, gst, F=Fr, HW=HW, C1=C1, C2=C2, frames_per_stat=1)
+        ops.groupnorm_gstat(out, y, g, be, gst, F=Fr, HW=HW, Cn=C, frames_per_stat=1, eps=1e-5, silu=True)
+        yv = y.view(Fr, HW, 32, cpg)
+        gi = 5 // cpg
+        assert torch.isnan(yv[1, :, gi]).all(), f"{bad}: the poisoned group must come out NaN"
+        keep = torch.ones(Fr, 32, dtype=torch.bool, device=DEV)
+        keep[1, gi] = False
+        assert torch.equal(yv.permute(0, 2, 1, 3)[keep], gref.view(Fr, HW, 32, cpg).permute(0, 2, 1, 3)[keep].to(y.dtype)) or \
+            relerr(yv.permute(0, 2, 1, 3)[keep], gref.view(Fr, HW, 32, cpg).permute(0, 2, 1, 3)[keep]) < TOL16
 
 
 # ---------------------------------------------------------------- q|k|v projection + temporal attention in one launch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the replayed UNet graph loses time against the same launches replayed hot in isolation.
 Inputs: two rocprofv3 --kernel-trace CSVs -- (1) `bench.py --steps 3 ...` (the graph), (2) `tools/plan_profile.py 2` (every
-recorded launch 1 + 5 times back to back, operands cache resident).  Kernels are keyed by (name, grid, workgroup); for the
+recorded launch 1 + 5 times back to back FROM ITS TRUE OPERANDS: snapshot / restore, see plan_profile.py).  Kernels are keyed by (name, grid, workgroup); for the
 graph the LAST complete forward is taken, for the isolated run the mean over the replays of a key.
     python tools/ingraph_vs_hot.py graph_kernel_trace.csv hot_kernel_trace.csv"""
 import collections
@@ -38,11 +38,13 @@ for s, e, n, grid, wg in fw:
     k = (short(n), grid, wg)
     gk[k][0] += e - s
     gk[k][1] += 1
-hk = collections.defaultdict(lambda: [0, 0])
+# isolated run (tools/plan_profile.py, true-operand mode): per key, every step instance contributes 1 in-sequence launch (the eager
+# pass that produces the operand snapshots) + 1 warm-up + REP timed launches from restored operands -> the MEDIAN duration of a key is
+# an isolated, warm, true-operand launch
+hd = collections.defaultdict(list)
 for s, e, n, grid, wg in h:
-    k = (short(n), grid, wg)
-    hk[k][0] += e - s
-    hk[k][1] += 1
+    hd[(short(n), grid, wg)].append(e - s)
+hk = {k: [sorted(v)[len(v) // 2], 1] for k, v in hd.items()}
 rows = []
 tot_g = tot_h = 0.0
 missing = 0
