@@ -508,6 +508,8 @@ def main():
     ap.add_argument("--step-mode", default="graph", choices=["graph", "host"],
                     help="graph: one hipGraph per DDIM step (timestep, UNet, noise, guidance + update: what DDIMSampler.sample runs); "
                          "host: p_sample_ddim per step (UNet graph + four small launches issued by the host)")
+    ap.add_argument("--no-weight-prefetch", action="store_true",
+                    help="A/B: do not stream the next weight-heavy launch's weights into the Infinity Cache on a side stream")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--height", type=int, default=40)
@@ -541,6 +543,7 @@ def main():
     if world > 1:
         multi = broadcast_and_verify(dm.model.diffusion_model, device, world, rank)     # C1 (RCCL over xGMI) + checksum proof
     unet = dm.model.diffusion_model
+    unet.weight_prefetch = not args.no_weight_prefetch
     sampler = DDIMSampler(dm)
     sampler.cfg_mode = args.cfg_mode
     sampler.share_prefix = not args.no_shared_prefix
@@ -693,7 +696,7 @@ def main():
                    "unet_steps_per_step": 2 * n_prompts, "context_tokens": 77, "weights": "random-init, 1.41B params, fp16 packed" +
                    ("" if world == 1 else "; materialised on rank 0 only, RCCL broadcast (C1), checksums all-gathered"),
                    "parallelism": f"dp{world} (independent prompts, no collective in the loop)",
-                   "hipgraph_replay": graph_on, "cfg_mode": args.cfg_mode, "cfg_shared_prefix": sampler.share_prefix and args.cfg_mode == "batched", "step_mode": "graph" if engines is not None else "host", "device": name, "compute_units": cus, "output_finite": finite,
+                   "hipgraph_replay": graph_on, "cfg_mode": args.cfg_mode, "cfg_shared_prefix": sampler.share_prefix and args.cfg_mode == "batched", "weight_prefetch": unet.weight_prefetch, "step_mode": "graph" if engines is not None else "host", "device": name, "compute_units": cus, "output_finite": finite,
                    "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
         "achieved_tflops": round(value / world * FLOP_PER_UNET_STEP / 1e12, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",

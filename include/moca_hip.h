@@ -386,6 +386,13 @@ int moca_graph_begin(void* stream);
 int moca_graph_end(void* stream, void** graph_exec_out);
 int moca_graph_launch(void* graph_exec, void* stream);
 int moca_graph_destroy(void* graph_exec);
+/* Weight prefetch on a side stream (no reference counterpart: a property of replaying 2.83 GB of weights per forward through a 256 MB
+ * memory-side cache).  moca_prefetch_fork: `side_stream` waits for everything enqueued on `main_stream` so far, then a small read-only
+ * kernel streams [ptr, ptr + bytes) through L2 into the Infinity Cache, concurrently with whatever `main_stream` runs next; `sink`
+ * (normally NULL) receives the xor of all 32-bit words (tests).  moca_stream_join: `main_stream` waits for `side_stream` (once per
+ * forward; required before the end of a stream capture that forked).  Both are capture-safe: they become graph dependencies. */
+int moca_prefetch_fork(const void* ptr, int64_t bytes, uint32_t* sink, void* main_stream, void* side_stream);
+int moca_stream_join(void* side_stream, void* main_stream);
 /* own non-blocking stream (so capture never touches the caller's default stream) */
 int moca_stream_create(void** stream_out);
 int moca_stream_destroy(void* stream);

@@ -121,6 +121,8 @@ SIGNATURES = {
     "moca_graph_end": (C.c_int, [_vp, C.POINTER(_vp)]),
     "moca_graph_launch": (C.c_int, [_vp, _vp]),
     "moca_graph_destroy": (C.c_int, [_vp]),
+    "moca_prefetch_fork": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "moca_stream_join": (C.c_int, [_vp, _vp]),
     "moca_stream_create": (C.c_int, [C.POINTER(_vp)]),
     "moca_stream_destroy": (C.c_int, [_vp]),
     "moca_stream_sync": (C.c_int, [_vp]),

@@ -285,6 +285,17 @@ def concat_channels_gstat(a, b, out, gstat, *, F, HW, C1, C2, frames_per_stat):
     return out
 
 
+def prefetch_fork(t, side_stream, sink=None):
+    """stream tensor `t` (the next weight-heavy launch's weights) through L2 into the Infinity Cache on `side_stream`, concurrently
+    with what the current stream runs next (moca_prefetch_fork)"""
+    _l.check(_l.load().moca_prefetch_fork(_l.ptr(t), t.numel() * t.element_size(), _l.ptr(sink), _st(), C.c_void_p(side_stream)),
+             "moca_prefetch_fork")
+
+
+def stream_join(side_stream):
+    _l.check(_l.load().moca_stream_join(C.c_void_p(side_stream), _st()), "moca_stream_join")
+
+
 def memset_zero(t):
     _l.check(_l.load().moca_memset_zero(_l.ptr(t), t.numel() * t.element_size(), _st()), "moca_memset_zero")
     return t

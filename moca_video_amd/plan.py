@@ -53,6 +53,26 @@ def gemm_splits(M, pw):
     return max(1, min(cap, nk // 8))
 
 
+PREFETCH_MIN_BYTES = 4 << 20     # weights of a launch worth warming the memory-side cache for (the 640- / 1280-channel levels)
+
+
+class _StepWithPrefetch:
+    """a recorded launch in front of which the weights of LATER weight-heavy launches are sent to the memory-side cache on the
+    plan's side stream (ops.prefetch_fork); looks like the launch it wraps (func / args / keywords) to the profiling tools"""
+    __slots__ = ("inner", "plan", "weights", "func", "args", "keywords")
+
+    def __init__(self, inner, plan, weights):
+        self.inner, self.plan, self.weights = inner, plan, weights
+        self.func, self.args, self.keywords = inner.func, inner.args, inner.keywords
+
+    def __call__(self):
+        if self.plan.prefetch_on:
+            for w in self.weights:
+                ops.prefetch_fork(w, self.plan.side_stream())
+            self.plan._forked = True
+        self.inner()
+
+
 class _LNRef:
     """a LayerNorm that exists only as statistics: x (fp16 [M][C]) + the row partial sums its producer left behind
     (f32 [nparts][M][2]); consumed by a MOCA_EP_LNFOLD GEMM"""
@@ -79,6 +99,30 @@ class _PlanBase:
         self._gstat_buf, self._gstat_used, self._last_gemm_step = None, 0, None
         self._gstat_full = []
         self.reps = 1            # > 1: the batch is `reps` context variants of the same Bx latents (_Plan: shared prefix)
+        self._side = None        # side stream of the weight prefetches (created on first use)
+        self._forked = False
+        self._prefetch_at = {}   # during the build: index of a recorded GEMM step -> weights of later launches to prefetch in front of it
+        self.prefetch_on = getattr(model, "weight_prefetch", True)
+
+    def side_stream(self):
+        if self._side is None:
+            h = C.c_void_p()
+            _l.check(_l.load().moca_stream_create(C.byref(h)), "moca_stream_create")
+            self._side = h.value
+        return self._side
+
+    def _note_gemm(self, pw):
+        """called right before a GEMM step is recorded: weight-heavy -> its weights are prefetched in front of the PREVIOUS GEMM launch
+        (they then stream into the Infinity Cache while that launch computes; the small launches in between do not matter)"""
+        if self._last_gemm_step is not None and pw.w.numel() * pw.w.element_size() >= PREFETCH_MIN_BYTES:
+            self._prefetch_at.setdefault(self._last_gemm_step, []).append(pw.w)
+        self._last_gemm_step = len(self.steps)
+
+    def _finish_prefetch(self):
+        """end of the build (every re-targeting of recorded steps is done): wrap the host launches"""
+        for j, ws in self._prefetch_at.items():
+            self.steps[j] = _StepWithPrefetch(self.steps[j], self, ws)
+        self._prefetch_at = {}
 
     def close(self):
         """release the instantiated hipGraph (moca_graph_destroy); the plan falls back to eager launches if used again"""
@@ -125,7 +169,7 @@ class _PlanBase:
             rows = ops.gemm_colsum_rows(a, pw, M=M, splits=splits, **kw)
             if rows > 0:
                 cs = (self.pool.get((M + rows - 1) // rows, 2 * pw.N, torch.float32), rows)
-        self._last_gemm_step = len(self.steps)
+        self._note_gemm(pw)
         self._emit(ops.gemm, a, pw, out, M=M, splits=splits, splitk_ws=ws, colsum=None if cs is None else cs[0], **kw)
         if ws is not None:
             self.pool.put(ws)
@@ -158,6 +202,7 @@ class _PlanBase:
             return self.conv(fm, self.P[id(conv)], up=1)
         out = self.pool.get(4 * M, phases[0].N)
         for ph, pw in enumerate(phases):
+            self._note_gemm(pw)
             self._emit(ops.gemm, fm.buf, pw, out, M=M, mode=_l.MOCA_A_CONV3X3, conv=(fm.C, fm.H, fm.W, fm.H, fm.W, 1, 0), splits=1,
                        up_phase=ph + 1)
         return _FMap(out, fm.F, fm.H * 2, fm.W * 2, phases[0].N, None)
@@ -235,6 +280,9 @@ class _PlanBase:
             ops.memset_zero(self._gstat_buf[:self._gstat_used])
         for s in self.steps:
             s()
+        if self._forked:                      # the side stream of the weight prefetches rejoins (required inside a capture)
+            ops.stream_join(self.side_stream())
+            self._forked = False
 
     def _launch(self, handle):
         lib = _l.load()
@@ -361,6 +409,7 @@ class _Plan(_PlanBase):
         if isinstance(l, _LNRef):
             pwf = fold_pw()
             out = self.pool.get(M, pwf.n_out if pwf.geglu else pwf.N)
+            self._note_gemm(pwf)
             self._emit(ops.gemm, l.x, pwf, out, M=M, lda=l.x.stride(-2), splits=1, lnfold=(l.part, l.nparts, 1e-5))
             return out
         return self.linear(l, M, pw)
@@ -401,6 +450,7 @@ class _Plan(_PlanBase):
         if not ops.gemm_tattn_ok(x, pw, lnfold=(None, l.nparts, 1e-5) if folded else None, **kw):
             return None
         o = self.pool.get(M, Cn)
+        self._note_gemm(pw)
         self._emit(ops.gemm, x, pw, o, lnfold=(l.part, l.nparts, 1e-5) if folded else None, **kw)
         return o
 
@@ -475,10 +525,12 @@ class _Plan(_PlanBase):
                         self._splits(M, pwf) == 1:
                     out = self.pool.get(M, pw.N)
                     part = self.pool.get(nparts * M, 2, torch.float32)
+                    self._note_gemm(pw)
                     self._emit(ops.gemm, a, pw, out, M=M, lda=lda, residual=residual, splits=1, rowsum=part)
                     return out, _LNRef(out, part, nparts)
         if ln_epilogue:
             out, l = self.pool.get(M, pw.N), self.pool.get(M, pw.N)
+            self._note_gemm(pw)
             self._emit(ops.gemm, a, pw, out, M=M, lda=lda, residual=residual, splits=1, ln=(gb[0], gb[1], l, 1e-5))
             return out, l
         out = self.linear(a, M, pw, residual=residual)
@@ -641,6 +693,7 @@ class _Plan(_PlanBase):
         self._release(g)
         self._emit(ops.nhwc_to_ncthw, o.buf, o.C, self.out, B=B, Cout=m.out_channels, T=T, HW=H * W)
         self._release(o.buf)
+        self._finish_prefetch()
 
     def set_context(self, context):
         """context [B, L, D], or one [n_i, L_i, D] tensor per segment"""

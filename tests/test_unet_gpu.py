@@ -241,6 +241,51 @@ def test_shared_cfg_prefix_refuses_different_fps(reduced_model):
     assert relerr(got, wrong + 3.0 * (e_c - wrong)) > relerr(got, right)
 
 
+def test_weight_prefetch_reads_everything_and_changes_nothing():
+    """moca_prefetch_fork: the side-stream kernel reads every 16-byte chunk of the range (xor checksum against torch, ragged tail
+    left out as documented: whole chunks only) and the main stream is ordered behind it by moca_stream_join; a UNet forward with the
+    prefetches (eager, captured, replayed) is bit-identical to one without (they only move weights into the memory-side cache)"""
+    import ctypes as C
+    from moca_video_amd import UNetModel, lib as L
+    from moca_video_amd import plan as P
+    lib = L.load()
+    side = C.c_void_p()
+    L.check(lib.moca_stream_create(C.byref(side)))
+    main = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n in (4 * 1024 * 1024 + 12, 1000):
+        w = torch.randint(-2 ** 31, 2 ** 31 - 1, (n,), dtype=torch.int32, device="cuda")
+        sink = torch.zeros(1, dtype=torch.int32, device="cuda")
+        L.check(lib.moca_prefetch_fork(L.ptr(w), n * 4, L.ptr(sink), main, side))
+        L.check(lib.moca_stream_join(side, main))
+        ref = w[:n // 4 * 4].cpu().numpy().view(np.uint32)
+        assert int(sink.cpu().numpy().view(np.uint32)[0]) == int(np.bitwise_xor.reduce(ref))
+    assert lib.moca_prefetch_fork(L.ptr(w), 0, None, main, side) == -1 and lib.moca_prefetch_fork(L.ptr(w), 64, None, main, main) == -1
+    L.check(lib.moca_stream_destroy(side))
+    # whole forward: a width at which some launches carry >= PREFETCH_MIN_BYTES of weights
+    cfg = dict(REDUCED, model_channels=128, context_dim=128)
+    x = inp("pf.x", (2, 4, 8, 16, 16)).cuda()
+    ctx = inp("pf.ctx", (2, 77, 128)).cuda()
+    t = torch.tensor([700, 30]).cuda()
+    outs = []
+    old_min = P.PREFETCH_MIN_BYTES
+    try:
+        P.PREFETCH_MIN_BYTES = 1 << 20
+        for on in (True, False):
+            m = UNetModel(**cfg)
+            m.load_state_dict(state_dict_for(m, 3), strict=True)
+            m = m.cuda()
+            m.weight_prefetch = on
+            ys = [m(x, t, context=ctx, fps=torch.tensor([8, 8]).cuda()) for _ in range(3)]
+            plan = next(iter(m._plans.values()))
+            n_pf = sum(len(s.weights) for s in plan.steps if isinstance(s, P._StepWithPrefetch))
+            assert n_pf > 10 and plan.graph is not None
+            assert torch.equal(ys[0], ys[1]) and torch.equal(ys[1], ys[2])
+            outs.append(ys[2])
+    finally:
+        P.PREFETCH_MIN_BYTES = old_min
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
+
+
 def test_forward_concurrent_equals_forward(reduced_model):
     """two forwards launched as separate hipGraphs on separate streams return what forward() returns"""
     g = golden("unet_reduced")
