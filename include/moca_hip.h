@@ -98,7 +98,7 @@ typedef struct moca_gemm_params {
     int32_t nopad_lo;      /* A_CONV3X3, stride 2: 1 = no padding at the top/left, one row/column at the
                               bottom/right (F.pad(x,(0,1,0,1)) + conv pad 0: ae_modules.py Downsample.forward);
                               0 = the symmetric padding 1 of every other 3x3 conv                              */
-    int32_t reserved_;
+    int32_t prefetch_kib;  /* size of `prefetch` in KiB (0: none) */
     float*      colsum;    /* MOCA_EP_COLSUM: f32 [ceil(M/rows)][N][2] = (sum, sum of squares) over the rows of each
                               row tile (rows = moca_gemm_colsum_rows()), of the values as stored (after bias / row add /
                               residual, before the fp16 rounding)                                                      */
@@ -118,7 +118,11 @@ typedef struct moca_gemm_params {
                               (statistics group, GroupNorm channel group of N / 32 columns)                             */
     int32_t     gstat_rows;/* rows per statistics group (frames_per_stat * H*W of the consumer's GroupNorm)             */
     float       tattn_scale;/* MOCA_EP_TATTN: softmax scale (dim_head ** -0.5); frames / pixels per frame in T / HW     */
-    void*       reserved5_;
+    const void* prefetch;  /* optional, no effect on results: [prefetch, prefetch + prefetch_kib KiB) -- the weights of the NEXT weight-heavy
+                              launch -- is read once by a few EXTRA blocks of this launch's grid (the direct-to-LDS kernels), which land on
+                              the CUs the launch leaves idle (200-250 tiles on 256 CUs at the 640- / 1280-channel levels) or on its tail, so
+                              that the next launch finds its W in the 256 MB Infinity Cache instead of HBM (inside a replayed forward every
+                              weight is a first-touch read: 2.83 GB per forward).  16-byte aligned.                               */
     int32_t     up_phase;  /* MOCA_A_CONV3X3 only.  0: the 3x3 conv.  1 + 2a + b (a, b in {0, 1}): phase (a, b) of `Upsample` =
                               F.interpolate(nearest, x2) + conv3x3 (openaimodel3d.py:96-106) as a 2 x 2 conv on the LOW-resolution grid:
                               out[f][2i+a][2j+b] = bias + sum_{r,s in {0,1}} Wp[r][s] . in[f][i+a-1+r][j+b-1+s], Wp = the 3x3 taps that
@@ -386,13 +390,6 @@ int moca_graph_begin(void* stream);
 int moca_graph_end(void* stream, void** graph_exec_out);
 int moca_graph_launch(void* graph_exec, void* stream);
 int moca_graph_destroy(void* graph_exec);
-/* Weight prefetch on a side stream (no reference counterpart: a property of replaying 2.83 GB of weights per forward through a 256 MB
- * memory-side cache).  moca_prefetch_fork: `side_stream` waits for everything enqueued on `main_stream` so far, then a small read-only
- * kernel streams [ptr, ptr + bytes) through L2 into the Infinity Cache, concurrently with whatever `main_stream` runs next; `sink`
- * (normally NULL) receives the xor of all 32-bit words (tests).  moca_stream_join: `main_stream` waits for `side_stream` (once per
- * forward; required before the end of a stream capture that forked).  Both are capture-safe: they become graph dependencies. */
-int moca_prefetch_fork(const void* ptr, int64_t bytes, uint32_t* sink, void* main_stream, void* side_stream);
-int moca_stream_join(void* side_stream, void* main_stream);
 /* own non-blocking stream (so capture never touches the caller's default stream) */
 int moca_stream_create(void** stream_out);
 int moca_stream_destroy(void* stream);

@@ -47,6 +47,30 @@ __device__ __forceinline__ void remap_tile_2d(int tiles_m, int tiles_n, int xn, 
     tile_n = xj * sn + j % sn;
 }
 
+// Blocks nblk .. gridDim.x - 1 of a launch with p.prefetch: no tile, they read the next weight-heavy launch's weights once (plain
+// 16-byte loads, 8 in flight per lane; the values are dropped) so that those lines sit in the Infinity Cache when that launch asks
+// for them.  They are dispatched after every tile block, i.e. onto the CUs this launch leaves idle or onto its tail.
+constexpr int PREFETCH_BLOCKS = 24;
+__device__ __forceinline__ bool prefetch_block(const moca_gemm_params& p, int nblk, int nthreads) {
+    if ((int)blockIdx.x < nblk) return false;
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(p.prefetch);
+    const int64_t n16 = (int64_t)p.prefetch_kib << 6;
+    const int64_t stride = (int64_t)((int)gridDim.x - nblk) * nthreads;
+    int64_t i = (int64_t)((int)blockIdx.x - nblk) * nthreads + threadIdx.x;
+    unsigned acc = 0;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        uint4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[i + j * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+    }
+    for (; i < n16; i += stride) { const uint4 v = src[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    asm volatile("" :: "v"(acc));                     // keeps the loads; nothing is stored
+    return true;
+}
+static inline int prefetch_blocks(const moca_gemm_params& p) { return (p.prefetch && p.prefetch_kib > 0) ? PREFETCH_BLOCKS : 0; }
+
 template <int BN>
 __device__ __forceinline__ void remap_block(int nblk, int& logical) {
     // XCD-aware bijective remap: physical blocks b, b+8, b+16, ... share an XCD (L2);
@@ -1043,6 +1067,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     int split, tile, kt_begin, kt_end;
     {
         const int nblk = tiles_m * tiles_n * p.splits;
+        if (prefetch_block(p, nblk, 512)) return;
         int logical;
         remap_block<BN>(nblk, logical);
         split = logical % p.splits;
@@ -1368,6 +1393,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     const int tiles_m = (p.M + TM - 1) / TM;
     const int tiles_n = p.N / BN;
     const int nblk = tiles_m * tiles_n * p.splits;
+    if (prefetch_block(p, nblk, 256)) return;
     int split = 0, tile_m, tile_n;
     if ((p.reserved4_ >> 8) > 1) {                       // 2-D XCD partition (see remap_tile_2d)
         remap_tile_2d(tiles_m, tiles_n, p.reserved4_ >> 8, tile_m, tile_n);
@@ -1628,6 +1654,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     const int tiles_m = (p.M + TM - 1) / TM;
     const int tiles_n = p.N / BN;
     const int nblk = tiles_m * tiles_n * p.splits;
+    if (prefetch_block(p, nblk, 512)) return;
     int split = 0, tile_m, tile_n;
     const int xcd_n = p.reserved4_ >> 8;                 // > 1: 2-D XCD partition (host: splits == 1, both tile counts divide)
     if (xcd_n > 1) {
@@ -2007,7 +2034,7 @@ int launch_gemm_w80s(const moca_gemm_params& p, hipStream_t st) {
             return MOCA_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_w80s_kernel<AMODE, SHAPE>), dim3(nblk), dim3(512), lds, st, pl);
+    hipLaunchKernelGGL((gemm_w80s_kernel<AMODE, SHAPE>), dim3(nblk + prefetch_blocks(pl)), dim3(512), lds, st, pl);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
@@ -2088,7 +2115,7 @@ int launch_gemm_g4(const moca_gemm_params& p, hipStream_t st) {
     }
     moca_gemm_params pl = p;
     pl.reserved4_ = (pl.reserved4_ & 0xff) | (choose_xcd_n(p, tiles_m, tiles_n, 256, 128) << 8);
-    hipLaunchKernelGGL((gemm_g4_kernel<AMODE, FAST>), dim3(nblk), dim3(256), lds, st, pl);
+    hipLaunchKernelGGL((gemm_g4_kernel<AMODE, FAST>), dim3(nblk + 2 * prefetch_blocks(pl)), dim3(256), lds, st, pl);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
@@ -2107,7 +2134,7 @@ int launch_gemm_glds(const moca_gemm_params& p, hipStream_t st) {
             return MOCA_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<BN, AMODE, FAST>), dim3(nblk), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_glds_kernel<BN, AMODE, FAST>), dim3(nblk + prefetch_blocks(p)), dim3(512), lds, st, p);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
@@ -2248,6 +2275,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     if (geglu && p.N % 128) return MOCA_E_BADARG;
     if (p.ldo % 8 || (p.residual && p.ldr % 8) || (p.rowadd && (p.ld_rowadd % 8 || p.rowadd_div <= 0))) return MOCA_E_BADARG;
     if (p.splits > 1 && !p.splitk_ws) return MOCA_E_BADARG;
+    if (p.prefetch_kib < 0 || (p.prefetch_kib > 0 && (!p.prefetch || (reinterpret_cast<uintptr_t>(p.prefetch) & 15)))) return MOCA_E_BADARG;
     // the plain-GELU epilogue (CLIP text MLP) exists in the 128-row kernel only
     if ((p.flags & MOCA_EP_GELU) && (geglu || p.splits != 1 || !((p.flags & MOCA_FORCE_SMALL_TILE) || p.M <= 128))) return MOCA_E_BADARG;
     normalise_splits(p);

@@ -104,63 +104,6 @@ extern "C" int moca_memset_zero(void* ptr, int64_t bytes, void* stream) {
     return MOCA_OK;
 }
 
-// ---- warm the memory-side cache with the NEXT weight-heavy launch's weights while the current launch computes ---------------
-// Inside a replayed forward every weight is a first-touch HBM read: the 2.83 GB of fp16 weights do not survive a forward in the
-// 256 MB Infinity Cache, and the launches of the 640- / 1280-channel levels (10-60 MB of weights each, few rows) wait for them
-// (same launch, weights resident vs not: 3-20 us, profiles/r03_ab_weight_prefetch.txt; in-graph vs isolated: profiles/r04_*).
-// A small read-only kernel on a SIDE stream, forked in front of the previous GEMM launch and joined at the end of the forward,
-// streams the next launch's weights through L2 into the Infinity Cache while the matrix pipe is busy with the current launch (a
-// few dozen 256-thread blocks without LDS: they share CUs with the GEMM's one 512-thread block per CU).  Nothing is written;
-// the kernel has no effect on results -- only on where the next launch finds its W.
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, int64_t n16, unsigned* __restrict__ sink) {
-    uint4 acc = {0u, 0u, 0u, 0u};
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 7 * stride < n16; i += 8 * stride) {              // 8 independent 16-byte loads in flight per lane
-        uint4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = p[i + j * stride];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { acc.x ^= v[j].x; acc.y ^= v[j].y; acc.z ^= v[j].z; acc.w ^= v[j].w; }
-    }
-    for (; i < n16; i += stride) { const uint4 v = p[i]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
-    // keeps the loads alive; the condition is false unless the caller asks for the checksum (sink != NULL: tests)
-    if (sink) atomicXor(sink, acc.x ^ acc.y ^ acc.z ^ acc.w);
-}
-
-static hipEvent_t g_fork_events[256];
-static int g_fork_next = 0;
-static hipEvent_t next_fork_event() {
-    hipEvent_t& e = g_fork_events[g_fork_next];
-    g_fork_next = (g_fork_next + 1) & 255;
-    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    return e;
-}
-
-extern "C" int moca_prefetch_fork(const void* ptr, int64_t bytes, uint32_t* sink, void* main_stream, void* side_stream) {
-    if (!ptr || bytes <= 0 || (reinterpret_cast<uintptr_t>(ptr) & 15) || !side_stream || side_stream == main_stream) return MOCA_E_BADARG;
-    hipEvent_t e = next_fork_event();
-    if (!e) return MOCA_E_LAUNCH;
-    if (hipEventRecord(e, moca_stream(main_stream)) != hipSuccess) return MOCA_E_LAUNCH;
-    if (hipStreamWaitEvent(moca_stream(side_stream), e, 0) != hipSuccess) return MOCA_E_LAUNCH;
-    const int64_t n16 = bytes / 16;
-    int64_t blocks = bytes >> 18;                                  // one block per 256 KiB, 16..128 blocks
-    blocks = blocks < 16 ? 16 : (blocks > 128 ? 128 : blocks);
-    hipLaunchKernelGGL(prefetch_kernel, dim3((unsigned)blocks), dim3(256), 0, moca_stream(side_stream), reinterpret_cast<const uint4*>(ptr),
-                       n16, sink);
-    MOCA_CHECK_LAUNCH();
-    return MOCA_OK;
-}
-
-extern "C" int moca_stream_join(void* side_stream, void* main_stream) {
-    if (!side_stream || side_stream == main_stream) return MOCA_E_BADARG;
-    hipEvent_t e = next_fork_event();
-    if (!e) return MOCA_E_LAUNCH;
-    if (hipEventRecord(e, moca_stream(side_stream)) != hipSuccess) return MOCA_E_LAUNCH;
-    if (hipStreamWaitEvent(moca_stream(main_stream), e, 0) != hipSuccess) return MOCA_E_LAUNCH;
-    return MOCA_OK;
-}
-
 // ---- kernel-choice knobs for tests / A-B runs (never results): one table instead of getenv() calls in the launchers
 static int g_tuning[MOCA_TUNE_COUNT] = {1, 1, 1, 1, 1};
 int moca_tuning_get(int knob) { return (knob >= 0 && knob < MOCA_TUNE_COUNT) ? g_tuning[knob] : 0; }

@@ -42,13 +42,13 @@ class GemmParams(C.Structure):
         ("rowadd_div", C.c_int32), ("a_mode", C.c_int32), ("C", C.c_int32),
         ("inH", C.c_int32), ("inW", C.c_int32), ("outH", C.c_int32), ("outW", C.c_int32),
         ("stride", C.c_int32), ("up", C.c_int32), ("T", C.c_int32), ("HW", C.c_int32),
-        ("flags", C.c_int32), ("splits", C.c_int32), ("nopad_lo", C.c_int32), ("reserved_", C.c_int32),
+        ("flags", C.c_int32), ("splits", C.c_int32), ("nopad_lo", C.c_int32), ("prefetch_kib", C.c_int32),
         ("colsum", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out", C.c_void_p),
         ("ld_ln", C.c_int32), ("ln_eps", C.c_float),
         ("rowsum", C.c_void_p), ("lnf_part", C.c_void_p), ("lnf_wsum", C.c_void_p),
         ("lnf_nparts", C.c_int32), ("reserved2_", C.c_int32),
         ("gstat", C.c_void_p), ("gstat_rows", C.c_int32), ("tattn_scale", C.c_float),
-        ("reserved5_", C.c_void_p), ("up_phase", C.c_int32), ("reserved4_", C.c_int32),
+        ("prefetch", C.c_void_p), ("up_phase", C.c_int32), ("reserved4_", C.c_int32),
     ]
 
 
@@ -121,8 +121,6 @@ SIGNATURES = {
     "moca_graph_end": (C.c_int, [_vp, C.POINTER(_vp)]),
     "moca_graph_launch": (C.c_int, [_vp, _vp]),
     "moca_graph_destroy": (C.c_int, [_vp]),
-    "moca_prefetch_fork": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
-    "moca_stream_join": (C.c_int, [_vp, _vp]),
     "moca_stream_create": (C.c_int, [C.POINTER(_vp)]),
     "moca_stream_destroy": (C.c_int, [_vp]),
     "moca_stream_sync": (C.c_int, [_vp]),

@@ -155,9 +155,11 @@ def finish_lnfold(pw: PackedWeight) -> PackedWeight:
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
                  residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None,
-                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, up_phase=0):
+                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, up_phase=0, prefetch=None):
     p = _l.GemmParams()
     p.up_phase = up_phase
+    if prefetch is not None:                 # tensor the launch's spare blocks stream into the memory-side cache (the NEXT heavy launch's weights)
+        p.prefetch, p.prefetch_kib = prefetch.data_ptr(), (prefetch.numel() * prefetch.element_size()) >> 10
     p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), (out.data_ptr() if out is not None else None)
     p.bias = pw.bias.data_ptr() if pw.bias is not None else None
     p.rowadd = rowadd.data_ptr() if rowadd is not None else None
@@ -283,17 +285,6 @@ def concat_channels_gstat(a, b, out, gstat, *, F, HW, C1, C2, frames_per_stat):
     _l.check(_l.load().moca_concat_channels_gstat_f16(_l.ptr(a), _l.ptr(b), _l.ptr(out), F, HW, C1, C2, frames_per_stat,
                                                       _l.ptr(gstat), _st()), "moca_concat_channels_gstat_f16")
     return out
-
-
-def prefetch_fork(t, side_stream, sink=None):
-    """stream tensor `t` (the next weight-heavy launch's weights) through L2 into the Infinity Cache on `side_stream`, concurrently
-    with what the current stream runs next (moca_prefetch_fork)"""
-    _l.check(_l.load().moca_prefetch_fork(_l.ptr(t), t.numel() * t.element_size(), _l.ptr(sink), _st(), C.c_void_p(side_stream)),
-             "moca_prefetch_fork")
-
-
-def stream_join(side_stream):
-    _l.check(_l.load().moca_stream_join(C.c_void_p(side_stream), _st()), "moca_stream_join")
 
 
 def memset_zero(t):

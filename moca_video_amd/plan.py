@@ -53,24 +53,9 @@ def gemm_splits(M, pw):
     return max(1, min(cap, nk // 8))
 
 
-PREFETCH_MIN_BYTES = 4 << 20     # weights of a launch worth warming the memory-side cache for (the 640- / 1280-channel levels)
-
-
-class _StepWithPrefetch:
-    """a recorded launch in front of which the weights of LATER weight-heavy launches are sent to the memory-side cache on the
-    plan's side stream (ops.prefetch_fork); looks like the launch it wraps (func / args / keywords) to the profiling tools"""
-    __slots__ = ("inner", "plan", "weights", "func", "args", "keywords")
-
-    def __init__(self, inner, plan, weights):
-        self.inner, self.plan, self.weights = inner, plan, weights
-        self.func, self.args, self.keywords = inner.func, inner.args, inner.keywords
-
-    def __call__(self):
-        if self.plan.prefetch_on:
-            for w in self.weights:
-                ops.prefetch_fork(w, self.plan.side_stream())
-            self.plan._forked = True
-        self.inner()
+import os as _os
+PREFETCH_HOST_FLOP = float(_os.environ.get("MOCA_PREFETCH_HOST_GF", "50")) * 1e9      # (env: A/B runs only)
+PREFETCH_MIN_BYTES = int(float(_os.environ.get("MOCA_PREFETCH_MIN_MB", "4")) * (1 << 20))   # weights of a launch worth warming the memory-side cache for (env: A/B runs only)
 
 
 class _LNRef:
@@ -99,29 +84,29 @@ class _PlanBase:
         self._gstat_buf, self._gstat_used, self._last_gemm_step = None, 0, None
         self._gstat_full = []
         self.reps = 1            # > 1: the batch is `reps` context variants of the same Bx latents (_Plan: shared prefix)
-        self._side = None        # side stream of the weight prefetches (created on first use)
-        self._forked = False
         self._prefetch_at = {}   # during the build: index of a recorded GEMM step -> weights of later launches to prefetch in front of it
         self.prefetch_on = getattr(model, "weight_prefetch", True)
 
-    def side_stream(self):
-        if self._side is None:
-            h = C.c_void_p()
-            _l.check(_l.load().moca_stream_create(C.byref(h)), "moca_stream_create")
-            self._side = h.value
-        return self._side
-
     def _note_gemm(self, pw):
-        """called right before a GEMM step is recorded: weight-heavy -> its weights are prefetched in front of the PREVIOUS GEMM launch
-        (they then stream into the Infinity Cache while that launch computes; the small launches in between do not matter)"""
+        """called right before a GEMM step is recorded: weight-heavy -> its weights ride on the PREVIOUS GEMM launch (moca_gemm_params.prefetch:
+        spare blocks of that launch's grid stream them into the Infinity Cache while its tiles compute; the small launches in between do
+        not matter)"""
         if self._last_gemm_step is not None and pw.w.numel() * pw.w.element_size() >= PREFETCH_MIN_BYTES:
             self._prefetch_at.setdefault(self._last_gemm_step, []).append(pw.w)
         self._last_gemm_step = len(self.steps)
 
     def _finish_prefetch(self):
-        """end of the build (every re-targeting of recorded steps is done): wrap the host launches"""
-        for j, ws in self._prefetch_at.items():
-            self.steps[j] = _StepWithPrefetch(self.steps[j], self, ws)
+        """end of the build (every re-targeting of recorded steps is done): the host launches get their `prefetch` operand (one per
+        launch: the largest of the weights that asked for it)"""
+        if self.prefetch_on:
+            for j, ws in self._prefetch_at.items():
+                prod = self.steps[j]
+                kw = dict(prod.keywords)
+                # the spare blocks must be done before the host's tiles are, or they prolong it: only hosts with enough work
+                if 2.0 * kw["M"] * prod.args[1].N * prod.args[1].K < PREFETCH_HOST_FLOP:
+                    continue
+                kw["prefetch"] = max(ws, key=lambda w: w.numel())
+                self.steps[j] = functools.partial(prod.func, *prod.args, **kw)
         self._prefetch_at = {}
 
     def close(self):
@@ -280,9 +265,6 @@ class _PlanBase:
             ops.memset_zero(self._gstat_buf[:self._gstat_used])
         for s in self.steps:
             s()
-        if self._forked:                      # the side stream of the weight prefetches rejoins (required inside a capture)
-            ops.stream_join(self.side_stream())
-            self._forked = False
 
     def _launch(self, handle):
         lib = _l.load()

@@ -53,7 +53,6 @@ with torch.no_grad():
             unet(x, ts, ctx, fps=torch.tensor([10] * B, device=dev))
 torch.cuda.synchronize()
 plan = next(iter(unet._plans.values()))
-plan.prefetch_on = False            # (steps are replayed one by one here: no side-stream weight prefetches between them)
 st = plan.stream
 ops.set_stream(st.cuda_stream)
 
