@@ -77,46 +77,51 @@ def build_model(device, seed=321, materialise=True):
     return dm
 
 
-def param_checksum(module):
-    """(sum, sum of squares) over every parameter in float64: identical bytes give identical values (same reduction on every
-    rank); a NaN-filled (never received) tensor makes it NaN, which equals nothing"""
-    s = torch.zeros(2, dtype=torch.float64, device=next(module.parameters()).device)
+def tensor_checksum(tensors, device):
+    """(sum, sum of squares) over the tensors in float64: identical bytes give identical values (same reduction on every rank); a
+    NaN-filled (never received) tensor makes it NaN, which equals nothing"""
+    s = torch.zeros(2, dtype=torch.float64, device=device)
     with torch.no_grad():
-        for p in module.parameters():
+        for p in tensors:
             d = p.detach().double()
             s[0] += d.sum()
             s[1] += (d * d).sum()
     return s
 
 
-def broadcast_and_verify(module, device, world, rank):
-    """C1 with proof: barrier, timed flat-bucket broadcast from rank 0 (RCCL over xGMI; gloo in the CPU self-test), then the
-    per-rank parameter checksums are all-gathered and must all equal rank 0's.  Returns the dict that goes into the JSON line;
-    raises (non-zero exit on every rank) when a rank's weights differ."""
+def broadcast_and_verify(module, device, world, rank, plans):
+    """C1 with proof: barrier, timed flat-bucket broadcast from rank 0 (RCCL over xGMI; gloo in the CPU self-test) of the PACKED operand
+    set the recorded launches of `plans` read (dist.broadcast_packed: fp16 weights + fp32 biases / norm parameters, 2.83 GB for the
+    UNet; the receivers built the same plans from placeholder parameters, get the data in place and drop their fp32 masters), then
+    the per-rank checksums of those packed buffers are all-gathered and must all equal rank 0's.  Returns the dict that goes into
+    the JSON line; raises (non-zero exit on every rank) when a rank's operands differ."""
     import torch.distributed as tdist
     from moca_video_amd import dist as mdist
     if not tdist.is_initialized():                                # (one process, no launcher: nothing to prove)
+        ts = mdist.packed_operands(module._packed, plans)
         return {"rccl_ranks": 1, "backend": None, "broadcast_bytes": 0, "broadcast_s": 0.0, "broadcast_GBps_per_receiver": None,
-                "param_checksums_equal": True, "param_checksum_rank0": [float(v) for v in param_checksum(module)]}
+                "param_checksums_equal": True, "param_checksum_rank0": [float(v) for v in tensor_checksum(ts, device)]}
     sync = (lambda: torch.cuda.synchronize(device)) if device.type == "cuda" else (lambda: None)
     mdist.barrier(); sync()
     t0 = time.perf_counter()
     if os.environ.get("MOCA_BENCH_STUB_BROADCAST") == "1":       # negative test hook (tests/test_dist_cpu.py): C1 skipped
-        nbytes = 0
+        nbytes, tensors = 0, mdist.packed_operands(module._packed, plans)
     else:
-        nbytes = mdist.broadcast_parameters(module, src=0)
+        nbytes, tensors = mdist.broadcast_packed(module, plans, src=0)
     sync(); mdist.barrier()
     dt = mdist.max_over_ranks(time.perf_counter() - t0, device)
-    cs = param_checksum(module)
+    cs = tensor_checksum(tensors, device)
     allcs = [torch.empty_like(cs) for _ in range(world)]
     tdist.all_gather(allcs, cs)
     sums = [[float(c[0]), float(c[1])] for c in allcs]
     equal = all(torch.equal(c, allcs[0]) for c in allcs) and bool(torch.isfinite(allcs[0]).all())
     info = {"rccl_ranks": tdist.get_world_size(), "backend": tdist.get_backend(), "broadcast_bytes": int(nbytes),
+            "broadcast_what": "packed operand set (fp16 weights + fp32 biases / norm parameters), %d tensors" % len(tensors),
+            "fp32_masters_on_this_rank_bytes": int(sum(p.numel() * p.element_size() for p in module.parameters())),
             "broadcast_s": round(dt, 4), "broadcast_GBps_per_receiver": round(nbytes / dt / 1e9, 2) if dt > 0 else None,
             "param_checksums_equal": equal, "param_checksum_rank0": sums[0]}
     if not equal:
-        raise RuntimeError(f"rank {rank}: parameter checksums differ after the C1 broadcast: {sums}")
+        raise RuntimeError(f"rank {rank}: packed-operand checksums differ after the C1 broadcast: {sums}")
     return info
 
 
@@ -470,13 +475,19 @@ def launcher_selftest(args):
     measures nothing and says so in `metric`; a stubbed-out broadcast makes every rank exit non-zero."""
     from moca_video_amd import dist as mdist
     rank, local, world = mdist.init_from_env(backend="gloo")
+    import functools
+    import types
+    from moca_video_amd import ops
     torch.manual_seed(100)
     m = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.Linear(64, 8))
     if rank != 0:
         with torch.no_grad():
             for p in m.parameters():
                 p.fill_(float("nan"))
-    info = broadcast_and_verify(m, torch.device("cpu"), world, rank)
+    # what UNetModel offers dist.broadcast_packed: `_packed` (id -> packed operands) and plans whose recorded steps reference them
+    m._packed = {id(l): ops.pack_linear(l.weight.detach(), l.bias.detach(), device="cpu") for l in m}
+    plan = types.SimpleNamespace(steps=[functools.partial(lambda *a, **k: None, None, pw, None) for pw in m._packed.values()])
+    info = broadcast_and_verify(m, torch.device("cpu"), world, rank, [plan])
     rows = mdist.shard_indices(N_PROMPTS, rank, world)
     mdist.barrier()
     t0 = time.perf_counter()
@@ -534,14 +545,12 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count())      # (more ranks than devices only in the 1-GPU gloo rehearsal)
     torch.cuda.set_device(device)
     lib = mlib.load()
 
-    dm = build_model(device, seed=321, materialise=(rank == 0))           # ranks != 0: NaN until C1 delivers rank 0's weights
+    dm = build_model(device, seed=321, materialise=(rank == 0))           # ranks != 0: NaN until C1 delivers rank 0's packed operands
     multi = None
-    if world > 1:
-        multi = broadcast_and_verify(dm.model.diffusion_model, device, world, rank)     # C1 (RCCL over xGMI) + checksum proof
     unet = dm.model.diffusion_model
     unet.weight_prefetch = not args.no_weight_prefetch
     sampler = DDIMSampler(dm)
@@ -578,6 +587,11 @@ def main():
     if args.step_mode == "graph" and args.cfg_mode == "batched" and sampler.share_prefix:
         from moca_video_amd.fifo_graph import BaseEngine
         engines = [BaseEngine(dm, sampler, b["x"], b["cond"], b["uc"], 12.0, seed=321 + i) for i, b in enumerate(batches)]
+    if world > 1:
+        # C1 (RCCL over xGMI) + checksum proof, on the PACKED set: every rank has built its plans (ranks != 0 from NaN placeholders)
+        if engines is None:
+            raise SystemExit("multi-GPU runs use --step-mode graph (the plans must exist before the packed broadcast)")
+        multi = broadcast_and_verify(unet, device, world, rank, [e.plan for e in engines])
 
     def ddim_step(i, imgs):
         if engines is not None:
@@ -694,7 +708,7 @@ def main():
                                 "running its %d rows as %d forward(s) of B=%d" % (N_PROMPTS, world, N_PROMPTS, 2 * N_PROMPTS, len(rows),
                                                                                   len(batches), 2 * batches[0]["n"])),
                    "unet_steps_per_step": 2 * n_prompts, "context_tokens": 77, "weights": "random-init, 1.41B params, fp16 packed" +
-                   ("" if world == 1 else "; materialised on rank 0 only, RCCL broadcast (C1), checksums all-gathered"),
+                   ("" if world == 1 else "; materialised and packed on rank 0 only, packed set RCCL-broadcast (C1), checksums all-gathered, no fp32 masters on the other ranks"),
                    "parallelism": f"dp{world} (independent prompts, no collective in the loop)",
                    "hipgraph_replay": graph_on, "cfg_mode": args.cfg_mode, "cfg_shared_prefix": sampler.share_prefix and args.cfg_mode == "batched", "weight_prefetch": unet.weight_prefetch, "step_mode": "graph" if engines is not None else "host", "device": name, "compute_units": cus, "output_finite": finite,
                    "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},

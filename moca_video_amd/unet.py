@@ -391,6 +391,7 @@ class UNetModel(nn.Module):
     # ---- weights -----------------------------------------------------------------------
     def _invalidate(self):
         self._packed = None
+        self._packed_only = False
         for pl in getattr(self, "_plans", {}).values():      # the hipGraphExec of a dropped plan is a device-side object
             pl.close()
         self._plans = {}
@@ -464,6 +465,9 @@ class UNetModel(nn.Module):
             B *= len(L)
         key = (B, T, H, W, L, x.dtype, x.device.index, replica, shared_x)
         plan = self._plans.get(key)
+        if plan is None and getattr(self, "_packed_only", False):
+            raise RuntimeError("this rank received the packed operand set of the plans built before dist.broadcast_packed and holds no "
+                               "parameters to pack a new plan from")
         if plan is None:
             plan = _Plan(self, B, T, H, W, L, x.dtype, x.device, shared_x=shared_x)
             self._plans[key] = plan

@@ -60,6 +60,64 @@ def test_dist_world2_gloo():
         assert shard == list(range(10))[rank::world]
 
 
+def _worker_packed(rank, world, port, q):
+    import functools
+    import types
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from moca_video_amd import dist as md
+    from moca_video_amd import ops
+    md.init_from_env(backend="gloo")
+    torch.manual_seed(7)
+    m = torch.nn.Sequential(torch.nn.Linear(96, 200), torch.nn.LayerNorm(200), torch.nn.Linear(200, 64, bias=False))
+    if rank != 0:                                     # placeholders: the receivers never see real fp32 masters
+        with torch.no_grad():
+            for p in m.parameters():
+                p.fill_(float("nan"))
+    pk = {id(m[0]): ops.pack_linear(m[0].weight.detach(), m[0].bias.detach(), device="cpu"),
+          id(m[1]): (m[1].weight.detach().float().clone(), m[1].bias.detach().float().clone()),
+          id(m[2]): ops.finish_lnfold(ops.pack_linear(m[2].weight.detach(), None, device="cpu")),
+          "unused": ops.pack_linear(torch.randn(64, 64), None, device="cpu")}       # packed but read by no recorded launch
+    m._packed = pk
+    step = lambda *a, **k: None
+    plan = types.SimpleNamespace(steps=[lambda: None,                                  # (an engine's pre() hook: no operands)
+                                        functools.partial(step, None, pk[id(m[0])], None, M=5),
+                                        functools.partial(step, None, None, pk[id(m[1])][0], pk[id(m[1])][1]),
+                                        functools.partial(step, None, pk[id(m[2])], None, ln=(pk[id(m[1])][0], pk[id(m[1])][1], None, 1e-5)),
+                                        functools.partial(step, None, pk[id(m[0])], None, M=9)])   # the same operand twice
+    sent, tensors = md.broadcast_packed(m, [plan], src=0, bucket_bytes=20000)
+    expect = (256 * 128 * 2 + 256 * 4) + 2 * 200 * 4 + (64 * 256 * 2 + 64 * 4)      # w0 (200 -> 256 rows, 96 -> 128 k) + b0, gamma, beta, w2 + its row sums
+    flat = torch.cat([t.reshape(-1).double() for t in tensors])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], g) for g in gathered) and bool(torch.isfinite(flat).all())
+    masters = sum(p.numel() for p in m.parameters())
+    q.put((rank, sent, expect, len(tensors), same, masters, getattr(m, "_packed_only", False),
+           bool(torch.isnan(pk["unused"].w).any())))
+    dist.destroy_process_group()
+
+
+def test_broadcast_packed_world2_gloo():
+    """C1 as the GPU job runs it (dist.broadcast_packed): the operand set the recorded launches read -- fp16 packed weights, fp32
+    biases / folded row sums / norm parameters, each once, in first-use order -- is what moves (bytes = the packed sizes, not the
+    fp32 masters); the receivers' packed buffers equal rank 0's afterwards, their masters are gone and they refuse new plans"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_packed, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    n_master = 96 * 200 + 200 + 2 * 200 + 200 * 64
+    for rank, sent, expect, n_t, same, masters, packed_only, unused_nan in out:
+        assert sent == expect and n_t == 6 and same
+        assert masters == (n_master if rank == 0 else 0) and packed_only == (rank != 0)
+        assert not unused_nan
+
+
 def test_shard_indices_cover():
     from moca_video_amd.dist import shard_indices
     for n in (0, 1, 7, 64):
@@ -86,7 +144,9 @@ def test_bench_launches_its_own_ranks():
     assert res["n_gpus"] == 2 and res["ranks_gathered"] == [0, 1] and res["weights_equal_after_broadcast"]
     assert res["steps"] == 3
     mg = res["multi_gpu"]                          # C1 proof: ranks as the backend saw them, bytes moved, checksums equal and finite
-    assert mg["rccl_ranks"] == 2 and mg["backend"] == "gloo" and mg["broadcast_bytes"] == (64 * 64 + 64 + 64 * 8 + 8) * 4
+    # C1 moves the PACKED set: two fp16 [64][64] matrices (the 8-row one zero padded to 64 rows) + two fp32 [64] biases
+    assert mg["rccl_ranks"] == 2 and mg["backend"] == "gloo" and mg["broadcast_bytes"] == 2 * (64 * 64 * 2 + 64 * 4)
+    assert "packed" in mg["broadcast_what"]
     assert mg["param_checksums_equal"] and mg["broadcast_s"] > 0 and all(v == v for v in mg["param_checksum_rank0"])
     assert res["rows_covered"]                     # the 64 prompt rows of config[4], strided over the ranks, all accounted for
 
