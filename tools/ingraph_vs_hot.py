@@ -58,5 +58,5 @@ for k, (t, c) in gk.items():
     tot_h += hot
 print(f"matched kernel time: graph {tot_g / 1e6:.3f} ms vs hot-isolated {tot_h / 1e6:.3f} ms (+{(tot_g - tot_h) / 1e6:.3f} ms); unmatched in graph {missing / 1e6:.3f} ms")
 print(f"{'delta_us':>9s} {'graph_us':>9s} {'hot_us':>9s} {'n':>4s} {'ratio':>6s}  kernel / grid / wg")
-for d, t, hot, c, k in sorted(rows, key=lambda r: -r[0])[:60]:
+for d, t, hot, c, k in sorted(rows, key=lambda r: -r[1]):
     print(f"{d / 1e3:9.1f} {t / 1e3:9.1f} {hot / 1e3:9.1f} {c:4d} {t / max(hot, 1):6.2f}  {k[0]} {k[1]} {k[2]}")
