@@ -1812,6 +1812,25 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
 #else
+#if defined(W80S_GN_DIAG)
+        // DIAGNOSTIC build only (results wrong by construction; `make gndiag`, profiles/r04_ab_gn_in_consumer.txt): what a GroupNorm
+        // apply + SiLU fused into this consumer would cost as a pass over the LANDED A k-tiles -- each wave rewrites its eighth of the
+        // A rows of tiles i and i+1 (affine + SiLU per element, as gn_apply does) before anyone reads fragments, one more barrier.
+        if constexpr (AMODE != MOCA_A_LINEAR && !SQ && !TQ) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                char* base = smem + (t == 0 ? s0 : s1) * STAGE;
+                for (int c = tid; c < A_BYTES / 16; c += 512) {
+                    half8v v = *reinterpret_cast<half8v*>(base + c * 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (half_t)moca_silu((float)v[j] * 1.0009765625f + 0.0009765625f);
+                    *reinterpret_cast<half8v*>(base + c * 16) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+#endif
         // ---- LOADe: tile i only ----
         read_tile(int_c<0>{}, s0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
