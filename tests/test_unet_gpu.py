@@ -264,9 +264,9 @@ def test_weight_prefetch_changes_nothing():
     ctx = inp("pf.ctx", (2, 77, 128)).cuda()
     t = torch.tensor([700, 30]).cuda()
     outs = []
-    old_min = P.PREFETCH_MIN_BYTES
+    old_min, old_host = P.PREFETCH_MIN_BYTES, P.PREFETCH_HOST_FLOP
     try:
-        P.PREFETCH_MIN_BYTES = 1 << 20
+        P.PREFETCH_MIN_BYTES, P.PREFETCH_HOST_FLOP = 1 << 20, 0.0
         for on in (True, False):
             m = UNetModel(**cfg)
             m.load_state_dict(state_dict_for(m, 3), strict=True)
@@ -279,7 +279,7 @@ def test_weight_prefetch_changes_nothing():
             assert torch.equal(ys[0], ys[1]) and torch.equal(ys[1], ys[2])
             outs.append(ys[2])
     finally:
-        P.PREFETCH_MIN_BYTES = old_min
+        P.PREFETCH_MIN_BYTES, P.PREFETCH_HOST_FLOP = old_min, old_host
     assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
 
 
