@@ -234,30 +234,37 @@ class FifoEngine:
     def _upload_sam(self, sam_masks):
         """pack the candidates of this iteration -- `sam_masks[w][i]` = [n,H,W] masks Grounded-SAM-2 returns for frame i of window w
         (reference call order), None / empty = no box -- into the pool and enqueue the copy on the plan's stream.  Frames with
-        t > 300 never reach the producer (ddim.py:592) and are not uploaded.  Pinned double buffer: no host synchronisation unless
-        the copy of two iterations ago is still in flight."""
+        t > 300 never reach the producer (ddim.py:592) and are not uploaded.  Host tensors go through a pinned double buffer (no
+        host synchronisation unless the copy of two iterations ago is still in flight); tensors already on the device are copied
+        there (stream-ordered, nothing read back: only their shapes are looked at)."""
         pool, tab, ev = self._sam_stage[self._sam_turn]
         self._sam_turn ^= 1
         ev.synchronize()
         tab.zero_()
-        used = 0
+        used, host_runs, dev_copies = 0, [], []
         if sam_masks is not None:
             for w in range(self.nW):
                 cw = sam_masks[w]
                 for i in range(self.f):
                     if self._t_host[w, i] > 300 or cw is None or i >= len(cw) or cw[i] is None:
                         continue
-                    m = torch.as_tensor(cw[i]).detach().to("cpu", torch.float32).reshape(-1, self.HW)
+                    m = torch.as_tensor(cw[i]).detach().reshape(-1, self.HW)
                     n = m.shape[0]
                     if n == 0:
                         continue
                     if used + n > self.sam_capacity:
                         raise ValueError(f"more than sam_capacity = {self.sam_capacity} candidate masks in one iteration")
-                    pool[used:used + n].copy_(m)
+                    if m.is_cuda:
+                        dev_copies.append((used, n, m))
+                    else:
+                        pool[used:used + n].copy_(m.to(torch.float32))
+                        host_runs.append((used, n))
                     tab[0, w * self.f + i], tab[1, w * self.f + i] = used, n
                     used += n
-        if used:
-            self.sam_cand[:used].copy_(pool[:used], non_blocking=True)
+        for a, n in host_runs:
+            self.sam_cand[a:a + n].copy_(pool[a:a + n], non_blocking=True)
+        for a, n, m in dev_copies:
+            self.sam_cand[a:a + n].copy_(m.to(self.device, torch.float32), non_blocking=True)
         self.sam_tab.copy_(tab, non_blocking=True)
         ev.record(self.plan.stream)
 

@@ -259,6 +259,8 @@ class _PlanBase:
         return y
 
     def _run_steps(self):
+        if self._prefetch_at:                  # plans whose build does not end in _finish_prefetch (VAE decoder, single blocks)
+            self._finish_prefetch()
         for full in self._gstat_full:
             ops.memset_zero(full)
         if self._gstat_used:

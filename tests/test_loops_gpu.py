@@ -200,7 +200,10 @@ def test_fifo_graph_prompt_mode_calls_vs_reference_golden(dm):
     eng = FifoEngine(FIFO_ARGS, dm, s, cond, uc, 12.0, lat, conditioned_image=cimg, n_slots=3, sam_capacity=64)
     injected = 0
     for i in range(3):
-        eng.step(noise=noises[i], shift_noise=shifts[i], sam_masks=[loop_sam_candidates(4 * i + w, 8, 16, 16) for w in range(4)])
+        cands = [loop_sam_candidates(4 * i + w, 8, 16, 16) for w in range(4)]
+        if i == 1:                                   # candidates that already live on the device take the device-side copy path
+            cands = [[None if c is None else c.cuda() for c in cw] for cw in cands]
+        eng.step(noise=noises[i], shift_noise=shifts[i], sam_masks=cands)
         xp, p0 = eng.window_outputs()
         idx = eng.sam_idx.cpu().reshape(4, 8)
         for w in range(4):
