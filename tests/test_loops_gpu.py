@@ -221,6 +221,36 @@ def test_fifo_graph_prompt_mode_calls_vs_reference_golden(dm):
     eng.close()
 
 
+def test_engine_argument_contracts(dm):
+    """the engines refuse what they cannot run faithfully: more candidate masks than the pool holds, candidates handed to an engine
+    built without a pool, guidance branches with different fps on the shared-prefix step graph"""
+    from moca_video_amd.fifo_graph import BaseEngine, FifoEngine
+    from moca_video_amd.sampler import DDIMSampler
+    t = _text()
+    s = DDIMSampler(dm)
+    s.make_schedule(16, ddim_eta=1.0, verbose=False)
+    cond = {"c_crossattn": [t["c1"], t["c2"]], "fps": torch.tensor([10]).cuda()}
+    uc = {"c_crossattn": [t["uc"]], "fps": cond["fps"]}
+    lat = inp("loop.q0", (1, 4, 20, 16, 16)).cuda()
+    many = [[torch.ones(3, 16, 16) * 0.0 for _ in range(8)] for _ in range(4)]          # 3 masks per window frame
+    eng = FifoEngine(FIFO_ARGS, dm, s, cond, uc, 12.0, lat.clone(), sam_capacity=4)
+    with pytest.raises(ValueError, match="sam_capacity"):
+        eng.step(sam_masks=many)
+    eng.close()
+    eng = FifoEngine(FIFO_ARGS, dm, s, cond, uc, 12.0, lat.clone())
+    with pytest.raises(ValueError, match="sam_capacity"):
+        eng.step(sam_masks=many)
+    eng.close()
+    x = inp("loop.base.randn0", (1, 4, 8, 16, 16)).cuda()
+    c1 = {"c_crossattn": [t["c1"]], "fps": torch.tensor([10]).cuda()}
+    u1 = {"c_crossattn": [t["uc"]], "fps": torch.tensor([24]).cuda()}
+    assert not BaseEngine.supported(dm, x, c1, u1, 12.0) and BaseEngine.supported(dm, x, c1, dict(u1, fps=c1["fps"]), 12.0)
+    be = BaseEngine(dm, s, x, c1, dict(u1, fps=c1["fps"]), 12.0)
+    with pytest.raises(ValueError, match="fps"):
+        be.reset(x, c1, u1)
+    be.close()
+
+
 def test_sam_select_kernel_equals_host_bookkeeping():
     """moca_sam_select_masks_f32 against DDIMSampler.select_sam_masks (the statement-by-statement restatement of ddim.py:739-903 the
     host loop uses, itself pinned by tests/golden/sampler_sam*.npz) on random candidate sets: overlapping blobs around a drifting
