@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Micro-benchmark of moca_attention_f16 / moca_temporal_attention_f16 on the UNet's shapes (B=2, T=16), random q / k / v, HIP events.
-Two figures per shape: "burst" = 10 back-to-back launches after 2 warm-ups (what an isolated replay sees: the chip boosts for a
-few milliseconds), "sustained" = back-to-back launches for >= 60 ms (the clock the chip holds under load: what a launch inside the
-replayed 32 ms forward sees).  The two differ by 15-20 % on the MFMA-heavy shapes -- quote the sustained one."""
+Two figures per shape: "burst" = 10 back-to-back launches after 2 warm-ups from an idle chip, "sustained" = back-to-back launches for
+>= 60 ms (what a launch inside the replayed 33 ms forward sees).  On the MFMA-heavy shapes the first launches from idle are the
+SLOWER ones (the clock ramps up under load: 359 vs 314 us at 2560 tokens, profiles/r04_bench_attn.txt) -- quote the sustained figure."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
