@@ -10,6 +10,7 @@ Public surface mirrors the reference interfaces for this path only:
   instantiate_from_config       utils/utils.py:27-42
   AutoencoderKL                 lvdm/models/autoencoder.py:13-107 + lvdm/modules/networks/ae_modules.py:364-579
   FrozenOpenCLIPEmbedder        lvdm/modules/encoders/condition.py:174-235 (text tower on token ids)
+  SimpleTokenizer               what open_clip.tokenize does (condition.py:207): byte-level BPE, needs the CLIP merges file
 Importing the package loads libmoca_hip.so and fails loudly if it has not been built.
 """
 from . import lib as _lib
@@ -20,5 +21,6 @@ from .unet import UNetModel  # noqa: E402
 from .wrapper import DiffusionWrapper, DenoiseModel, instantiate_from_config, load_unet_config  # noqa: E402
 from .vae import AutoencoderKL  # noqa: E402
 from .clip_text import FrozenOpenCLIPEmbedder  # noqa: E402
+from .tokenizer import SimpleTokenizer  # noqa: E402
 
-__all__ = ["UNetModel", "DiffusionWrapper", "DenoiseModel", "AutoencoderKL", "FrozenOpenCLIPEmbedder", "instantiate_from_config", "load_unet_config"]
+__all__ = ["UNetModel", "DiffusionWrapper", "DenoiseModel", "AutoencoderKL", "FrozenOpenCLIPEmbedder", "SimpleTokenizer", "instantiate_from_config", "load_unet_config"]

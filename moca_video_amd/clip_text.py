@@ -8,7 +8,8 @@ The transformer blocks themselves are `open_clip_torch==2.30.0` code (requiremen
 weights (`laion2b_s32b_b79k`) and BPE vocabulary are not available offline: the module mirrors open_clip's parameter names
 (`model.token_embedding.weight`, `model.positional_embedding`, `model.transformer.resblocks.N.{ln_1,attn.in_proj_weight,
 attn.in_proj_bias,attn.out_proj,ln_2,mlp.c_fc,mlp.c_proj}`, `model.ln_final`, `model.text_projection`, `model.logit_scale`) so a
-`cond_stage_model.*` checkpoint loads, and it takes TOKEN IDS (`open_clip.tokenize` is the caller's).
+`cond_stage_model.*` checkpoint loads; it takes TOKEN IDS, or strings once `.tokenizer` holds a `SimpleTokenizer` (tokenizer.py: the
+published byte-level BPE, parity unpinned for the same reason).
 """
 from __future__ import annotations
 
@@ -68,6 +69,7 @@ class FrozenOpenCLIPEmbedder(nn.Module):
         self.layer = layer
         self.layer_idx = 0 if layer == "last" else 1
         self._packed = None
+        self.tokenizer = None          # `open_clip.tokenize` stand-in (moca_video_amd.tokenizer.SimpleTokenizer) once a vocabulary exists
         self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_packed", None))
 
     def _apply(self, fn, recurse=True):
@@ -92,8 +94,14 @@ class FrozenOpenCLIPEmbedder(nn.Module):
         self._packed = P
 
     def forward(self, text):
+        """condition.py:205-209: `tokens = open_clip.tokenize(text)`.  Strings need `self.tokenizer` (a
+        `moca_video_amd.tokenizer.SimpleTokenizer` built from the CLIP merges file, which is not available offline); token ids
+        [B, 77] are taken as they are."""
         if isinstance(text, (str, list, tuple)) and not torch.is_tensor(text):
-            raise NotImplementedError("open_clip.tokenize (BPE vocabulary) is not available offline: pass token ids [B, 77]")
+            if self.tokenizer is None:
+                raise NotImplementedError("no BPE vocabulary: set `.tokenizer = SimpleTokenizer(<bpe_simple_vocab_16e6.txt.gz>)` or pass "
+                                          "token ids [B, 77]")
+            text = self.tokenizer(text, self.max_length).to(self.model.positional_embedding.device)
         return self.encode_with_transformer(text)
 
     encode = forward

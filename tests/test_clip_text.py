@@ -82,3 +82,56 @@ def test_hip_text_tower_vs_oracle(layer):
         m(["a prompt"])
     with pytest.raises(ValueError):
         m.encode_with_transformer(tok[:, :50].cuda())
+    m.tokenizer, _ = _toy_tokenizer()               # strings go through `open_clip.tokenize`'s stand-in (condition.py:207)
+    ids = m.tokenizer(["hello world", ""], 77)
+    assert torch.equal(m(["hello world", ""]), m.encode_with_transformer(ids.cuda()))
+
+
+# ---------------------------------------------------------------- byte-level BPE tokenizer (CPU; synthetic merge table: the real vocabulary is absent)
+def _toy_tokenizer():
+    from moca_video_amd.tokenizer import SimpleTokenizer
+    merges = [("h", "e"), ("l", "l"), ("he", "ll"), ("hell", "o</w>"), ("w", "o"), ("r", "l"), ("wo", "rl"), ("worl", "d</w>"),
+              ("c", "a"), ("ca", "t</w>"), ("a", "b"), ("ab", "c</w>")]
+    return SimpleTokenizer(merges=merges), merges
+
+
+def test_tokenizer_bpe_on_a_synthetic_merge_table():
+    """id layout (256 byte symbols, 256 word-final ones, one id per merge, start / end), merge PRIORITY (lowest rank first, not left
+    to right), word-final marker, lower-casing / whitespace / html clean-up, punctuation and digits split off, utf-8 bytes,
+    context padding and truncation that keeps `<end_of_text>` -- the published CLIP algorithm on a 12-merge table"""
+    tok, merges = _toy_tokenizer()
+    base = 512
+    assert len(tok.encoder) == 512 + len(merges) + 2 and tok.sot == 512 + len(merges) and tok.eot == tok.sot + 1
+    mid = lambda pair: base + merges.index(pair)
+    assert tok.encode("hello") == [mid(("hell", "o</w>"))]
+    assert tok.encode("  Hello   WORLD ") == [mid(("hell", "o</w>")), mid(("worl", "d</w>"))]
+    assert tok.encode("hello&amp;cat") == [mid(("hell", "o</w>")), 256 + list(tok.byte_encoder.values()).index("&"), mid(("c", "a")) + 1]
+    # "hell" is not word-final: h e l l -> he ll -> hell, then no rule for (hell</w>)...: symbols ['he', 'll</w>']?  the final l carries </w>
+    assert tok.bpe("hell") == "he l l</w>"                     # ('l','l</w>') is not a rule: only ('l','l') is -> 'he' merges, 'll' cannot
+    assert tok.encode("abc ab") == [mid(("ab", "c</w>")), tok.encoder["a"], tok.encoder["b</w>"]]     # ('a','b</w>') is not a rule
+    assert tok.encode("7up!") == [tok.encoder["7</w>"], tok.encoder["u"], tok.encoder["p</w>"], tok.encoder["!</w>"]]
+    ids = tok.encode("é")                                      # two utf-8 bytes -> two byte symbols, the last one word-final
+    assert len(ids) == 2 and ids[0] < 256 <= ids[1] < 512
+    assert tok.decode(tok.encode("hello cat é")).strip() == "hello cat é"
+    t = tok(["hello world", "", "cat " * 100], context_length=9)
+    assert t.shape == (3, 9) and t.dtype == torch.int64
+    assert t[0].tolist() == [tok.sot, mid(("hell", "o</w>")), mid(("worl", "d</w>")), tok.eot, 0, 0, 0, 0, 0]
+    assert t[1].tolist() == [tok.sot, tok.eot] + [0] * 7
+    assert t[2, 0] == tok.sot and t[2, -1] == tok.eot and (t[2, 1:-1] == mid(("ca", "t</w>"))).all()
+    with pytest.raises(ValueError):
+        type(tok)()
+
+
+def test_tokenizer_reads_a_merges_file(tmp_path):
+    from moca_video_amd.tokenizer import SimpleTokenizer, bytes_to_unicode
+    _, merges = _toy_tokenizer()
+    import gzip
+    body = "#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n"
+    (tmp_path / "m.txt").write_text(body, encoding="utf-8")
+    with gzip.open(tmp_path / "m.txt.gz", "wt", encoding="utf-8") as f:
+        f.write(body)
+    for name in ("m.txt", "m.txt.gz"):
+        tok = SimpleTokenizer(str(tmp_path / name))
+        assert tok.encode("hello world") == [512 + 3, 512 + 7]
+    b2u = bytes_to_unicode()
+    assert len(b2u) == 256 and len(set(b2u.values())) == 256 and b2u[ord("a")] == "a" and b2u[0] == chr(256)
