@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import os
 import warnings
 
 import torch
@@ -53,9 +54,11 @@ def gemm_splits(M, pw):
     return max(1, min(cap, nk // 8))
 
 
-import os as _os
-PREFETCH_HOST_FLOP = float(_os.environ.get("MOCA_PREFETCH_HOST_GF", "50")) * 1e9      # (env: A/B runs only)
-PREFETCH_MIN_BYTES = int(float(_os.environ.get("MOCA_PREFETCH_MIN_MB", "4")) * (1 << 20))   # weights of a launch worth warming the memory-side cache for (env: A/B runs only)
+# weight prefetch (moca_gemm_params.prefetch): weights of a launch worth warming the memory-side cache for, and the least work a host
+# launch must have so that its spare blocks finish before its tiles do (same-box A/B: profiles/r04_ab_weight_prefetch_in_kernel.txt;
+# the environment variables exist for such A/B runs only)
+PREFETCH_MIN_BYTES = int(float(os.environ.get("MOCA_PREFETCH_MIN_MB", "4")) * (1 << 20))
+PREFETCH_HOST_FLOP = float(os.environ.get("MOCA_PREFETCH_HOST_GF", "50")) * 1e9
 
 
 class _LNRef:

@@ -251,7 +251,8 @@ class DDIMSampler(object):
         unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
         if self.share_prefix and hasattr(unet, "forward_segments") and getattr(self.model.model, "conditioning_key", None) == "crossattn" \
                 and same_fps([fps_c, fps_u]):
-            e = unet.forward_segments(x, t, [cc, cu], fps=[fps_rows(fps_c, W), fps_rows(fps_u, W)], shared_x=True)
+            fr_c = fps_rows(fps_c, W)
+            e = unet.forward_segments(x, t, [cc, cu], fps=[fr_c, fr_c if fps_u is fps_c else fps_rows(fps_u, W)], shared_x=True)
             e_c, e_u = e[:W], e[W:]
         elif cc.shape == cu.shape and isinstance(fps_c, int) == isinstance(fps_u, int):
             fps2 = fps_c if isinstance(fps_c, int) else torch.cat([fps_rows(fps_c, W), fps_rows(fps_u, W)], 0)

@@ -251,6 +251,55 @@ def test_engine_argument_contracts(dm):
     be.close()
 
 
+def test_fifo_graph_with_different_fps_per_branch(dm):
+    """guidance branches with DIFFERENT fps cannot share the UNet prefix (it adds one fps embedding): the engine then runs the plain
+    batch of 2 x nW windows (gather repeats the windows) -- same video as the host-driven loop, which calls the two branches separately"""
+    from moca_video_amd.fifo import fifo_ddim_sampling
+    from moca_video_amd.sampler import DDIMSampler
+    t = _text()
+    s = DDIMSampler(dm)
+    s.make_schedule(16, ddim_eta=1.0, verbose=False)
+    cond = {"c_crossattn": [t["c1"], t["c2"]], "fps": torch.tensor([10]).cuda()}
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    rnd = lambda *shape: torch.randn(*shape, device="cuda", generator=gen)
+    lat0 = rnd(1, 4, 20, 16, 16)
+    noises = [[rnd(1, 4, 8, 16, 16) for _ in range(4)] for _ in range(3)]
+    shifts = [rnd(1, 4, 16, 16) for _ in range(3)]
+    outs = {}
+    import moca_video_amd.fifo as F
+    for use_graph in (True, False):
+        lat = lat0.clone()
+        # fifo_ddim_sampling builds the unconditional dict as a copy of `cond` (funcs.py:268-270): give that copy its own fps where
+        # the two paths receive it (the engine's constructor, the host loop's batched UNet call)
+        real = F.FifoEngine.__init__
+
+        def init(self_e, args, model, sampler, cond_, uc, *a, **k):
+            uc = dict(uc, fps=torch.tensor([24]).cuda())
+            return real(self_e, args, model, sampler, cond_, uc, *a, **k)
+        F.FifoEngine.__init__ = init
+        real_win = s.unet_windows
+
+        def win(windows, c_, ts_list, unconditional_guidance_scale=1., unconditional_conditioning=None, **kw):
+            return real_win(windows, c_, ts_list, unconditional_guidance_scale=unconditional_guidance_scale,
+                            unconditional_conditioning=dict(unconditional_conditioning, fps=torch.tensor([24]).cuda()), **kw)
+        s.unet_windows = win
+        try:
+            frames = fifo_ddim_sampling(FIFO_ARGS, dm, cond, (1, 4, 8, 16, 16), s, cfg_scale=12.0, uc_emb=t["uc"], latents=lat, n_iterations=3,
+                                        noises=noises, shift_noises=shifts, use_graph=use_graph)
+        finally:
+            F.FifoEngine.__init__ = real
+            s.unet_windows = real_win
+        outs[use_graph] = (lat.clone(), [f.clone() for f in frames])
+    assert relerr(outs[True][0], outs[False][0]) < 2e-2
+    for a, b in zip(outs[True][1], outs[False][1]):
+        assert relerr(a, b) < 2e-2
+    # and it differs from the equal-fps video (the fps embedding matters): the shared-prefix engine on the same inputs
+    lat = lat0.clone()
+    fifo_ddim_sampling(FIFO_ARGS, dm, cond, (1, 4, 8, 16, 16), s, cfg_scale=12.0, uc_emb=t["uc"], latents=lat, n_iterations=3,
+                       noises=noises, shift_noises=shifts)
+    assert relerr(lat, outs[True][0]) > 1e-3
+
+
 def test_sam_select_kernel_equals_host_bookkeeping():
     """moca_sam_select_masks_f32 against DDIMSampler.select_sam_masks (the statement-by-statement restatement of ddim.py:739-903 the
     host loop uses, itself pinned by tests/golden/sampler_sam*.npz) on random candidate sets: overlapping blobs around a drifting
