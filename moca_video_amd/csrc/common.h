@@ -61,10 +61,35 @@ __device__ __forceinline__ f32x2 moca_erf2(f32x2 x) {
     y = 1.0f - y * t * e;
     return f32x2{copysignf(y[0], x[0]), copysignf(y[1], x[1])};
 }
-// value * gelu(gate) for two (value, gate) pairs
+// value * gelu(gate) for two (value, gate) pairs.  gelu(g) = g * Phi(g) with Phi from the same A&S 7.1.26 erf, written so that no
+// sign has to be restored:  for x = |g| / sqrt(2), t = 1 / (1 + p x), q = (a1 t + ... + a5 t^5) exp(-x^2) = 1 - erf(x):
+//     gelu(g) = max(g, 0) - |g| q / 2 = g / 2 + |g| (1 - q) / 2
+// (g >= 0: g (1 - q / 2) = g (1 + erf) / 2;  g < 0: g q / 2 = g (1 - erf(|x|)) / 2).  The 1/2 is folded into the coefficients, the
+// 1/sqrt(2) into p, exp(-x^2) = exp2(-(g c)^2) with c = sqrt(log2(e) / 2): 12 plain + 2 transcendental instructions per output in
+// scalar form, 9 issue slots in the packed form below (the round-4 form took 18.5: copysign, 1 - y, (erf + 1), g / 2 and the moves
+// the packed operands needed).
+#ifdef MOCA_GELU_OLD
 __device__ __forceinline__ f32x2 moca_geglu2(f32x2 v, f32x2 g) {
     return v * (g * 0.5f) * (moca_erf2(g * 0.70710678118654752f) + 1.0f);
 }
+#else
+__device__ __forceinline__ f32x2 moca_geglu2(f32x2 v, f32x2 g) {
+    const f32x2 ag = {fabsf(g[0]), fabsf(g[1])};
+    const f32x2 d = ag * (0.3275911f * 0.70710678118654752f) + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 y = t * (0.5f * 1.061405429f) - (0.5f * 1.453152027f);
+    y = y * t + (0.5f * 1.421413741f);
+    y = y * t - (0.5f * 0.284496736f);
+    y = y * t + (0.5f * 0.254829592f);
+    y = y * t;
+    const f32x2 u = g * 0.84932180028801904f;                    // sqrt(log2(e) / 2)
+    const f32x2 s = -u * u;
+    const f32x2 e = {__builtin_amdgcn_exp2f(s[0]), __builtin_amdgcn_exp2f(s[1])};
+    // max(g, 0) - |g| y e = g / 2 + |g| (1 / 2 - y e)      ((g + |g|) / 2 is exact; no v_max, which costs two instructions under IEEE mode)
+    const f32x2 w = 0.5f - y * e;
+    return v * (g * 0.5f + ag * w);
+}
+#endif
 
 // GroupNorm statistics accumulated across blocks (MOCA_EP_GSTAT, concat with statistics): 64-bit FIXED-POINT atomics -- integer
 // addition is associative, so the finished statistics do not depend on the order in which the producer's blocks arrive and a

@@ -16,6 +16,7 @@
 // fp32 LDS tile so that bias / time-embedding / residual are applied in fp32 and the
 // result leaves as full 16-byte coalesced stores.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -443,8 +444,19 @@ __device__ unsigned long long g_stamps[STAMP_BLOCKS * STAMP_SLOTS];
             g_stamps[blockIdx.x * STAMP_SLOTS + (k)] = t__;                                        \
         }                                                                                          \
     } while (0)
+#define MOCA_STAMP_HW()                                                                            \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {                                       \
+            unsigned hw__, xcc__;                                                                  \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw__));                     \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc__));                   \
+            g_stamps[blockIdx.x * STAMP_SLOTS + 6] = hw__;                                         \
+            g_stamps[blockIdx.x * STAMP_SLOTS + 7] = xcc__;                                        \
+        }                                                                                          \
+    } while (0)
 #else
 #define MOCA_STAMP(k) do {} while (0)
+#define MOCA_STAMP_HW() do {} while (0)
 #endif
 
 // q = n / d, r = n % d for 0 <= n < 2^24 via one float multiply and a +-1 fix-up (rd = 1.0f / d);
@@ -1341,15 +1353,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     else if (p.flags & MOCA_EP_ROWSUM) store_fp16_tile_rowsum<512, BN, 4>(p, smem, pitch, TM, m0, n0, tid);
     else store_fp16_tile<512>(p, smem, pitch, TM, out_bn, m0, on0, tid);
     MOCA_STAMP(5);
-#ifdef MOCA_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_stamps[blockIdx.x * STAMP_SLOTS + 6] = hw;
-        g_stamps[blockIdx.x * STAMP_SLOTS + 7] = xcc;
-    }
-#endif
+    MOCA_STAMP_HW();
 }
 
 #ifdef MOCA_STAMPS
@@ -1374,6 +1378,25 @@ namespace {
 // LDS rows are 64 B; chunk swizzle phys = chunk ^ f((row>>2)&3), f = {0,2,3,1} (conflict-free for the four
 // 16-lane groups of ds_read_b128 on the 16x16x32 operand map; derivation in DESIGN.md).
 // =====================================================================================
+// per-CU arrival parity (index = XCC id * 256 + HW_ID[15:8] = se / sh / cu): the second block a CU receives draws 1
+__device__ unsigned g_cu_parity[8 * 256];
+__device__ __forceinline__ void skew_second_block(int cycles) {
+    // EXPERIMENT (MOCA_EXP bit 0): two co-resident blocks that start together stay in lockstep -- both in their main loops, then both
+    // in their epilogues.  The block that arrives second on a CU waits `cycles` once; every later block inherits the offset.
+    __shared__ unsigned par;
+    if (threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        par = atomicXor(&g_cu_parity[(xcc & 7) * 256 + ((hw >> 8) & 255)], 1u) & 1u;
+    }
+    __syncthreads();
+    if (par && (int)blockIdx.x < 512) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < cycles) __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 template <int AMODE, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params p) {
     constexpr int TM = 256, BN = 128, KS = 32;
@@ -1385,6 +1408,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     constexpr int NMMA = MT * NT;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MOCA_STAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1394,6 +1418,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     const int tiles_n = p.N / BN;
     const int nblk = tiles_m * tiles_n * p.splits;
     if (prefetch_block(p, nblk, 256)) return;
+    if (p.reserved2_ > 0) skew_second_block(p.reserved2_);
     int split = 0, tile_m, tile_n;
     if ((p.reserved4_ >> 8) > 1) {                       // 2-D XCD partition (see remap_tile_2d)
         remap_tile_2d(tiles_m, tiles_n, p.reserved4_ >> 8, tile_m, tile_n);
@@ -1514,8 +1539,10 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     issue_pair(kt_begin, 0, 1);
     LnFoldRegs lf = {0.f, 0.f, 0.f, 0.f};
     if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, m0 + tid, tid);
+    MOCA_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    MOCA_STAMP(2);
     for (int i = 0; i < nk; i += 2) {
         phase(yes_t{}, i);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile i+1 landed with its partner; everyone is past tile i's MFMAs
@@ -1525,6 +1552,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
         __builtin_amdgcn_s_barrier();
     }
     // (the last barrier also ends every fragment read: the ring is free for the epilogue)
+    MOCA_STAMP(3);
 
     // ---- epilogue (same scheme as the 8-wave kernel): lane owns 4 consecutive columns of row
     //      m = wave_m*128 + mt*16 + fr: column n = wave_n*64 + nt*16 + 4*fg + r ----
@@ -1596,9 +1624,275 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
         }
     }
     __syncthreads();
+    MOCA_STAMP(4);
     store_fp16_tile<256>(p, smem, pitch, TM, out_bn, m0, on0, tid);
+    MOCA_STAMP(5);
+    MOCA_STAMP_HW();
 }
 
+
+// =====================================================================================
+// "g4p" kernel: the two-blocks-per-CU 256 x 128 x 32 structure of g4 as a PERSISTENT kernel for the linears (A mode LINEAR).
+// Phase stamps of g4 / the 256 x 256 staggered kernel on the GEGLU projection of the 320-channel level
+// (profiles/r05_g4_phase_stamps.txt): of a tile's ~30 k cycles the main loop is 42-44 %; 10-16 % go to the prologue (row set-up,
+// first DMA round trip), 30-35 % to the accumulator -> LDS staging pass with the erf-GELU, 8-10 % to the store loop.  Here
+//   * a block walks its tiles (XCD-local order: the blocks of an XCD work on consecutive tiles of the tile_m-major raster, so an A
+//     row tile is fetched from beyond L2 once and then hit by the blocks that own its other column tiles);
+//   * the DMA stream never stops: the last even phase of a tile issues the first k-tile pair of the NEXT tile (per-lane offsets
+//     switched just before), so there is no prologue except the block's first;
+//   * the ring is never used for staging: W rows are fetched into the LDS tile in a PERMUTED order (free -- the source address of
+//     an LDS-DMA is per lane) chosen so that the 4 + 4 accumulator columns a lane holds in two neighbouring 16-column MFMA tiles are
+//     8 CONSECUTIVE output columns: the epilogue goes from registers to memory as 16-byte stores (16 rows x 64 B per instruction),
+//     no LDS pass, no barrier, and it runs while the next tile's first pair is in flight;
+//   * LayerNorm-fold statistics of a tile (row: rstd, -mean rstd; column: wsum, bias) are fetched at the tile's start and
+//     published in 3 KiB of LDS behind the ring.
+// Buffer-addressed DMA (SGPR descriptors, 32-bit per-lane offsets, out-of-range = zero fill) as in the staggered kernels.
+// =====================================================================================
+// LDS row rho (0..127) of the W tile <- packed W row n0 + g4p_perm(rho): MFMA tile nt = (rho >> 4) & 3, column j = rho & 15 of wave
+// column wn = rho >> 6 holds output column  wn * 64 + (nt >> 1) * 32 + 8 (j >> 2) + 4 (nt & 1) + (j & 3)  of the tile
+__device__ __forceinline__ int g4p_perm(int rho) {
+    const int wn = rho >> 6, nt = (rho >> 4) & 3, j = rho & 15;
+    return wn * 64 + (nt >> 1) * 32 + 8 * (j >> 2) + 4 * (nt & 1) + (j & 3);
+}
+__device__ __forceinline__ void st_out8_nt(half_t* ptr, const half8v v, bool nt) { st_out8(ptr, v, nt); }
+
+template <bool GEGLU>
+__global__ __launch_bounds__(256, 2) void gemm_g4p_kernel(const moca_gemm_params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TM = 256, BN = 128, KS = 32, RB = 64, MT = 8, NT = 4;
+    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB, RING = 3 * STAGE;     // 24 KiB per k-tile, 72 KiB ring
+    constexpr int NMMA = MT * NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lst = reinterpret_cast<float*>(smem + RING);          // [TM] float2 (rstd, -mean rstd), [BN] wsum, [BN] bias  (MFMA column order)
+    float* lws = lst + 2 * TM;
+    float* lbi = lws + BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int nper = p.reserved2_;                               // persistent blocks (multiple of 8); the rest of the grid prefetches
+    if (prefetch_block(p, nper, 256)) return;
+
+    const int tiles_n = p.N / BN;
+    const int ntiles = ((p.M + TM - 1) / TM) * tiles_n;
+    // tiles of this block: XCD x = b & 7 owns a contiguous range of the raster, its J = nper / 8 blocks walk it with stride J
+    int t_cur, t_end;
+    const int J = nper >> 3;
+    {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        t_cur = start + j;
+        t_end = start + q + (x < r ? 1 : 0);
+    }
+    if (t_cur >= t_end) return;                                  // (block-uniform)
+    const int nk = 2 * (p.K / 64);                               // K % 64 == 0 (host-checked)
+
+    // ---- DMA addressing: piece = 16 rows x 64 B, lane -> row lane >> 2, physical chunk lane & 3 ----
+    const int lrow = lane >> 2, pch = lane & 3;
+    const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, OOB_OFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, OOB_OFF, 0x00020000);
+    unsigned a_off[4], w_off[2];
+    int w_perm[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) w_perm[g] = g4p_perm((g * 4 + wave) * 16 + lrow);
+    auto set_dma_tile = [&](int t) {                             // t < 0: no tile (every lane out of range: zero fill, no traffic)
+        const int tm = t / tiles_n, tn = t - tm * tiles_n;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = tm * TM + (g * 4 + wave) * 16 + lrow;
+            a_off[g] = (t >= 0 && row < p.M) ? (unsigned)(((int64_t)row * p.lda + lch * 8) * 2) : OOB_OFF;
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            w_off[g] = t >= 0 ? (unsigned)(((int64_t)(tn * BN + w_perm[g]) * p.ldw + lch * 8) * 2) : OOB_OFF;
+    };
+    auto dma_piece = [&](int kt, int slot, int j) {              // piece j (0..3: A, 4..5: W) of k-tile kt of the DMA tile
+        const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
+        const unsigned soff = (unsigned)(kt * KS * 2);
+        if (j < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, sa + (j * 4 + wave) * 1024, 16, a_off[j], soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, sa + A_BYTES + ((j - 4) * 4 + wave) * 1024, 16, w_off[j - 4], soff, 0, 0);
+    };
+
+    const int fr = lane & 15, fg = lane >> 4;
+    int fa_off[MT], fb_off[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = wave_m * 128 + mt * 16 + fr;
+        fa_off[mt] = row * RB + ((fg ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 4);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int row = wave_n * 64 + nt * 16 + fr;
+        fb_off[nt] = A_BYTES + row * RB + ((fg ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 4);
+    }
+
+    f32x4 acc[MT][NT];
+    half8v af[MT], bf[NT];
+    int s0 = 0, s1 = 1, s2 = 2;                                  // ring slots of k-tiles i, i+1, i+2 of the running stream
+    // one phase = one k-tile: fragments -> registers, 32 MFMAs; EVEN phases issue the pair (kt2, kt2 + 1) of the DMA tile: kt2 into the
+    // slot of k-tile i - 1, kt2 + 1 into k-tile i's own slot (hence the barrier behind the fragment reads)
+    auto phase = [&](auto even_tag, int kt2) {
+        constexpr bool even = decltype(even_tag)::value;
+        const char* cur = smem + s0 * STAGE;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const half8v*>(cur + fa_off[mt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const half8v*>(cur + fb_off[nt]);
+        if constexpr (even) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < NMMA; ++j) {
+            const int mt = j / NT, nt = j % NT;
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);   // D^T: lane = row m
+            if constexpr (even) {
+                if (j % 5 == 2 && j / 5 < 6) {
+                    dma_piece(kt2, s2, j / 5);
+                    dma_piece(kt2 + 1, s0, j / 5);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        { const int t = s0; s0 = s1; s1 = s2; s2 = t; }
+    };
+
+    // statistics of tile t: raw values -> registers (issued early), finished and published behind the tile's main loop
+    const bool fold = (p.flags & MOCA_EP_LNFOLD) != 0;
+    float2 rp0, rp1;
+    float rws, rbi;
+    auto stat_issue = [&](int t) {
+        const int tm = t / tiles_n, tn = t - tm * tiles_n;
+        rp0 = float2{0.f, 0.f}; rp1 = float2{0.f, 0.f}; rws = 0.f; rbi = 0.f;
+        if (tid < BN) {
+            const int n = tn * BN + g4p_perm(tid);
+            if (fold) rws = p.lnf_wsum[n];
+            if (p.bias) rbi = p.bias[n];
+        }
+        if (fold) {
+            const int m = min(tm * TM + tid, p.M - 1);
+            rp0 = *reinterpret_cast<const float2*>(p.lnf_part + (int64_t)m * 2);
+            if (p.lnf_nparts > 1) rp1 = *reinterpret_cast<const float2*>(p.lnf_part + ((int64_t)p.M + m) * 2);
+        }
+    };
+    auto stat_publish = [&](int t) {
+        float rs = 1.f, rb = 0.f;
+        if (fold) {
+            const int tm = t / tiles_n;
+            const int m = min(tm * TM + tid, p.M - 1);
+            float s = rp0.x + rp1.x, q = rp0.y + rp1.y;
+            for (int i = 2; i < p.lnf_nparts; ++i) {
+                const float2 v = *reinterpret_cast<const float2*>(p.lnf_part + ((int64_t)i * p.M + m) * 2);
+                s += v.x; q += v.y;
+            }
+            const float inv_k = 1.0f / (float)p.K;
+            const float mean = s * inv_k;
+            const float var = fmaxf(q * inv_k - mean * mean, 0.f);
+            rs = rsqrtf(var + p.ln_eps);
+            rb = -mean * rs;
+        }
+        *reinterpret_cast<float2*>(lst + 2 * tid) = float2{rs, rb};
+        if (tid < BN) { lws[tid] = rws; lbi[tid] = rbi; }
+    };
+
+    // ---- prologue: first pair of the first tile ----
+    stat_issue(t_cur);
+    set_dma_tile(t_cur);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { dma_piece(0, 0, j); dma_piece(1, 1, j); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const bool nt_out = out_streams(p);
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    while (true) {
+        const int t_next = t_cur + J < t_end ? t_cur + J : -1;
+        const int tm = t_cur / tiles_n, tn = t_cur - tm * tiles_n;
+        const int m0 = tm * TM, n0 = tn * BN;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < nk; i += 2) {
+            const bool last = i + 2 >= nk;
+            if (last) set_dma_tile(t_next);                      // the stream moves on to the next tile's first pair
+            phase(yes_t{}, last ? 0 : i + 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            phase(no_t{}, 0);
+            if (!last) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // pair (i+2, i+3) complete
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        stat_publish(t_cur);
+        if (t_next >= 0) stat_issue(t_next);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        // ---- epilogue from registers: lane = row m0 + wave_m * 128 + mt * 16 + fr, 8 consecutive columns per tile pair ----
+        f32x4 cw[NT], cb[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            cw[nt] = *reinterpret_cast<const f32x4*>(lws + wave_n * 64 + nt * 16 + 4 * fg);
+            cb[nt] = *reinterpret_cast<const f32x4*>(lbi + wave_n * 64 + nt * 16 + 4 * fg);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rl = wave_m * 128 + mt * 16 + fr;
+            const int m = m0 + rl;
+            const float2 st = *reinterpret_cast<const float2*>(lst + 2 * rl);
+            f32x4 v[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) v[nt] = st.x * acc[mt][nt] + (st.y * cw[nt] + cb[nt]);
+            if constexpr (GEGLU) {
+                // value tiles 0, 1 and their gate tiles 2, 3 -> output columns on0 + wave_n * 32 + 8 fg + (0..7)
+                half8v h;
+#pragma unroll
+                for (int nv = 0; nv < 2; ++nv) {
+                    const f32x2 lo = moca_geglu2(f32x2{v[nv][0], v[nv][1]}, f32x2{v[nv + 2][0], v[nv + 2][1]});
+                    const f32x2 hi = moca_geglu2(f32x2{v[nv][2], v[nv][3]}, f32x2{v[nv + 2][2], v[nv + 2][3]});
+                    h[4 * nv + 0] = (half_t)lo[0]; h[4 * nv + 1] = (half_t)lo[1]; h[4 * nv + 2] = (half_t)hi[0]; h[4 * nv + 3] = (half_t)hi[1];
+                }
+                if (m < p.M) st_out8(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + (n0 >> 1) + wave_n * 32 + 8 * fg, h, nt_out);
+            } else {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int col = n0 + wave_n * 64 + hh * 32 + 8 * fg;
+                    float o[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { o[r] = v[2 * hh][r]; o[4 + r] = v[2 * hh + 1][r]; }
+                    if (m < p.M) {
+                        if (rowadd) {
+                            const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) o[r] = (float)(half_t)o[r] + (float)e[r];   // (as the staged kernels: fp16 tile, then + row add, + residual in fp32)
+                        }
+                        if (resid) {
+                            const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) o[r] = (rowadd ? o[r] : (float)(half_t)o[r]) + (float)e[r];
+                        }
+                        half8v h;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) h[r] = (half_t)o[r];
+                        st_out8(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col, h, nt_out);
+                    }
+                }
+            }
+        }
+        if (t_next < 0) break;
+        t_cur = t_next;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           // the next tile's first pair has landed (and the stores have left)
+        __builtin_amdgcn_s_barrier();
+    }
+#endif
+}
 
 // =====================================================================================
 // "w80s" kernel: the 320 x 160 x 32 tile / 80 x 80 wave tile / 5-slot ring of w80b, with the main loop cut into
@@ -1645,6 +1939,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     constexpr int NAP = SQ ? 2 : (WIDE ? 2 : 3);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MOCA_STAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1792,8 +2087,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     issue_pair(2, 3);
     LnFoldRegs lf = {0.f, 0.f, 0.f, 0.f};
     if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, grow(tid), tid);
+    MOCA_STAMP(1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
     __builtin_amdgcn_s_barrier();
+    MOCA_STAMP(2);
     if (late) __builtin_amdgcn_s_barrier();            // from here on waves 4..7 run one barrier behind waves 0..3
 
     int s0 = 0;                                          // ring slot of tile i
@@ -1873,6 +2170,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     if (!late) __builtin_amdgcn_s_barrier();           // the halves meet again
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // every DMA (incl. the repeats) is done: the ring is free for the epilogue
+    MOCA_STAMP(3);
 
     // ---- epilogue (as w80): lane owns 4 consecutive columns n = wave_n*80 + nt*16 + 4*fg + r of row m = wave_m*80 + mt*16 + fr ----
     if (p.splits > 1) {
@@ -1922,7 +2220,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
                     }
                 }
             __syncthreads();
+            MOCA_STAMP(4);
             store_fp16_tile<512>(p, smem, gpitch, TM, BN / 2, m0, n0 / 2, tid);
+            MOCA_STAMP(5);
+            MOCA_STAMP_HW();
             return;
         }
     }
@@ -1954,6 +2255,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         }
     }
     __syncthreads();
+    MOCA_STAMP(4);
     if constexpr (TQ) {
         // temporal attention of the 20 pixels of this tile for head tile_n: q | k | v = columns [0,64) | [64,128) | [128,192) of the
         // staged fp16 rows, 16 frames per pixel.  One wavefront per pixel (pixels w, w + 8, w + 16); the arithmetic is that of
@@ -2012,6 +2314,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         else if (p.flags & MOCA_EP_ROWSUM) store_fp16_tile_rowsum<512, BN, 4>(p, smem, pitch, TM, m0, n0, tid);
         else store_fp16_tile<512>(p, smem, pitch, TM, BN, m0, n0, tid);
     }
+    MOCA_STAMP(5);
+    MOCA_STAMP_HW();
 #endif
 }
 
@@ -2077,6 +2381,13 @@ static inline bool wants_g4(const moca_gemm_params& p) {
     return g4_mode == 2 || (g4_mode == 1 && (p.flags & MOCA_EP_GEGLU) && p.K <= 640 && p.M < (1 << 17));
 }
 static inline bool buffer_addressable(const moca_gemm_params& p);
+static inline bool g4p_ok(const moca_gemm_params& p);
+// the persistent two-blocks-per-CU kernel (MOCA_TUNE_GEMM_G4P = 0: never, 1: the GEGLU projections, 2: every linear it can run -- tests, A/B)
+static inline bool takes_g4p(const moca_gemm_params& p) {
+    const int mode = moca_tuning_get(MOCA_TUNE_GEMM_G4P);
+    if (!mode || !g4p_ok(p)) return false;
+    return mode == 2 || (p.flags & MOCA_EP_GEGLU);
+}
 // the staggered kernel on 256 x 256 tiles for the wide projections (MOCA_TUNE_GEMM_SQ256 = 0: never, 1: not where g4 is preferred,
 // 2: every wide linear -- A/B runs); asked after takes_w80()
 static inline bool takes_sq256(const moca_gemm_params& p, bool use_g4) {
@@ -2134,7 +2445,34 @@ int launch_gemm_g4(const moca_gemm_params& p, hipStream_t st) {
     }
     moca_gemm_params pl = p;
     pl.reserved4_ = (pl.reserved4_ & 0xff) | (choose_xcd_n(p, tiles_m, tiles_n, 256, 128) << 8);
+    static const int skew = getenv("MOCA_G4_SKEW") ? atoi(getenv("MOCA_G4_SKEW")) : 0;
+    pl.reserved2_ = skew;
     hipLaunchKernelGGL((gemm_g4_kernel<AMODE, FAST>), dim3(nblk + 2 * prefetch_blocks(pl)), dim3(256), lds, st, pl);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+// persistent two-blocks-per-CU kernel: which calls it can run (linears whose 256 x 128 tiles fill two blocks on every CU; bias,
+// LayerNorm fold, GEGLU or row add / residual -- none of the statistics epilogues)
+constexpr int G4P_BLOCKS = 512;
+static inline bool g4p_ok(const moca_gemm_params& p) {
+    if (p.a_mode != MOCA_A_LINEAR || p.splits != 1 || p.N % 128 || p.K % 64 || !buffer_addressable(p)) return false;
+    if (p.flags & ~(MOCA_EP_GEGLU | MOCA_EP_LNFOLD)) return false;
+    if ((p.flags & MOCA_EP_GEGLU) && (p.residual || p.rowadd)) return false;
+    return ((p.M + 255) / 256) * (p.N / 128) >= G4P_BLOCKS;
+}
+template <bool GEGLU>
+int launch_gemm_g4p(const moca_gemm_params& p, hipStream_t st) {
+    constexpr int lds = 3 * (256 + 128) * 64 + (2 * 256 + 2 * 128) * 4;      // 72 KiB ring + 3 KiB of tile statistics
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g4p_kernel<GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MOCA_E_LAUNCH;
+        attr_set = true;
+    }
+    moca_gemm_params pl = p;
+    pl.reserved2_ = G4P_BLOCKS;
+    hipLaunchKernelGGL((gemm_g4p_kernel<GEGLU>), dim3(G4P_BLOCKS + 2 * prefetch_blocks(pl)), dim3(256), lds, st, pl);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
@@ -2218,6 +2556,7 @@ static int rowsum_cols(const moca_gemm_params& p) {
 static bool lnfold_ok(const moca_gemm_params& p) {
     if (p.a_mode != MOCA_A_LINEAR || p.splits != 1) return false;
     if (p.flags & (MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_GSTAT | MOCA_EP_LN | MOCA_EP_ROWSUM | MOCA_EP_GELU | MOCA_FORCE_SMALL_TILE)) return false;
+    if (takes_g4p(p)) return true;
     if (takes_w80(p)) return !(p.flags & MOCA_EP_GEGLU) && takes_w80s(p);
     const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
     if (!(big_bn != 0 && p.M > 128)) return false;
@@ -2354,7 +2693,9 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
         return launch_gemm_w80s<MOCA_A_LINEAR, 3>(p, st);
     }
     if ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1 && lnfold_ok(p))) return MOCA_E_BADARG;   // ask moca_gemm_lnfold_ok() first
-    if (use_w80) {
+    if (takes_g4p(p)) {
+        rc = (p.flags & MOCA_EP_GEGLU) ? launch_gemm_g4p<true>(p, st) : launch_gemm_g4p<false>(p, st);
+    } else if (use_w80) {
         rc = launch_gemm_w80_mode(p, st);
     } else if (takes_sq256(p, use_g4)) {
         rc = launch_gemm_w80s<MOCA_A_LINEAR, 2>(p, st);

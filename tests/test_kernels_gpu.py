@@ -497,6 +497,38 @@ def test_gemm_sq256(M, K, N, geglu, with_res, tune):
     check(out, ref, TOL16, f"sq256 {M}x{N}x{K} geglu={geglu}")
 
 
+# ---------------------------------------------------------------- GEMM: the persistent two-blocks-per-CU kernel (register epilogue)
+@pytest.mark.parametrize("M,K,N,kind", [(8200, 320, 2048, "geglu"), (16384, 640, 1024, "geglu"), (8192, 640, 2048, "res"),
+                                        (9000, 128, 2048, "rowadd+res"), (8192, 64, 2048, "plain"), (70000, 320, 256, "res")])
+def test_gemm_g4p(M, K, N, kind, tune):
+    """MOCA_TUNE_GEMM_G4P = 2 sends every linear with >= 512 tiles of 256 x 128 to the persistent kernel: W rows fetched in permuted
+    order, 16-byte stores straight from the accumulators (GEGLU / bias / row add / residual), M tails, a block's walk over several
+    tiles with the DMA stream running across tile boundaries, K = 64 (one k-tile pair per tile)."""
+    tune(L.MOCA_TUNE_GEMM_G4P, 2)
+    a = rnd(M, K)
+    w = rnd(N, K, scale=K ** -0.5)
+    b = rnd(N, dtype=torch.float32, scale=0.1)
+    y = a.float() @ w.float().t() + b
+    if kind == "geglu":
+        pw = ops.pack_geglu(w, b)
+        out = torch.full((M, N // 2), float("nan"), dtype=torch.float16, device=DEV)
+        ops.gemm(a, pw, out, M=M)
+        ref = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+    else:
+        pw = ops.pack_linear(w, b)
+        res = rnd(M, N) if "res" in kind else None
+        div = 100
+        ra = rnd(M // div, N) if "rowadd" in kind else None
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+        ops.gemm(a, pw, out, M=M, residual=res, rowadd=ra, rowadd_div=div if ra is not None else 1)
+        ref = y
+        if ra is not None:
+            ref = ref + ra.float().repeat_interleave(div, dim=0)
+        if res is not None:
+            ref = ref + res.float()
+    check(out, ref, TOL16, f"g4p {M}x{N}x{K} {kind}")
+
+
 # ---------------------------------------------------------------- LayerNorm folded into the consuming linear
 @pytest.mark.parametrize("M,C,Kp,with_res,consumers", [
     (40000, 320, 320, True, [("lin", 960), ("geglu", 1280)]),            # 160 x 320 producer (1 partial); staggered / g4 consumers

@@ -85,6 +85,15 @@ def linear(lv, k, n, geglu=False, splits=None):
     return run(f"linear   L{lv} {k}->{nn}{' geglu' if geglu else ''} M={M} s={s}", fn, 2.0 * M * nn * k)
 
 
+def linear_res(lv, k, n):
+    """with residual (as in the model: attention out-proj, ff2, proj_out all add a residual)"""
+    H, W = LV[lv]; M = F * H * W
+    x = torch.randn(M, k, device=DEV).half()
+    pw = ops.pack_linear(torch.randn(n, k, device=DEV) * k ** -0.5, torch.zeros(n, device=DEV))
+    out = torch.empty(M, n, device=DEV, dtype=torch.float16); res = torch.randn(M, n, device=DEV).half()
+    return run(f"linear+res L{lv} {k}->{n} M={M}", lambda: ops.gemm(x, pw, out, M=M, residual=res), 2.0 * M * n * k)
+
+
 if __name__ == "__main__":
     ops.set_stream(None)
     conv(0, 320, 320); conv(0, 640, 320); conv(0, 960, 320)
@@ -96,11 +105,4 @@ if __name__ == "__main__":
     linear(1, 640, 640); linear(1, 640, 1920); linear(1, 640, 2560, geglu=True); linear(1, 2560, 640)
     linear(2, 1280, 1280); linear(2, 1280, 3840); linear(2, 1280, 5120, geglu=True); linear(2, 5120, 1280)
     linear(3, 1280, 3840); linear(3, 1280, 5120, geglu=True); linear(3, 5120, 1280)
-    # with residual (as in the model: attention out-proj, ff2, proj_out all add a residual)
-    def linear_res(lv, k, n):
-        H, W = LV[lv]; M = F * H * W
-        x = torch.randn(M, k, device=DEV).half()
-        pw = ops.pack_linear(torch.randn(n, k, device=DEV) * k ** -0.5, torch.zeros(n, device=DEV))
-        out = torch.empty(M, n, device=DEV, dtype=torch.float16); res = torch.randn(M, n, device=DEV).half()
-        run(f"linear+res L{lv} {k}->{n} M={M}", lambda: ops.gemm(x, pw, out, M=M, residual=res), 2.0 * M * n * k)
     linear_res(0, 320, 320); linear_res(0, 1280, 320); linear_res(1, 640, 640); linear_res(1, 2560, 640)
