@@ -1810,10 +1810,18 @@ __global__ __launch_bounds__(256, 2) void gemm_g4p_kernel(const moca_gemm_params
     const bool nt_out = out_streams(p);
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
     const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    int tile_no = 0;
+    (void)tile_no;
     while (true) {
         const int t_next = t_cur + J < t_end ? t_cur + J : -1;
         const int tm = t_cur / tiles_n, tn = t_cur - tm * tiles_n;
         const int m0 = tm * TM, n0 = tn * BN;
+#ifdef MOCA_STAMPS
+        const bool stamp_it = tile_no == 2;
+        if (stamp_it) MOCA_STAMP(0);
+        if (stamp_it) MOCA_STAMP(1);
+        if (stamp_it) MOCA_STAMP(2);
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1830,10 +1838,16 @@ __global__ __launch_bounds__(256, 2) void gemm_g4p_kernel(const moca_gemm_params
                 __builtin_amdgcn_s_barrier();
             }
         }
+#ifdef MOCA_STAMPS
+        if (stamp_it) MOCA_STAMP(3);
+#endif
         stat_publish(t_cur);
         if (t_next >= 0) stat_issue(t_next);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef MOCA_STAMPS
+        if (stamp_it) MOCA_STAMP(4);
+#endif
 
         // ---- epilogue from registers: lane = row m0 + wave_m * 128 + mt * 16 + fr, 8 consecutive columns per tile pair ----
         f32x4 cw[NT], cb[NT];
@@ -1886,6 +1900,10 @@ __global__ __launch_bounds__(256, 2) void gemm_g4p_kernel(const moca_gemm_params
                 }
             }
         }
+#ifdef MOCA_STAMPS
+        if (stamp_it) { MOCA_STAMP(5); MOCA_STAMP_HW(); }
+        ++tile_no;
+#endif
         if (t_next < 0) break;
         t_cur = t_next;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           // the next tile's first pair has landed (and the stores have left)
@@ -1893,6 +1911,280 @@ __global__ __launch_bounds__(256, 2) void gemm_g4p_kernel(const moca_gemm_params
     }
 #endif
 }
+
+// "g4q": g4p on v_mfma_f32_32x32x16_f16 (wave tile 128 x 64 = 4 x 2 tiles).  The kernel is bound by the SIMDs' issue port (an MFMA of
+// either shape holds it for 8 cycles): half as many MFMA instructions for the same matrix cycles, the same fragment bytes.
+// W-row permutation for this operand map: LDS row rho -> tile nt = (rho >> 5) & 1 of wave column wn = rho >> 6, MFMA row i = rho & 31 =
+// 8 g + 4 h + r (g = accumulator register group, h = lane >> 5) holds column 16 (g >> 1) + 8 h + 4 (g & 1) + r of the tile's 32.
+__device__ __forceinline__ int g4q_perm(int rho) {
+    const int wn = rho >> 6, nt = (rho >> 5) & 1, i = rho & 31;
+    const int g = i >> 3, h = (i >> 2) & 1, r = i & 3;
+    return wn * 64 + nt * 32 + 16 * (g >> 1) + 8 * h + 4 * (g & 1) + r;
+}
+template <bool GEGLU>
+__global__ __launch_bounds__(256, 2) void gemm_g4q_kernel(const moca_gemm_params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TM = 256, BN = 128, KS = 32, RB = 64, MT = 4, NT = 2;      // 32 x 32 MFMA tiles per wave (128 x 64)
+    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB, RING = 3 * STAGE;     // 24 KiB per k-tile, 72 KiB ring
+        extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lst = reinterpret_cast<float*>(smem + RING);          // [TM] float2 (rstd, -mean rstd), [BN] wsum, [BN] bias  (MFMA column order)
+    float* lws = lst + 2 * TM;
+    float* lbi = lws + BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int nper = p.reserved2_;                               // persistent blocks (multiple of 8); the rest of the grid prefetches
+    if (prefetch_block(p, nper, 256)) return;
+
+    const int tiles_n = p.N / BN;
+    const int ntiles = ((p.M + TM - 1) / TM) * tiles_n;
+    // tiles of this block: XCD x = b & 7 owns a contiguous range of the raster, its J = nper / 8 blocks walk it with stride J
+    int t_cur, t_end;
+    const int J = nper >> 3;
+    {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        t_cur = start + j;
+        t_end = start + q + (x < r ? 1 : 0);
+    }
+    if (t_cur >= t_end) return;                                  // (block-uniform)
+    const int nk = 2 * (p.K / 64);                               // K % 64 == 0 (host-checked)
+
+    // ---- DMA addressing: piece = 16 rows x 64 B, lane -> row lane >> 2, physical chunk lane & 3 ----
+    const int lrow = lane >> 2, pch = lane & 3;
+    const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, OOB_OFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, OOB_OFF, 0x00020000);
+    unsigned a_off[4], w_off[2];
+    int w_perm[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) w_perm[g] = g4q_perm((g * 4 + wave) * 16 + lrow);
+    auto set_dma_tile = [&](int t) {                             // t < 0: no tile (every lane out of range: zero fill, no traffic)
+        const int tm = t / tiles_n, tn = t - tm * tiles_n;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = tm * TM + (g * 4 + wave) * 16 + lrow;
+            a_off[g] = (t >= 0 && row < p.M) ? (unsigned)(((int64_t)row * p.lda + lch * 8) * 2) : OOB_OFF;
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            w_off[g] = t >= 0 ? (unsigned)(((int64_t)(tn * BN + w_perm[g]) * p.ldw + lch * 8) * 2) : OOB_OFF;
+    };
+    auto dma_piece = [&](int kt, int slot, int j) {              // piece j (0..3: A, 4..5: W) of k-tile kt of the DMA tile
+        const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
+        const unsigned soff = (unsigned)(kt * KS * 2);
+        if (j < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, sa + (j * 4 + wave) * 1024, 16, a_off[j], soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, sa + A_BYTES + ((j - 4) * 4 + wave) * 1024, 16, w_off[j - 4], soff, 0, 0);
+    };
+
+    const int fr = lane & 31, fh = lane >> 5;                    // 32x32x16 operand map: row lane & 31, k = 8 (lane >> 5) .. + 7
+    int fa_off[MT][2], fb_off[NT][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = wave_m * 128 + mt * 32 + fr;
+            fa_off[mt][ks] = row * RB + (((2 * ks + fh) ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 4);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int row = wave_n * 64 + nt * 32 + fr;
+            fb_off[nt][ks] = A_BYTES + row * RB + (((2 * ks + fh) ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 4);
+        }
+    }
+
+    f32x16 acc[MT][NT];
+    half8v af[MT][2], bf[NT][2];
+    int s0 = 0, s1 = 1, s2 = 2;                                  // ring slots of k-tiles i, i+1, i+2 of the running stream
+    // one phase = one k-tile: fragments -> registers, 32 MFMAs; EVEN phases issue the pair (kt2, kt2 + 1) of the DMA tile: kt2 into the
+    // slot of k-tile i - 1, kt2 + 1 into k-tile i's own slot (hence the barrier behind the fragment reads)
+    auto phase = [&](auto even_tag, int kt2) {
+        constexpr bool even = decltype(even_tag)::value;
+        const char* cur = smem + s0 * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt][ks] = *reinterpret_cast<const half8v*>(cur + fb_off[nt][ks]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt][ks] = *reinterpret_cast<const half8v*>(cur + fa_off[mt][ks]);
+        }
+        if constexpr (even) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 2 * MT * NT; ++j) {
+            const int ks = j / (MT * NT), mt = (j / NT) % MT, nt = j % NT;
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);   // D^T: lane & 31 = row m
+            if constexpr (even) {
+                if ((j & 1) && j / 2 < 6) {
+                    dma_piece(kt2, s2, j / 2);
+                    dma_piece(kt2 + 1, s0, j / 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        { const int t = s0; s0 = s1; s1 = s2; s2 = t; }
+    };
+
+    // statistics of tile t: raw values -> registers (issued early), finished and published behind the tile's main loop
+    const bool fold = (p.flags & MOCA_EP_LNFOLD) != 0;
+    float2 rp0, rp1;
+    float rws, rbi;
+    auto stat_issue = [&](int t) {
+        const int tm = t / tiles_n, tn = t - tm * tiles_n;
+        rp0 = float2{0.f, 0.f}; rp1 = float2{0.f, 0.f}; rws = 0.f; rbi = 0.f;
+        if (tid < BN) {
+            const int n = tn * BN + g4q_perm(tid);
+            if (fold) rws = p.lnf_wsum[n];
+            if (p.bias) rbi = p.bias[n];
+        }
+        if (fold) {
+            const int m = min(tm * TM + tid, p.M - 1);
+            rp0 = *reinterpret_cast<const float2*>(p.lnf_part + (int64_t)m * 2);
+            if (p.lnf_nparts > 1) rp1 = *reinterpret_cast<const float2*>(p.lnf_part + ((int64_t)p.M + m) * 2);
+        }
+    };
+    auto stat_publish = [&](int t) {
+        float rs = 1.f, rb = 0.f;
+        if (fold) {
+            const int tm = t / tiles_n;
+            const int m = min(tm * TM + tid, p.M - 1);
+            float s = rp0.x + rp1.x, q = rp0.y + rp1.y;
+            for (int i = 2; i < p.lnf_nparts; ++i) {
+                const float2 v = *reinterpret_cast<const float2*>(p.lnf_part + ((int64_t)i * p.M + m) * 2);
+                s += v.x; q += v.y;
+            }
+            const float inv_k = 1.0f / (float)p.K;
+            const float mean = s * inv_k;
+            const float var = fmaxf(q * inv_k - mean * mean, 0.f);
+            rs = rsqrtf(var + p.ln_eps);
+            rb = -mean * rs;
+        }
+        *reinterpret_cast<float2*>(lst + 2 * tid) = float2{rs, rb};
+        if (tid < BN) { lws[tid] = rws; lbi[tid] = rbi; }
+    };
+
+    // ---- prologue: first pair of the first tile ----
+    stat_issue(t_cur);
+    set_dma_tile(t_cur);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { dma_piece(0, 0, j); dma_piece(1, 1, j); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const bool nt_out = out_streams(p);
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    while (true) {
+        const int t_next = t_cur + J < t_end ? t_cur + J : -1;
+        const int tm = t_cur / tiles_n, tn = t_cur - tm * tiles_n;
+        const int m0 = tm * TM, n0 = tn * BN;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        for (int i = 0; i < nk; i += 2) {
+            const bool last = i + 2 >= nk;
+            if (last) set_dma_tile(t_next);                      // the stream moves on to the next tile's first pair
+            phase(yes_t{}, last ? 0 : i + 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            phase(no_t{}, 0);
+            if (!last) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // pair (i+2, i+3) complete
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        stat_publish(t_cur);
+        if (t_next >= 0) stat_issue(t_next);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        // ---- epilogue from registers: lane = row m0 + wave_m * 128 + mt * 32 + (lane & 31); accumulator registers 4 g + r of a tile
+        //      are (permuted W rows) columns 16 (g >> 1) + 8 (lane >> 5) + 4 (g & 1) + r of the tile's 32 ----
+        // (the 16 column constants of a lane stay in registers for the GEGLU form; the plain form, which also holds row add / residual
+        //  operands, re-reads them from LDS per use)
+        f32x4 cw[NT][4], cb[NT][4];
+        if constexpr (GEGLU) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    cw[nt][g] = *reinterpret_cast<const f32x4*>(lws + wave_n * 64 + nt * 32 + 8 * g + 4 * fh);
+                    cb[nt][g] = *reinterpret_cast<const f32x4*>(lbi + wave_n * 64 + nt * 32 + 8 * g + 4 * fh);
+                }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rl = wave_m * 128 + mt * 32 + fr;
+            const int m = m0 + rl;
+            const float2 st = *reinterpret_cast<const float2*>(lst + 2 * rl);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {                        // store s: registers g = 2 s, 2 s + 1 -> 8 consecutive columns 16 s + 8 fh
+                f32x4 v[NT][2];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int g = 2 * s + gg;
+                        const f32x4 a4 = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                        if constexpr (!GEGLU) {
+                            cw[nt][g] = *reinterpret_cast<const f32x4*>(lws + wave_n * 64 + nt * 32 + 8 * g + 4 * fh);
+                            cb[nt][g] = *reinterpret_cast<const f32x4*>(lbi + wave_n * 64 + nt * 32 + 8 * g + 4 * fh);
+                        }
+                        v[nt][gg] = st.x * a4 + (st.y * cw[nt][g] + cb[nt][g]);
+                    }
+                if constexpr (GEGLU) {
+                    half8v h;
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const f32x2 lo = moca_geglu2(f32x2{v[0][gg][0], v[0][gg][1]}, f32x2{v[1][gg][0], v[1][gg][1]});
+                        const f32x2 hi = moca_geglu2(f32x2{v[0][gg][2], v[0][gg][3]}, f32x2{v[1][gg][2], v[1][gg][3]});
+                        h[4 * gg + 0] = (half_t)lo[0]; h[4 * gg + 1] = (half_t)lo[1]; h[4 * gg + 2] = (half_t)hi[0]; h[4 * gg + 3] = (half_t)hi[1];
+                    }
+                    if (m < p.M) st_out8(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + (n0 >> 1) + wave_n * 32 + 16 * s + 8 * fh, h, nt_out);
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int col = n0 + wave_n * 64 + nt * 32 + 16 * s + 8 * fh;
+                        float o[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { o[r] = v[nt][0][r]; o[4 + r] = v[nt][1][r]; }
+                        if (m < p.M) {
+                            if (rowadd) {
+                                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) o[r] = (float)(half_t)o[r] + (float)e[r];
+                            }
+                            if (resid) {
+                                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) o[r] = (rowadd ? o[r] : (float)(half_t)o[r]) + (float)e[r];
+                            }
+                            half8v h;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) h[r] = (half_t)o[r];
+                            st_out8(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col, h, nt_out);
+                        }
+                    }
+                }
+            }
+        }
+        if (t_next < 0) break;
+        t_cur = t_next;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           // the next tile's first pair has landed (and the stores have left)
+        __builtin_amdgcn_s_barrier();
+    }
+#endif
+}
+
 
 // =====================================================================================
 // "w80s" kernel: the 320 x 160 x 32 tile / 80 x 80 wave tile / 5-slot ring of w80b, with the main loop cut into
@@ -2472,7 +2764,17 @@ int launch_gemm_g4p(const moca_gemm_params& p, hipStream_t st) {
     }
     moca_gemm_params pl = p;
     pl.reserved2_ = G4P_BLOCKS;
-    hipLaunchKernelGGL((gemm_g4p_kernel<GEGLU>), dim3(G4P_BLOCKS + 2 * prefetch_blocks(pl)), dim3(256), lds, st, pl);
+    if (moca_tuning_get(MOCA_TUNE_GEMM_MF32)) {
+        static bool attr_set_q = false;
+        if (!attr_set_q) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g4q_kernel<GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                return MOCA_E_LAUNCH;
+            attr_set_q = true;
+        }
+        hipLaunchKernelGGL((gemm_g4q_kernel<GEGLU>), dim3(G4P_BLOCKS + 2 * prefetch_blocks(pl)), dim3(256), lds, st, pl);
+    } else {
+        hipLaunchKernelGGL((gemm_g4p_kernel<GEGLU>), dim3(G4P_BLOCKS + 2 * prefetch_blocks(pl)), dim3(256), lds, st, pl);
+    }
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }
