@@ -434,11 +434,19 @@ __device__ __attribute__((aligned(16))) half_t g_zero_page[ZERO_PAGE_HALVES];
 
 #ifdef MOCA_STAMPS
 // diagnostic build only (-DMOCA_STAMPS): per-block s_memtime stamps, read back with moca_debug_stamps()
-constexpr int STAMP_SLOTS = 8, STAMP_BLOCKS = 16384;
+constexpr int STAMP_SLOTS = 16, STAMP_BLOCKS = 16384;
 __device__ unsigned long long g_stamps[STAMP_BLOCKS * STAMP_SLOTS];
 #define MOCA_STAMP(k)                                                                              \
     do {                                                                                           \
         if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {                                       \
+            unsigned long long t__;                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
+            g_stamps[blockIdx.x * STAMP_SLOTS + (k)] = t__;                                        \
+        }                                                                                          \
+    } while (0)
+#define MOCA_STAMP_W(k, w)                                                                         \
+    do {                                                                                           \
+        if (threadIdx.x == (w) * 64 && blockIdx.x < STAMP_BLOCKS) {                                \
             unsigned long long t__;                                                                \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
             g_stamps[blockIdx.x * STAMP_SLOTS + (k)] = t__;                                        \
@@ -2421,10 +2429,23 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         }
 #endif
         // ---- LOADe: tile i only ----
+#ifdef MOCA_STAMPS
+#ifndef SEG_WAVE
+#define SEG_WAVE 0
+#endif
+        const bool seg = i == 2;
+        if (seg) MOCA_STAMP_W(8, SEG_WAVE);
+#endif
         read_tile(int_c<0>{}, s0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MOCA_STAMPS
+        if (seg) MOCA_STAMP_W(9, SEG_WAVE);
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef MOCA_STAMPS
+        if (seg) MOCA_STAMP_W(10, SEG_WAVE);
+#endif
         // ---- MFMAe with the reads of tile i+1 in the gaps ----
         {
             const char* nx = smem + s1 * STAGE;
@@ -2445,14 +2466,29 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MOCA_STAMPS
+        if (seg) MOCA_STAMP_W(11, SEG_WAVE);
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef MOCA_STAMPS
+        if (seg) MOCA_STAMP_W(12, SEG_WAVE);
+#endif
 #endif
         // ---- LOADo ----
         ga.advance();
         issue_pair(sp, s0);
+#ifdef MOCA_STAMPS
+        if (seg) MOCA_STAMP_W(13, SEG_WAVE);
+#endif
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MOCA_STAMPS
+        if (seg) MOCA_STAMP_W(14, SEG_WAVE);
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef MOCA_STAMPS
+        if (seg) MOCA_STAMP_W(15, SEG_WAVE);
+#endif
         // ---- MFMAo ----
         mfma_tile(int_c<1>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -2611,6 +2647,409 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
 #endif
 }
 
+// =====================================================================================
+// "sqp" kernel: the 256 x 256 staggered kernel (SHAPE 2 above: 8 waves as 4 x 2, wave tile 64 x 128, 5-slot ring of 32 KiB k-tiles, the
+// two waves of a SIMD half an iteration apart) as a PERSISTENT kernel with a REGISTER epilogue, for the wide linears (GEGLU
+// projections first).  Per 256 x 256 tile of the 320-channel GEGLU the round-4 kernel spent 31.5 k cycles: 5.0 k in the prologue, 14.0 k in
+// the main loop, 9.5 k in the accumulator -> LDS staging pass with the erf-GELU, 2.5 k in the store loop
+// (profiles/r05_g4_phase_stamps.txt).  Here
+//   * one block per CU walks its tiles; the DMA stream is CONTINUOUS: the pair issued in an iteration's LOADo segment simply moves on to
+//     the next tile's k-tiles when the current tile's are exhausted, so a tile's first two pairs are landing while the previous tile's
+//     last iterations and epilogue run -- no prologue, no drain, no repeated pieces;
+//   * W rows are fetched into the LDS tile in the permuted order of g4p_perm, so a lane's accumulators in two neighbouring MFMA tiles
+//     are 8 consecutive output columns and the epilogue stores 16 bytes per lane straight from registers (16 rows x 64 B per
+//     instruction): the ring is never used for staging, nothing waits for it to drain;
+//   * tile statistics (LayerNorm fold: rstd, -mean rstd per row; wsum, bias per column) travel in four registers through the main
+//     loop, as in the staggered kernel, and are published in the ONE ring slot that is free during an epilogue (the slot of the tile's
+//     last k-tile: the stream refills it in the next tile's first LOADo, two barriers after the late half's epilogue has ended).
+// =====================================================================================
+// LDS accesses the compiler must not see: a read / write of ring memory that it cannot prove disjoint from an LDS-DMA in flight is
+// given an `s_waitcnt vmcnt(0)` of its own (eight per epilogue here, each behind a global store).  Addresses are LDS byte offsets;
+// lds_wait() = lgkmcnt(0) + the scheduling fence that keeps consumers below it (cdna_hip_programming.md rule 18).
+__device__ __forceinline__ void lds_wr_f2(unsigned a, f32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_wr_f1(unsigned a, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x2 lds_rd_f2(unsigned a) { f32x2 v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(a) : "memory"); return v; }
+__device__ __forceinline__ f32x4 lds_rd_f4(unsigned a) { f32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory"); return v; }
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+
+__device__ __forceinline__ int sqp_perm(int rho) {              // LDS row of the 256-row W tile -> packed W row of the tile (64-column groups as g4p_perm)
+    return (rho & ~63) + (g4p_perm(rho & 127) & 63);
+}
+
+template <bool GEGLU>
+__global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifndef SEG_WAVE
+#define SEG_WAVE 0
+#endif
+    constexpr int MT = 4, NT = 8, KS = 32, RB = 64, WTM = 64, WTN = 128, TM = 256, BN = 256;
+    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB, NS = 5, PPW = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const bool late = wave >= 4;
+    const int nper = p.reserved2_;                               // persistent blocks (multiple of 8); the rest of the grid prefetches
+    if (prefetch_block(p, nper, 512)) return;
+
+    // ---- this block's tiles: XCD x = b & 7 owns either a contiguous range of the tile_m-major raster or (xcd_n > 1) an xm x xn sub-grid,
+    //      its J = nper / 8 blocks walk it with stride J ----
+    const int tiles_n = p.N / BN, tiles_m = (p.M + TM - 1) / TM;
+    const int xcd_n = p.reserved4_ >> 8;
+    const int J = nper >> 3;
+    int q_base, q_cnt, sub_n, tm_base, tn_base;
+    {
+        const int x = blockIdx.x & 7;
+        if (xcd_n > 1) {
+            const int xm = 8 / xcd_n, sm = tiles_m / xm;
+            sub_n = tiles_n / xcd_n;
+            const int xi = x / xcd_n, xj = x - xi * xcd_n;
+            tm_base = xi * sm; tn_base = xj * sub_n;
+            q_base = 0; q_cnt = sm * sub_n;
+        } else {
+            const int ntiles = tiles_m * tiles_n, q = ntiles >> 3, r = ntiles & 7;
+            q_base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+            q_cnt = q + (x < r ? 1 : 0);
+            sub_n = tiles_n; tm_base = 0; tn_base = 0;
+        }
+    }
+    auto tile_of = [&](int q, int& tm, int& tn) {                // q-th tile of this XCD's set
+        const int l = q_base + q;
+        const int a = l / sub_n;
+        tm = tm_base + a; tn = tn_base + (l - a * sub_n);
+    };
+    int q_cur = blockIdx.x >> 3;
+    if (q_cur >= q_cnt) return;                                  // (block-uniform)
+    const int nk = p.K / 32;                                     // K % 64 == 0 (host-checked): an even number of k-tiles
+
+    // ---- DMA stream: piece = 16 rows x 64 B; A pieces w and 8 + w, W pieces w and 8 + w of every k-tile (4 per wave) ----
+    const int lrow = lane >> 2, pch = lane & 3;
+    const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, OOB_OFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, OOB_OFF, 0x00020000);
+    unsigned a_off[2], w_off[2];
+    int d_q = q_cur, d_k = 0;                                    // tile / even k-tile of the next pair the stream issues
+    auto set_dma_tile = [&](int q) {                             // q >= q_cnt: no tile (every lane out of range: zero fill, no traffic)
+        int tm, tn;
+        tile_of(q, tm, tn);
+        const bool any = q < q_cnt;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int row = tm * TM + (g * 8 + wave) * 16 + lrow;
+            a_off[g] = (any && row < p.M) ? (unsigned)(((int64_t)row * p.lda + lch * 8) * 2) : OOB_OFF;
+            w_off[g] = any ? (unsigned)(((int64_t)(tn * BN + sqp_perm((g * 8 + wave) * 16 + lrow)) * p.ldw + lch * 8) * 2) : OOB_OFF;
+        }
+    };
+    auto issue_pair = [&](int slot_even, int slot_odd) {
+        const unsigned soff = (unsigned)(d_k * KS * 2);
+        const lds_ptr se = (lds_ptr)smem + slot_even * STAGE, so = (lds_ptr)smem + slot_odd * STAGE;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, se + (g * 8 + wave) * 1024, 16, a_off[g], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, so + (g * 8 + wave) * 1024, 16, a_off[g], soff + KS * 2, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, se + A_BYTES + (g * 8 + wave) * 1024, 16, w_off[g], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, so + A_BYTES + (g * 8 + wave) * 1024, 16, w_off[g], soff + KS * 2, 0, 0);
+        }
+        d_k += 2;
+        if (d_k >= nk) { d_k = 0; d_q += J; set_dma_tile(d_q); }
+    };
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int swz = (fg ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
+    const int a_off0 = (wave_m * WTM + fr) * RB + swz;
+    const int b_off0 = A_BYTES + (wave_n * WTN + fr) * RB + swz;
+    f32x4 acc[MT][NT];
+    half8v af[2][MT], bf[2][NT];
+    auto read_tile = [&](auto set_tag, int slot) {
+        constexpr int S = decltype(set_tag)::value;
+        const char* cur = smem + slot * STAGE;
+#pragma unroll
+        for (int r = 0; r < NT; ++r) bf[S][r] = *reinterpret_cast<const half8v*>(cur + b_off0 + r * 1024);
+#pragma unroll
+        for (int r = 0; r < MT; ++r) af[S][r] = *reinterpret_cast<const half8v*>(cur + a_off0 + r * 1024);
+    };
+
+    // (asm volatile: recomputed where it is used -- as a loop invariant it is hoisted, kept across the main loop and spilled)
+    auto tid_now = [&]() -> int {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return wave * 64 + l;
+    };
+    // ---- tile statistics: thread t < 256 (the early half) owns row t and LDS column t of the tile.  The values of tile q + 1 are
+    //      fetched at the head of tile q's epilogue and finished behind its stores; they travel through the main loop as four registers
+    //      (rstd, -mean rstd, wsum, bias).  The loads are INLINE ASM with a counted wait of their own: a VGPR load the compiler knows about
+    //      makes it guard every later write of those registers (fragment reads in the main loop, the next fetch) with `s_waitcnt
+    //      vmcnt(0)`, which drains the DMA stream once per iteration.  Every lane loads (dummy addresses where it has nothing to fetch):
+    //      no branch, a fixed count. ----
+    const bool fold = (p.flags & MOCA_EP_LNFOLD) != 0;
+    struct StatRaw { f32x2 p0, p1; float ws, b; };
+    const float* const dummy = reinterpret_cast<const float*>(p.w);
+    auto stat_issue = [&](int q) -> StatRaw {
+        int tm, tn;
+        tile_of(q < q_cnt ? q : 0, tm, tn);
+        const int t256 = tid_now() & 255;
+        const int n = tn * BN + sqp_perm(t256);
+        const int m = min(tm * TM + t256, p.M - 1);
+        const float* a0 = fold ? p.lnf_part + (int64_t)m * 2 : dummy;
+        const float* a1 = (fold && p.lnf_nparts > 1) ? p.lnf_part + ((int64_t)p.M + m) * 2 : dummy;
+        const float* a2 = fold ? p.lnf_wsum + n : dummy;
+        const float* a3 = p.bias ? p.bias + n : dummy;
+        StatRaw r;
+        asm volatile("global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off"
+                     : "=&v"(r.p0), "=&v"(r.p1), "=&v"(r.ws), "=&v"(r.b) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+        return r;
+    };
+    // (`after` = vector-memory instructions this wave has issued behind the loads, at least: the wait leaves that many outstanding)
+    // Row partials beyond the second (the 1280-channel level: 4 or 10 per row) are fetched here, eight at a time, behind a full drain:
+    // once per tile, where a tile is 40 k-tiles long.
+    auto stat_finish = [&](StatRaw& r, int q, auto after_tag) -> LnFoldRegs {
+        constexpr int after = decltype(after_tag)::value;
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.p0), "+v"(r.p1), "+v"(r.ws), "+v"(r.b) : "n"(after) : "memory");
+        LnFoldRegs f = {1.f, 0.f, fold ? r.ws : 0.f, p.bias ? r.b : 0.f};
+        if (fold) {
+            float s = r.p0[0] + (p.lnf_nparts > 1 ? r.p1[0] : 0.f), qq = r.p0[1] + (p.lnf_nparts > 1 ? r.p1[1] : 0.f);
+            for (int i0 = 2; i0 < p.lnf_nparts; i0 += 8) {       // (block-uniform)
+                int tm, tn;
+                tile_of(q < q_cnt ? q : 0, tm, tn);
+                const int m = min(tm * TM + (tid_now() & 255), p.M - 1);
+                f32x2 e[8];
+                const float* ea[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ea[j] = i0 + j < p.lnf_nparts ? p.lnf_part + ((int64_t)(i0 + j) * p.M + m) * 2 : dummy;
+                asm volatile("global_load_dwordx2 %0, %8, off\n\tglobal_load_dwordx2 %1, %9, off\n\tglobal_load_dwordx2 %2, %10, off\n\t"
+                             "global_load_dwordx2 %3, %11, off\n\tglobal_load_dwordx2 %4, %12, off\n\tglobal_load_dwordx2 %5, %13, off\n\t"
+                             "global_load_dwordx2 %6, %14, off\n\tglobal_load_dwordx2 %7, %15, off\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(e[4]), "=&v"(e[5]), "=&v"(e[6]), "=&v"(e[7])
+                             : "v"(ea[0]), "v"(ea[1]), "v"(ea[2]), "v"(ea[3]), "v"(ea[4]), "v"(ea[5]), "v"(ea[6]), "v"(ea[7]) : "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (i0 + j < p.lnf_nparts) { s += e[j][0]; qq += e[j][1]; }
+            }
+            const float inv_k = 1.0f / (float)p.K;
+            const float mean = s * inv_k;
+            const float var = fmaxf(qq * inv_k - mean * mean, 0.f);
+            f.rs = rsqrtf(var + p.ln_eps);
+            f.rb = -mean * f.rs;
+        }
+        return f;
+    };
+
+    // ---- prologue (once per block): two pairs in flight, the first landed everywhere ----
+    LnFoldRegs lf;
+    {
+        StatRaw raw0 = stat_issue(q_cur);
+        lf = stat_finish(raw0, q_cur, int_c<0>{});
+    }
+    set_dma_tile(q_cur);
+    issue_pair(0, 1);
+    issue_pair(2, 3);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();                      // from here on waves 4..7 run one barrier behind waves 0..3
+
+#ifdef SQP_NO_NT
+    const bool nt_out = false;
+#else
+    const bool nt_out = out_streams(p);
+#endif
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    int s0 = 0;                                                  // ring slot of the running stream's current k-tile
+    bool lenient_first = false;                                  // the previous tile's epilogue issued its full count of stores
+#ifdef MOCA_STAMPS
+    int tile_no = 0;
+#endif
+    while (true) {
+        int tm, tn;
+        tile_of(q_cur, tm, tn);
+        const int m0 = tm * TM, n0 = tn * BN;
+#ifdef MOCA_STAMPS
+        const bool stamp_it = tile_no == 3;          // (phases: [0, 0, main loop, publish + barrier, epilogue arithmetic + stores] + the statistics wait)
+        if (stamp_it) { MOCA_STAMP(0); }
+#endif
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < nk; i += 2) {
+            const int s1 = s0 + 1 == NS ? 0 : s0 + 1;
+            const int sp = s0 == 0 ? NS - 1 : s0 - 1;
+            // ---- LOADe: k-tile i ----
+#ifdef MOCA_STAMPS
+            const bool seg = stamp_it && i == 2;
+            if (seg) MOCA_STAMP_W(8, SEG_WAVE);
+#endif
+            read_tile(int_c<0>{}, s0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef MOCA_STAMPS
+            if (seg) MOCA_STAMP_W(9, SEG_WAVE);
+#endif
+            __builtin_amdgcn_s_barrier();
+#ifdef MOCA_STAMPS
+            if (seg) MOCA_STAMP_W(10, SEG_WAVE);
+#endif
+            // ---- MFMAe with the reads of k-tile i + 1 in the gaps ----
+            {
+                const char* nx = smem + s1 * STAGE;
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < MT * NT; ++j) {
+                    const int mt = j / NT, nt = j % NT;
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][nt], af[0][mt], acc[mt][nt], 0, 0, 0);
+                    if (j % 2 == 0 && j / 2 < MT + NT) {
+                        const int r = j / 2;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (r < NT) bf[1][r] = *reinterpret_cast<const half8v*>(nx + b_off0 + r * 1024);
+                        else af[1][r - NT] = *reinterpret_cast<const half8v*>(nx + a_off0 + (r - NT) * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef MOCA_STAMPS
+            if (seg) MOCA_STAMP_W(11, SEG_WAVE);
+#endif
+            __builtin_amdgcn_s_barrier();
+#ifdef MOCA_STAMPS
+            if (seg) MOCA_STAMP_W(12, SEG_WAVE);
+#endif
+            // ---- LOADo: the stream's next pair into the slots of k-tiles i - 1 and i; the pair before it has landed ----
+            issue_pair(sp, s0);
+#ifdef MOCA_STAMPS
+            if (seg) MOCA_STAMP_W(13, SEG_WAVE);
+#endif
+            // (the first LOADo behind an epilogue: its stores are younger than the pair this wait is for -- leave them outstanding too;
+            //  a tile with rows past M may have issued fewer: plain wait)
+            if (i == 0 && lenient_first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW + (GEGLU ? 8 : 16)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef MOCA_STAMPS
+            if (seg) MOCA_STAMP_W(14, SEG_WAVE);
+#endif
+            __builtin_amdgcn_s_barrier();
+#ifdef MOCA_STAMPS
+            if (seg) MOCA_STAMP_W(15, SEG_WAVE);
+#endif
+            // ---- MFMAo ----
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[1][nt], af[1][mt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef MOCA_STAMPS
+            if (seg) MOCA_STAMP_W(1, SEG_WAVE);
+#endif
+            __builtin_amdgcn_s_barrier();
+#ifdef MOCA_STAMPS
+            if (seg) MOCA_STAMP_W(2, SEG_WAVE);
+#endif
+            s0 = s1 + 1 == NS ? 0 : s1 + 1;
+        }
+#ifdef MOCA_STAMPS
+        if (stamp_it) MOCA_STAMP(3);
+#endif
+        // ---- epilogue: statistics -> the free slot (that of the tile's last k-tile), then registers -> memory.  The halves MEET first
+        //      (waves 0..3 wait for waves 4..7's last MFMAo) and part again behind it: one barrier apart, with no barrier inside, the
+        //      two epilogues would run one after the other -- each half's 6 k cycles of arithmetic inside the other's barrier wait ----
+        if (!late) __builtin_amdgcn_s_barrier();
+        const unsigned lst = (unsigned)(size_t)((lds_ptr)smem + (s0 == 0 ? NS - 1 : s0 - 1) * STAGE);   // [TM] float2, [BN] wsum, [BN] bias
+        const unsigned lws = lst + 8 * TM, lbi = lws + 4 * BN;
+        if (!late) {
+            const int t = tid_now();                              // (recomputed: a thread id kept across the main loop is the one value it spills)
+            lds_wr_f2(lst + 8 * t, f32x2{lf.rs, lf.rb});
+            lds_wr_f1(lws + 4 * t, lf.ws);
+            lds_wr_f1(lbi + 4 * t, lf.b);
+        }
+        lds_wait();
+        __builtin_amdgcn_s_barrier();
+#ifdef MOCA_STAMPS
+        if (stamp_it) MOCA_STAMP(4);
+#endif
+        f32x2 st[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) st[mt] = lds_rd_f2(lst + 8 * (wave_m * WTM + mt * 16 + fr));
+        const int q_next = q_cur + J;
+        StatRaw raw = stat_issue(q_next);                         // (in flight under the epilogue's arithmetic; finished behind its stores)
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            f32x4 cw[4], cb[4];                                   // (per 64-column group: 32 registers instead of 64)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                cw[t] = lds_rd_f4(lws + 4 * (wave_n * WTN + (grp * 4 + t) * 16 + 4 * fg));
+                cb[t] = lds_rd_f4(lbi + 4 * (wave_n * WTN + (grp * 4 + t) * 16 + 4 * fg));
+            }
+            lds_wait();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m0 + wave_m * WTM + mt * 16 + fr;
+                f32x4 v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = st[mt][0] * acc[mt][grp * 4 + t] + (st[mt][1] * cw[t] + cb[t]);
+                if constexpr (GEGLU) {
+                    half8v h;
+#pragma unroll
+                    for (int nv = 0; nv < 2; ++nv) {
+                        const f32x2 lo = moca_geglu2(f32x2{v[nv][0], v[nv][1]}, f32x2{v[nv + 2][0], v[nv + 2][1]});
+                        const f32x2 hi = moca_geglu2(f32x2{v[nv][2], v[nv][3]}, f32x2{v[nv + 2][2], v[nv + 2][3]});
+                        h[4 * nv + 0] = (half_t)lo[0]; h[4 * nv + 1] = (half_t)lo[1]; h[4 * nv + 2] = (half_t)hi[0]; h[4 * nv + 3] = (half_t)hi[1];
+                    }
+                    if (m < p.M) st_out8(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + (n0 >> 1) + wave_n * 64 + grp * 32 + 8 * fg, h, nt_out);
+                } else {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int col = n0 + wave_n * WTN + grp * 64 + hh * 32 + 8 * fg;
+                        float o[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { o[r] = v[2 * hh][r]; o[4 + r] = v[2 * hh + 1][r]; }
+                        if (m < p.M) {
+                            if (rowadd) {
+                                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) o[r] = (float)(half_t)o[r] + (float)e[r];
+                            }
+                            if (resid) {
+                                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) o[r] = (rowadd ? o[r] : (float)(half_t)o[r]) + (float)e[r];
+                            }
+                            half8v h;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) h[r] = (half_t)o[r];
+                            st_out8(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col, h, nt_out);
+                        }
+                    }
+                }
+            }
+        }
+        // the next tile's statistics: complete once at most the stores issued behind their loads are outstanding (GEGLU: 8 per lane, plain
+        // 16; a tile with rows past M may have skipped stores: full drain there)
+#ifdef MOCA_STAMPS
+        if (stamp_it) { MOCA_STAMP(5); MOCA_STAMP_HW(); }
+        ++tile_no;
+#endif
+        if (m0 + TM > p.M) lf = stat_finish(raw, q_next, int_c<0>{});
+        else lf = stat_finish(raw, q_next, int_c<(GEGLU ? 8 : 16)>{});
+        if (q_next >= q_cnt) break;
+#ifndef SQP_STRICT_FIRST
+        lenient_first = m0 + TM <= p.M;
+#endif
+        q_cur = q_next;
+        if (late) __builtin_amdgcn_s_barrier();                  // waves 4..7 fall one barrier behind again
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the stream's last pairs were zero fill; the halves are together here)
+#endif
+}
+
 // XCD partition (xm x xn = 8, xn returned; 1 = the 1-D partition) of a tiles_m x tiles_n grid of TM x BN tiles of a LINEAR
 // launch: estimated fabric bytes = W part + A part.  W: an XCD whose W sub-range ((tiles_n / xn) BN x K) fits its L2 (<= 3 MB)
 // fetches it once -> xm |W| in total; one that does not streams it again for every M tile it owns -> tiles_m |W| whatever
@@ -2674,6 +3113,13 @@ static inline bool wants_g4(const moca_gemm_params& p) {
 }
 static inline bool buffer_addressable(const moca_gemm_params& p);
 static inline bool g4p_ok(const moca_gemm_params& p);
+static inline bool sqp_ok(const moca_gemm_params& p);
+// the persistent 256 x 256 kernel (MOCA_TUNE_GEMM_SQP = 0: never, 1: the GEGLU projections, 2: every linear it can run -- tests, A/B)
+static inline bool takes_sqp(const moca_gemm_params& p) {
+    const int mode = moca_tuning_get(MOCA_TUNE_GEMM_SQP);
+    if (!mode || !sqp_ok(p)) return false;
+    return mode == 2 || (p.flags & MOCA_EP_GEGLU);
+}
 // the persistent two-blocks-per-CU kernel (MOCA_TUNE_GEMM_G4P = 0: never, 1: the GEGLU projections, 2: every linear it can run -- tests, A/B)
 static inline bool takes_g4p(const moca_gemm_params& p) {
     const int mode = moca_tuning_get(MOCA_TUNE_GEMM_G4P);
@@ -2779,6 +3225,32 @@ int launch_gemm_g4p(const moca_gemm_params& p, hipStream_t st) {
     return MOCA_OK;
 }
 
+// persistent 256 x 256 staggered kernel: the linears whose 256 x 256 tiles give every CU at least one (bias, LayerNorm fold, GEGLU or
+// row add / residual -- none of the statistics epilogues)
+constexpr int SQP_BLOCKS = 256;
+static inline bool sqp_ok(const moca_gemm_params& p) {
+    if (p.a_mode != MOCA_A_LINEAR || p.splits != 1 || p.N % 256 || p.K % 64 || !buffer_addressable(p)) return false;
+    if (p.flags & ~(MOCA_EP_GEGLU | MOCA_EP_LNFOLD)) return false;
+    if ((p.flags & MOCA_EP_GEGLU) && (p.residual || p.rowadd)) return false;
+    return ((p.M + 255) / 256) * (p.N / 256) >= SQP_BLOCKS;
+}
+template <bool GEGLU>
+int launch_gemm_sqp(const moca_gemm_params& p, hipStream_t st) {
+    constexpr int lds = 5 * (256 + 256) * 64;                    // the whole 160 KiB: the ring; tile statistics live in its one free slot
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sqp_kernel<GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MOCA_E_LAUNCH;
+        attr_set = true;
+    }
+    moca_gemm_params pl = p;
+    pl.reserved2_ = SQP_BLOCKS;
+    pl.reserved4_ = (pl.reserved4_ & 0xff) | (choose_xcd_n(p, (p.M + 255) / 256, p.N / 256, 256, 256) << 8);
+    hipLaunchKernelGGL((gemm_sqp_kernel<GEGLU>), dim3(SQP_BLOCKS + prefetch_blocks(pl)), dim3(512), lds, st, pl);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
 template <int BN, int AMODE, bool FAST>
 int launch_gemm_glds(const moca_gemm_params& p, hipStream_t st) {
     const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / BN;
@@ -2858,7 +3330,7 @@ static int rowsum_cols(const moca_gemm_params& p) {
 static bool lnfold_ok(const moca_gemm_params& p) {
     if (p.a_mode != MOCA_A_LINEAR || p.splits != 1) return false;
     if (p.flags & (MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_GSTAT | MOCA_EP_LN | MOCA_EP_ROWSUM | MOCA_EP_GELU | MOCA_FORCE_SMALL_TILE)) return false;
-    if (takes_g4p(p)) return true;
+    if (takes_sqp(p) || takes_g4p(p)) return true;
     if (takes_w80(p)) return !(p.flags & MOCA_EP_GEGLU) && takes_w80s(p);
     const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
     if (!(big_bn != 0 && p.M > 128)) return false;
@@ -2995,7 +3467,9 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
         return launch_gemm_w80s<MOCA_A_LINEAR, 3>(p, st);
     }
     if ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1 && lnfold_ok(p))) return MOCA_E_BADARG;   // ask moca_gemm_lnfold_ok() first
-    if (takes_g4p(p)) {
+    if (takes_sqp(p)) {
+        rc = (p.flags & MOCA_EP_GEGLU) ? launch_gemm_sqp<true>(p, st) : launch_gemm_sqp<false>(p, st);
+    } else if (takes_g4p(p)) {
         rc = (p.flags & MOCA_EP_GEGLU) ? launch_gemm_g4p<true>(p, st) : launch_gemm_g4p<false>(p, st);
     } else if (use_w80) {
         rc = launch_gemm_w80_mode(p, st);

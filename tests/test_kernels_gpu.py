@@ -500,13 +500,16 @@ def test_gemm_sq256(M, K, N, geglu, with_res, tune):
 # ---------------------------------------------------------------- GEMM: the persistent two-blocks-per-CU kernel (register epilogue)
 @pytest.mark.parametrize("M,K,N,kind", [(8200, 320, 2048, "geglu"), (16384, 640, 1024, "geglu"), (8192, 640, 2048, "res"),
                                         (9000, 128, 2048, "rowadd+res"), (8192, 64, 2048, "plain"), (70000, 320, 256, "res")])
-@pytest.mark.parametrize("mf32", [0, 1])
-def test_gemm_g4p(M, K, N, kind, mf32, tune):
+@pytest.mark.parametrize("kern", ["g4p", "g4q", "sqp"])
+def test_gemm_g4p(M, K, N, kind, kern, tune):
     """MOCA_TUNE_GEMM_G4P = 2 sends every linear with >= 512 tiles of 256 x 128 to the persistent kernel: W rows fetched in permuted
     order, 16-byte stores straight from the accumulators (GEGLU / bias / row add / residual), M tails, a block's walk over several
     tiles with the DMA stream running across tile boundaries, K = 64 (one k-tile pair per tile)."""
+    # g4p / g4q: 256 x 128 tiles, two blocks per CU, both MFMA shapes (16x16x32 / 32x32x16: different W-row permutations and store maps);
+    # sqp: the persistent 256 x 256 staggered kernel (continuous DMA stream, statistics in the ring's free slot)
+    tune(L.MOCA_TUNE_GEMM_SQP, 2 if kern == "sqp" else 0)
     tune(L.MOCA_TUNE_GEMM_G4P, 2)
-    tune(L.MOCA_TUNE_GEMM_MF32, mf32)                          # both MFMA shapes (16x16x32 / 32x32x16: different W-row permutations and store maps)
+    tune(L.MOCA_TUNE_GEMM_MF32, 1 if kern == "g4q" else 0)
     a = rnd(M, K)
     w = rnd(N, K, scale=K ** -0.5)
     b = rnd(N, dtype=torch.float32, scale=0.1)

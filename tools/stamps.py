@@ -23,7 +23,8 @@ lib = L.load()
 lib.moca_debug_stamps.restype = C.c_int
 lib.moca_debug_stamps.argtypes = [C.c_void_p, C.c_int]
 nb = 16384
-buf = np.zeros((nb, 8), dtype=np.uint64)
+NS = int(os.environ.get('STAMP_SLOTS', '16'))
+buf = np.zeros((nb, NS), dtype=np.uint64)
 assert lib.moca_debug_stamps(buf.ctypes.data_as(C.c_void_p), nb) == 0
 ok = buf[:, 5] > 0
 s = buf[ok].astype(np.int64)
@@ -35,6 +36,16 @@ names = ["start->issued", "issued->tile0 landed", "main loop", "stage1+sync", "s
 for i, n in enumerate(names):
     d = (s[:, i + 1] - s[:, i]) * tick_us
     print(f"{n:24s} mean {d.mean():8.0f} cyc  p50 {np.median(d):8.0f}  p90 {np.percentile(d, 90):8.0f}")
+if NS > 8 and (s[:, 15] > 0).any():
+    segn = ["LOADe reads+wait", "barrier", "MFMAe (+reads)", "barrier", "LOADo issue", "LOADo vmcnt wait", "barrier"]
+    ss = s[s[:, 15] > 0]
+    for i, n in enumerate(segn):
+        d = (ss[:, 9 + i] - ss[:, 8 + i]).astype(np.float64)
+        print(f"   seg {n:20s} mean {d.mean():8.0f} cyc  p50 {np.median(d):8.0f}  p90 {np.percentile(d, 90):8.0f}")
+    if (ss[:, 1] > ss[:, 15]).all():      # (sqp: slots 1 / 2 = end of MFMAo / behind its barrier)
+        for n, a, b in (("MFMAo", 15, 1), ("barrier", 1, 2)):
+            d = (ss[:, b] - ss[:, a]).astype(np.float64)
+            print(f"   seg {n:20s} mean {d.mean():8.0f} cyc  p50 {np.median(d):8.0f}  p90 {np.percentile(d, 90):8.0f}")
 tot = (s[:, 5] - s[:, 0]) * tick_us
 print(f"{'block total':24s} mean {tot.mean():8.0f} cyc")
 # gaps between consecutive blocks on the same CU
@@ -44,5 +55,5 @@ for c in np.unique(cu):
     r = s[cu == c]
     r = r[np.argsort(r[:, 0])]
     gaps += list((r[1:, 0] - r[:-1, 5]) * tick_us)
-gaps = np.array(gaps)
+gaps = np.array(gaps) if len(gaps) else np.zeros(1)
 print(f"CUs seen {len(np.unique(cu))}; gap end(prev)->start(next) on a CU: mean {gaps.mean():.0f} cyc  p50 {np.median(gaps):.0f}  p90 {np.percentile(gaps,90):.0f}")
