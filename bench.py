@@ -78,14 +78,17 @@ def build_model(device, seed=321, materialise=True):
 
 
 def tensor_checksum(tensors, device):
-    """(sum, sum of squares) over the tensors in float64: identical bytes give identical values (same reduction on every rank); a
-    NaN-filled (never received) tensor makes it NaN, which equals nothing"""
+    """(sum, sum of squares) over the tensors in float64, each tensor weighted by its POSITION in the list: identical bytes in the
+    identical order give identical values (same reduction on every rank); a NaN-filled (never received) tensor makes it NaN, which
+    equals nothing; two same-shape operands that a receiver enumerated in a different order (the data then sits in the wrong buffers)
+    change both values -- an unweighted sum would not see that."""
     s = torch.zeros(2, dtype=torch.float64, device=device)
     with torch.no_grad():
-        for p in tensors:
+        for i, p in enumerate(tensors):
             d = p.detach().double()
-            s[0] += d.sum()
-            s[1] += (d * d).sum()
+            w = 1.0 + (i % 1021) / 1021.0
+            s[0] += w * d.sum()
+            s[1] += w * (d * d).sum()
     return s
 
 
@@ -386,6 +389,54 @@ VAE_DD = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, out_ch
 VAE_FLOP_PER_FRAME = 1.5635e12      # conv/linear/bmm MACs x 2 of AutoencoderKL.decode on [1,4,40,64] (FlopCounterMode on the oracle)
 
 
+def emulate_world_leg(dm, sampler, device, T, H, W, world=8, steps=5):
+    """configs[4] on ONE GPU of an N-GPU node: rank 0's prompt rows (64 / N, strided as videocrafter_main.py:181) as B = 16 forwards
+    of the one-graph DDIM step, no collective (there is none in the loop).  The N-GPU job's whole-job rate is N x this per-GPU rate
+    minus the start-up broadcast (`broadcast_bytes`, once per job) -- stated as a projection, never as a measurement."""
+    from moca_video_amd import dist as mdist
+    from moca_video_amd.fifo_graph import BaseEngine
+    rows = mdist.shard_indices(N_PROMPTS, 0, world)
+    engines = []
+    for i in range(0, len(rows), PROMPTS_PER_FORWARD):
+        xs, cs, us = [], [], []
+        for r in rows[i:i + PROMPTS_PER_FORWARD]:
+            g = torch.Generator(device=device).manual_seed(321 + r)
+            xs.append(torch.randn(1, 4, T, H, W, device=device, generator=g))
+            cs.append(torch.randn(1, 77, 1024, device=device, generator=g))
+            us.append(torch.randn(1, 77, 1024, device=device, generator=g))
+        fps = torch.tensor([10] * len(xs), device=device)
+        engines.append(BaseEngine(dm, sampler, torch.cat(xs), {"c_crossattn": [torch.cat(cs)], "fps": fps},
+                                  {"c_crossattn": [torch.cat(us)], "fps": fps}, 12.0, seed=321 + i))
+
+    def step():
+        cur = torch.cuda.current_stream(device)
+        for e in engines:
+            e.step()
+            cur.wait_stream(e.plan.stream)
+    for _ in range(2):                                   # eager pass + capture pass
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    finite = all(bool(torch.isfinite(e.latents()).all()) for e in engines)
+    packed = mdist.packed_operands(dm.model.diffusion_model._packed, [e.plan for e in engines])
+    nbytes = int(sum(t.numel() * t.element_size() for t in packed))
+    per_gpu = 2 * len(rows) * steps / dt
+    del engines
+    torch.cuda.empty_cache()
+    return {"world_emulated": world, "prompt_rows_on_this_gpu": len(rows), "forwards_per_step": -(-len(rows) // PROMPTS_PER_FORWARD),
+            "batch_per_forward": 2 * min(len(rows), PROMPTS_PER_FORWARD), "steps": steps, "ms_per_ddim_step": round(dt / steps * 1e3, 2),
+            "unet_steps_per_s_this_gpu": round(per_gpu, 2), "output_finite": finite,
+            "broadcast_bytes": nbytes, "projected_whole_job_unet_steps_per_s": round(world * per_gpu, 1),
+            "note": "measured on ONE GPU: rank 0's share of BASELINE configs[4] (64 prompts strided over %d GPUs, 16x320x512, DDIM S=50, CFG 12) as "
+                    "one-hipGraph DDIM steps; no collective exists in the loop, so the %d-GPU job runs %d such independent streams: the projection "
+                    "is %d x this rate and excludes the one-time start-up broadcast of `broadcast_bytes` packed operands (C1) and the final "
+                    "gather (C2); NOT a multi-GPU measurement" % (world, world, world, world)}
+
+
 def vae_leg(device, H, W, frames=8, iters=5):
     """Extra: AutoencoderKL.decode of `frames` emitted latent frames [frames,4,40,64] -> [frames,3,320,512]
     (funcs.py:360 decodes one frame per FIFO iteration, 148 per video)."""
@@ -520,7 +571,8 @@ def main():
                     help="graph: one hipGraph per DDIM step (timestep, UNet, noise, guidance + update: what DDIMSampler.sample runs); "
                          "host: p_sample_ddim per step (UNet graph + four small launches issued by the host)")
     ap.add_argument("--no-weight-prefetch", action="store_true",
-                    help="A/B: do not stream the next weight-heavy launch's weights into the Infinity Cache on a side stream")
+                    help="A/B: no moca_gemm_params.prefetch (spare blocks of a GEMM launch's grid that read the next weight-heavy "
+                         "launch's weights into the Infinity Cache)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--height", type=int, default=40)
@@ -529,6 +581,8 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="1-GPU rehearsal of rank 0's share of the N-GPU configs[4] job (its 64/N prompt rows in B=16 forwards, no "
                          "collectives): `value` is then THIS GPU's UNet-steps/s on that workload; extra legs are skipped")
+    ap.add_argument("--no-emulate-world", action="store_true",
+                    help="skip the default leg that measures rank 0's share of the 8-GPU configs[4] job on this GPU (`emulate_world_8`)")
     ap.add_argument("--selftest-cpu", action="store_true", help="launcher/collective plumbing only (CPU, gloo): see launcher_selftest")
     args = ap.parse_args()
 
@@ -734,6 +788,8 @@ def main():
                                      "step; no collectives; value = this GPU alone" % (emu, len(rows), len(batches), 2 * batches[0]["n"]))
         print(json.dumps(res))
         return
+    if world == 1 and not args.no_emulate_world:
+        res["emulate_world_8"] = emulate_world_leg(dm, sampler, device, T, H, W)
     if world == 1 and not args.no_fifo:
         zdd = ZeroDataDenoiser(dm)
         res["fifo"] = fifo_leg(dm, device, T, H, W)
@@ -746,7 +802,7 @@ def main():
     if world == 1 and not args.no_fifo:
         zdd.restore()                           # back to the headline weights
     if world == 1 and not args.no_cpu_baseline:
-        threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share
+        threads = args.cpu_threads or len(os.sched_getaffinity(0))            # the host cores this process may run on
         ts = torch.full((1,), int(sampler.ddim_timesteps[S - 1]), device=device, dtype=torch.long)
         cdt, y_cpu, ctimes = cpu_baseline(dm, x, ctx, ts, threads)
         y_gpu = dm.apply_model(x, ts, cond).float().cpu()

@@ -3507,3 +3507,12 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     }
     return MOCA_OK;
 }
+
+// The library's version string lives beside the kernels a diagnostic build changes (`make stamps` / `gndiag` / `diagx` recompile this file
+// only): such a build -- stamps, timing-only variants with wrong results -- reports "DIAG:<name>", and moca_video_amd/lib.py refuses to
+// load it unless MOCA_HIP_DIAG=1 is set.
+#ifdef MOCA_DIAG_NAME
+extern "C" const char* moca_version(void) { return "moca_hip 0.1 (gfx950) DIAG:" MOCA_DIAG_NAME; }
+#else
+extern "C" const char* moca_version(void) { return "moca_hip 0.1 (gfx950)"; }
+#endif

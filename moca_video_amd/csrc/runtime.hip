@@ -114,4 +114,3 @@ extern "C" int moca_set_tuning(int32_t knob, int32_t value) {
     return old;
 }
 
-extern "C" const char* moca_version(void) { return "moca_hip 0.1 (gfx950)"; }

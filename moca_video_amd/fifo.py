@@ -182,9 +182,12 @@ def fifo_ddim_sampling(args, model, conditioning, noise_shape, ddim_sampler, cfg
             (lambda i: [sam_masks(i, w) for w in range(len(list(fifo_windows(args))))]) if callable(sam_masks) else (lambda i: sam_masks[i])
         if sam_in_graph and sam_capacity is None:
             n_wf = len(list(fifo_windows(args))) * f
+            # (a list: the exact maximum over the iterations, an iteration / window / frame entry may be None; a callable: a guess of 4
+            #  candidate masks per window frame -- pass `sam_capacity` explicitly when the producer can return more: an iteration that
+            #  exceeds the pool raises ValueError from FifoEngine._upload_sam, after earlier frames have been emitted)
             sam_capacity = 4 * n_wf if callable(sam_masks) else max(
                 [1] + [sum(0 if c is None else int(torch.as_tensor(c).reshape(-1, latents.shape[-2], latents.shape[-1]).shape[0])
-                           for cw in it if cw is not None for c in cw) for it in sam_masks[:total]])
+                           for cw in it if cw is not None for c in cw) for it in sam_masks[:total] if it is not None])
         eng = FifoEngine(args, model, ddim_sampler, cond, uc, cfg_scale, latents, conditioned_image=conditioned_image, masks=masks,
                          n_slots=decode_batch if decode else max(total, 1), seed=seed, anchor_moments=moments,
                          scale_factor=getattr(model, "scale_factor", 1.0), sam_capacity=sam_capacity if sam_in_graph else 0)

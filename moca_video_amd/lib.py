@@ -16,7 +16,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MOCA_HIP_LIB: diagnostic builds only (e.g. the -DMOCA_STAMPS library used by tools/stamps.py)
+# MOCA_HIP_LIB: diagnostic builds only (e.g. the -DMOCA_STAMPS library used by tools/stamps.py); load() refuses one without MOCA_HIP_DIAG=1
 LIB_PATH = os.environ.get("MOCA_HIP_LIB") or os.path.join(_HERE, "libmoca_hip.so")
 
 MOCA_A_LINEAR, MOCA_A_CONV3X3, MOCA_A_TCONV3 = 0, 1, 2
@@ -151,7 +151,18 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # A diagnostic build (stamps, timing-only variants that compute WRONG results; csrc/Makefile `stamps` / `gndiag` / `diagx`) exports the
+    # whole API and reports "... DIAG:<name>": never load one by accident through a stray MOCA_HIP_LIB.
+    ver = lib.moca_version().decode()
+    if "DIAG:" in ver and os.environ.get("MOCA_HIP_DIAG") != "1":
+        raise ImportError(f"{LIB_PATH} is a diagnostic build ({ver}); set MOCA_HIP_DIAG=1 to load it on purpose")
     _lib = lib
+    # MOCA_TUNE="knob:value,...": kernel-choice knobs for same-box A/B runs of whole programs (bench.py); never results
+    for kv in os.environ.get("MOCA_TUNE", "").split(","):
+        if kv:
+            k, v = kv.split(":")
+            if lib.moca_set_tuning(int(k), int(v)) < 0:
+                raise MocaHipError(f"MOCA_TUNE: bad knob setting {kv!r}")
     return lib
 
 

@@ -267,9 +267,13 @@ def pack_tree(root, dev):
 # --------------------------------------------------------------------------------------
 # the model
 # --------------------------------------------------------------------------------------
+_SAME_FPS_CACHE = {}          # (id, version) of two fps tensors -> verdict: one device read-back per pair of tensors, not per DDIM step
+
+
 def same_fps(fps_list):
     """True when every entry of a per-segment fps list describes the same frame rates (ints, or tensors with equal values).
-    The tensor comparison reads the device once; callers on a replayed-graph path do it at construction time only."""
+    Comparing two distinct tensors reads the device; the verdict is cached per pair of (tensor object, in-place version), so the
+    host-driven paths (p_sample_ddim, unet_windows, forward_segments: one call per step / window batch) pay the read-back once."""
     first = fps_list[0]
     for f in fps_list[1:]:
         if f is first:
@@ -278,13 +282,29 @@ def same_fps(fps_list):
             if f != first:
                 return False
             continue
+        key = None
+        if torch.is_tensor(first) and torch.is_tensor(f):
+            key = (id(first), first._version, id(f), f._version)
+            hit = _SAME_FPS_CACHE.get(key)
+            if hit is not None and hit[0]() is first and hit[1]() is f:
+                if not hit[2]:
+                    return False
+                continue
         a = torch.as_tensor(first).reshape(-1).to(torch.int64).cpu()
         b = torch.as_tensor(f).reshape(-1).to(torch.int64).cpu()
+        ok = True
         if a.shape != b.shape:
             if a.numel() != 1 and b.numel() != 1:
-                return False
-            a, b = torch.broadcast_tensors(a, b)
-        if not torch.equal(a, b):
+                ok = False
+            else:
+                a, b = torch.broadcast_tensors(a, b)
+        ok = ok and bool(torch.equal(a, b))
+        if key is not None:
+            import weakref
+            if len(_SAME_FPS_CACHE) > 64:
+                _SAME_FPS_CACHE.clear()
+            _SAME_FPS_CACHE[key] = (weakref.ref(first), weakref.ref(f), ok)
+        if not ok:
             return False
     return True
 

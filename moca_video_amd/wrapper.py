@@ -71,9 +71,6 @@ class DiffusionWrapper(nn.Module):
         if self.conditioning_key == 'crossattn':
             cc = torch.cat(c_crossattn, 1)                                   # :711
             out = self.diffusion_model(x, t, context=cc, **kwargs)           # :712
-        elif self.conditioning_key == 'resblockcond':
-            cc = c_crossattn[0]
-            out = self.diffusion_model(x, t, context=cc)
         else:
             raise NotImplementedError(f"conditioning_key={self.conditioning_key!r} is outside the MoCA hot path")
         return out

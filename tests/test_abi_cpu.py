@@ -194,3 +194,19 @@ def test_upsample_phase_algebra_cpu():
         xp = F.pad(x, (1 - bb, bb, 1 - a, a))                              # input rows i + a - 1 .. i + a, columns j + b - 1 .. j + b
         out[:, :, a::2, bb::2] = F.conv2d(xp, k, pw.bias[:64])
     assert (out - ref).abs().max() < 2e-3 * ref.abs().max()                # (the summed weight pairs are rounded to fp16 once)
+
+
+def test_product_library_is_not_a_diagnostic_build():
+    """Diagnostic builds (stamps, timing-only variants with wrong results) export the whole API; they report "DIAG:<name>" in
+    moca_version() and lib.load() refuses them unless MOCA_HIP_DIAG=1.  Every diagnostic target of the Makefile must set the name."""
+    import os
+    import re
+    from moca_video_amd import lib
+    assert "DIAG:" not in lib.version()
+    mk = open(os.path.join(os.path.dirname(lib.LIB_PATH), "csrc", "Makefile")).read()
+    for target in ("stamps", "gndiag", "diagx"):
+        body = mk[mk.index(f"\n{target}:"):].split("\n\n")[0]
+        compile_lines = [l for l in body.splitlines() if "-c gemm.hip" in l]
+        assert compile_lines and all("-DMOCA_DIAG_NAME=" in l for l in compile_lines), target
+    src = open(os.path.join(os.path.dirname(lib.LIB_PATH), "lib.py")).read()
+    assert re.search(r'"DIAG:" in ver and os\.environ\.get\("MOCA_HIP_DIAG"\) != "1"', src)
