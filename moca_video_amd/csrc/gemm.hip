@@ -2871,6 +2871,9 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
         const bool stamp_it = tile_no == 3;          // (phases: [0, 0, main loop, publish + barrier, epilogue arithmetic + stores] + the statistics wait)
         if (stamp_it) { MOCA_STAMP(0); }
 #endif
+        // (plain zeros, default unrolling: the compiler peels the first iteration -- literal C operand -- and reconciles the peeled copy's
+        //  result registers with ~100 v_mov per steady-state iteration; opaque zeros and / or `unroll(disable)` remove the moves and
+        //  measure 1-8 % SLOWER on every GEGLU shape, same box, profiles/r05_ab_sqp_loop_shape.txt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
