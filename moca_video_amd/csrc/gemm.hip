@@ -2851,15 +2851,10 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
     __builtin_amdgcn_s_barrier();
     if (late) __builtin_amdgcn_s_barrier();                      // from here on waves 4..7 run one barrier behind waves 0..3
 
-#ifdef SQP_NO_NT
-    const bool nt_out = false;
-#else
     const bool nt_out = out_streams(p);
-#endif
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
     const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
     int s0 = 0;                                                  // ring slot of the running stream's current k-tile
-    bool lenient_first = false;                                  // the previous tile's epilogue issued its full count of stores
 #ifdef MOCA_STAMPS
     int tile_no = 0;
 #endif
@@ -2928,10 +2923,9 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
 #ifdef MOCA_STAMPS
             if (seg) MOCA_STAMP_W(13, SEG_WAVE);
 #endif
-            // (the first LOADo behind an epilogue: its stores are younger than the pair this wait is for -- leave them outstanding too;
-            //  a tile with rows past M may have issued fewer: plain wait)
-            if (i == 0 && lenient_first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW + (GEGLU ? 8 : 16)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            // (behind an epilogue this also waits for the epilogue's stores, which are older than the pair just issued: leaving them
+            //  outstanding -- vmcnt(8 + stores) in a tile's first LOADo -- measured no different, profiles/r05_ab_sqp_store_wait.txt)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
             __builtin_amdgcn_sched_barrier(0);
 #ifdef MOCA_STAMPS
             if (seg) MOCA_STAMP_W(14, SEG_WAVE);
@@ -3043,9 +3037,6 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
         if (m0 + TM > p.M) lf = stat_finish(raw, q_next, int_c<0>{});
         else lf = stat_finish(raw, q_next, int_c<(GEGLU ? 8 : 16)>{});
         if (q_next >= q_cnt) break;
-#ifndef SQP_STRICT_FIRST
-        lenient_first = m0 + TM <= p.M;
-#endif
         q_cur = q_next;
         if (late) __builtin_amdgcn_s_barrier();                  // waves 4..7 fall one barrier behind again
     }

@@ -2,7 +2,7 @@
 # same-device A/B of a bench.py flag: alternating runs (A = without, B = with the flag), N rounds, one line per run
 #   bash tools/ab_flag.sh "--no-weight-prefetch" 3 [extra bench args] > gpurun_out/ab.txt
 FLAG="$1"; N=${2:-3}; shift 2
-ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-fifo --no-video $@"
+ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-fifo --no-video --no-emulate-world $@"
 for i in $(seq 1 $N); do
   for v in A B; do
     if [ $v = A ]; then F=""; else F="$FLAG"; fi

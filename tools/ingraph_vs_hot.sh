@@ -4,7 +4,7 @@ set -e
 OUT=$1
 export TMPDIR=/tmp
 mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/g -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-fifo --no-video > $OUT/g.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/g -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-fifo --no-video --no-emulate-world > $OUT/g.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $OUT/h -- python3 tools/plan_profile.py 2 > $OUT/h.log 2>&1
 G=$(find $OUT/g -name "*kernel_trace.csv" | head -1)
 H=$(find $OUT/h -name "*kernel_trace.csv" | head -1)

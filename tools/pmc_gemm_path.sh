@@ -5,7 +5,7 @@
 OUT=$1
 export TMPDIR=/tmp
 mkdir -p $OUT
-BENCH="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fifo --no-video"
+BENCH="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fifo --no-video --no-emulate-world"
 i=0
 for SET in "TA_BUSY_avr GRBM_GUI_ACTIVE" \
            "TA_BUFFER_READ_LDS_WAVEFRONTS_sum TA_BUFFER_WAVEFRONTS_sum" \

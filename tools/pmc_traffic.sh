@@ -4,5 +4,5 @@ set -e
 OUT=$1; shift
 export TMPDIR=/tmp
 mkdir -p $OUT
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-fifo > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-fifo > $OUT/write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-fifo --no-emulate-world > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-fifo --no-emulate-world > $OUT/write.log 2>&1
