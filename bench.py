@@ -38,7 +38,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X dense fp16 MFMA (MI355X_MICROARCH.m
 # doubled per the gfx950 correction in MI355X_MICROARCH.md; Infinity-Cache hits are included in these counters).  The
 # figure is READ from the committed summary of the current kernels -- never a constant in this file -- and the JSON
 # names the file; it is null when no summary for this round exists.
-TRAFFIC_PROFILES = ("profiles/r04_pmc_traffic_per_forward.txt", "profiles/r03_pmc_traffic_per_forward.txt")
+TRAFFIC_PROFILES = ("profiles/r05_pmc_traffic_per_forward.txt", "profiles/r04_pmc_traffic_per_forward.txt")
 
 
 def traffic_from_profile():
@@ -770,8 +770,8 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic_bytes if not concurrent else None, "traffic_source": traffic_src if not concurrent else None,
                      "kernel": ("the whole DDIM-step hipGraph (%d launches: timestep rows + device noise + the UNet forward + guidance / "
-                                "DDIM update; the implicit-GEMM conv/linear kernels gemm_w80s/gemm_glds/gemm_g4 are 80%% of its kernel "
-                                "time, profiles/r04_bench_kernel_stats_summary.txt)" if engines is not None else
+                                "DDIM update; the implicit-GEMM conv/linear kernels gemm_w80s/gemm_glds/gemm_sqp are 84%% of its kernel "
+                                "time, profiles/r05_bench_kernel_stats_summary.txt)" if engines is not None else
                                 "UNet forward launch sequence (hipGraph of %d launches)") % n_launches +
                                (", two B=1 graphs on two streams" if concurrent else ", batch %d" % (2 * batches[0]["n"])),
                      "flop_per_launch": flop_per_launch, "avg_launch_ms": round(avg_launch_ms, 3), "launches": len(unet_ms),

@@ -97,25 +97,24 @@ __device__ __forceinline__ f32x2 moca_geglu2(f32x2 v, f32x2 g) {
 // (|sum| < 8.6e9), sum of squares: 2^-16 units (< 1.4e14, i.e. an rms of 1.8e4 over a 4e5-element group: beyond what fp16
 // activations can hold); the rounding of a partial to those units changes a group's mean of squares by < 2^-17 * partials / elements
 // < 1e-8, far below the eps (1e-6 / 1e-5) added to the variance.
-// A partial that is NON-FINITE (NaN / Inf activations) or too large for the accumulator (|v| > 2^50 units: 1e6 as a sum, 1.7e10 as a
-// sum of squares, i.e. an rms of 1.2e3 over a 320 x 40 tile -- no finite fp16 tensor of this network comes near) must not turn into
-// finite statistics: it sets bit 62 of the group's sum-of-squares accumulator (acc layout [group][2] = {sum, sum of squares}) and adds
-// nothing.  That accumulator is non-negative and every accepted add is <= 2^50; OR is idempotent, so the bit survives however many
-// partials are poisoned.  moca_gstat_get returns NaN when the accumulator is >= 2^61 -- the poison bit, or finite adds that came
-// within a factor 2 of it (2^11 partials at the limit; a group of the UNet receives <= 2^10: rows of a statistics group / 160-row
-// tiles x 2 column tiles) -- so accepted adds can neither alias the bit unnoticed nor wrap (that would take 2^14 partials at the
-// limit): the group's variance, rstd and every normalised value then come out NaN exactly as with a plain f32 / f64 reduction of
-// NaN / overflowing inputs.
+// A NON-FINITE partial (NaN / Inf activations) must not turn into finite statistics: it sets bit 62 of the group's sum-of-squares
+// accumulator (acc layout [group][2] = {sum, sum of squares}) and adds nothing; OR is idempotent, so the bit survives however many
+// partials are poisoned.  A finite partial is clamped to +-2^53 units (8.4e6 as a sum, 1.4e11 as a sum of squares: an rms of 3.3e3 over
+// a 320 x 40 tile) before it is added.  moca_gstat_get returns NaN when the sum-of-squares accumulator is >= 2^61 -- the poison bit, or
+// finite adds that came within a factor 2 of it (256 partials at the clamp; a group of the UNet receives <= 2^10: rows of a statistics
+// group / 160-row tiles x 2 column tiles, so accepted adds stay below 2^63 and cannot wrap): overflowing statistics read back as NaN
+// like poisoned ones, never as a wrong finite number, and finite adds can not alias the poison bit unnoticed.
 #define MOCA_GSTAT_SUM_SCALE 1073741824.0
 #define MOCA_GSTAT_SQ_SCALE 65536.0
 #define MOCA_GSTAT_POISON (1ull << 62)
-#define MOCA_GSTAT_MAX_UNITS 1125899906842624.0      /* 2^50 */
+#define MOCA_GSTAT_MAX_UNITS 9007199254740992.0      /* 2^53 */
 __device__ __forceinline__ void moca_gstat_add(int64_t* acc, int comp, float partial) {
-    const double v = (double)partial * (comp ? MOCA_GSTAT_SQ_SCALE : MOCA_GSTAT_SUM_SCALE);
-    if (!(fabs(v) <= MOCA_GSTAT_MAX_UNITS)) {      // NaN, Inf or out of range
+    if (!(fabsf(partial) <= 3.0e38f)) {            // NaN or Inf
         atomicOr(reinterpret_cast<unsigned long long*>(acc + (1 - comp)), MOCA_GSTAT_POISON);
         return;
     }
+    double v = (double)partial * (comp ? MOCA_GSTAT_SQ_SCALE : MOCA_GSTAT_SUM_SCALE);
+    v = fmin(fmax(v, -MOCA_GSTAT_MAX_UNITS), MOCA_GSTAT_MAX_UNITS);
     atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)__double2ll_rn(v));
 }
 __device__ __forceinline__ double moca_gstat_get(const int64_t* acc, int comp) {

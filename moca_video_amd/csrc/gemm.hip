@@ -2670,6 +2670,7 @@ __device__ __forceinline__ void lds_wr_f2(unsigned a, f32x2 v) { asm volatile("d
 __device__ __forceinline__ void lds_wr_f1(unsigned a, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
 __device__ __forceinline__ f32x2 lds_rd_f2(unsigned a) { f32x2 v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(a) : "memory"); return v; }
 __device__ __forceinline__ f32x4 lds_rd_f4(unsigned a) { f32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory"); return v; }
+__device__ __forceinline__ float lds_rd_f1(unsigned a) { float v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(a) : "memory"); return v; }
 __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 
 __device__ __forceinline__ int sqp_perm(int rho) {              // LDS row of the 256-row W tile -> packed W row of the tile (64-column groups as g4p_perm)
@@ -2781,54 +2782,56 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
     };
     // ---- tile statistics: thread t < 256 (the early half) owns row t and LDS column t of the tile.  The values of tile q + 1 are
     //      fetched at the head of tile q's epilogue and finished behind its stores; they travel through the main loop as four registers
-    //      (rstd, -mean rstd, wsum, bias).  The loads are INLINE ASM with a counted wait of their own: a VGPR load the compiler knows about
-    //      makes it guard every later write of those registers (fragment reads in the main loop, the next fetch) with `s_waitcnt
-    //      vmcnt(0)`, which drains the DMA stream once per iteration.  Every lane loads (dummy addresses where it has nothing to fetch):
-    //      no branch, a fixed count. ----
+    //      (rstd, -mean rstd, wsum, bias).  The fetch is LDS-DMA (4 bytes per lane, into 22 KiB of the free slot behind the published
+    //      statistics, one private area per wavefront), read back with inline-asm ds_reads behind a counted wait -- no VGPR is the
+    //      destination of a load: a VGPR load the compiler knows about makes it guard every later write of those registers (the fragment
+    //      reads of the main loop) with `s_waitcnt vmcnt(0)`, draining the DMA stream once per iteration; an inline-asm VGPR load is
+    //      copied by the register allocator BEFORE the asm wait that retires it (`v_mov` of the load destinations in front of the
+    //      `s_waitcnt` statement that names them "+v": seen in the ISA of the first form of this path -- stale statistics whenever a load
+    //      is slower than the epilogue's arithmetic). ----
     const bool fold = (p.flags & MOCA_EP_LNFOLD) != 0;
-    struct StatRaw { f32x2 p0, p1; float ws, b; };
     const float* const dummy = reinterpret_cast<const float*>(p.w);
-    auto stat_issue = [&](int q) -> StatRaw {
+    constexpr unsigned STAT_SCRATCH = 8192;                      // offset of the raw-value areas inside the free slot
+    const int stat_floats = 2 + 2 * (fold ? p.lnf_nparts : 0);   // per lane: wsum, bias, (sum, sum of squares) per row partial
+    auto stat_dma = [&](int q, unsigned slot_off) {              // waves 0..3 only
         int tm, tn;
         tile_of(q < q_cnt ? q : 0, tm, tn);
-        const int t256 = tid_now() & 255;
-        const int n = tn * BN + sqp_perm(t256);
-        const int m = min(tm * TM + t256, p.M - 1);
-        const float* a0 = fold ? p.lnf_part + (int64_t)m * 2 : dummy;
-        const float* a1 = (fold && p.lnf_nparts > 1) ? p.lnf_part + ((int64_t)p.M + m) * 2 : dummy;
-        const float* a2 = fold ? p.lnf_wsum + n : dummy;
-        const float* a3 = p.bias ? p.bias + n : dummy;
-        StatRaw r;
-        asm volatile("global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off"
-                     : "=&v"(r.p0), "=&v"(r.p1), "=&v"(r.ws), "=&v"(r.b) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
-        return r;
-    };
-    // (`after` = vector-memory instructions this wave has issued behind the loads, at least: the wait leaves that many outstanding)
-    // Row partials beyond the second (the 1280-channel level: 4 or 10 per row) are fetched here, eight at a time, behind a full drain:
-    // once per tile, where a tile is 40 k-tiles long.
-    auto stat_finish = [&](StatRaw& r, int q, auto after_tag) -> LnFoldRegs {
-        constexpr int after = decltype(after_tag)::value;
-        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.p0), "+v"(r.p1), "+v"(r.ws), "+v"(r.b) : "n"(after) : "memory");
-        LnFoldRegs f = {1.f, 0.f, fold ? r.ws : 0.f, p.bias ? r.b : 0.f};
+        const int t = tid_now();
+        const int n = tn * BN + sqp_perm(t);
+        const int m = min(tm * TM + t, p.M - 1);
+        const lds_ptr area = (lds_ptr)smem + slot_off + STAT_SCRATCH + wave * (22 * 256);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(fold ? p.lnf_wsum + n : dummy), area, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(p.bias ? p.bias + n : dummy), area + 256, 4, 0, 0);
         if (fold) {
-            float s = r.p0[0] + (p.lnf_nparts > 1 ? r.p1[0] : 0.f), qq = r.p0[1] + (p.lnf_nparts > 1 ? r.p1[1] : 0.f);
-            for (int i0 = 2; i0 < p.lnf_nparts; i0 += 8) {       // (block-uniform)
-                int tm, tn;
-                tile_of(q < q_cnt ? q : 0, tm, tn);
-                const int m = min(tm * TM + (tid_now() & 255), p.M - 1);
-                f32x2 e[8];
-                const float* ea[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ea[j] = i0 + j < p.lnf_nparts ? p.lnf_part + ((int64_t)(i0 + j) * p.M + m) * 2 : dummy;
-                asm volatile("global_load_dwordx2 %0, %8, off\n\tglobal_load_dwordx2 %1, %9, off\n\tglobal_load_dwordx2 %2, %10, off\n\t"
-                             "global_load_dwordx2 %3, %11, off\n\tglobal_load_dwordx2 %4, %12, off\n\tglobal_load_dwordx2 %5, %13, off\n\t"
-                             "global_load_dwordx2 %6, %14, off\n\tglobal_load_dwordx2 %7, %15, off\n\ts_waitcnt vmcnt(0)"
-                             : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(e[4]), "=&v"(e[5]), "=&v"(e[6]), "=&v"(e[7])
-                             : "v"(ea[0]), "v"(ea[1]), "v"(ea[2]), "v"(ea[3]), "v"(ea[4]), "v"(ea[5]), "v"(ea[6]), "v"(ea[7]) : "memory");
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (i0 + j < p.lnf_nparts) { s += e[j][0]; qq += e[j][1]; }
+            for (int i = 0; i < p.lnf_nparts; ++i) {             // (block-uniform; <= 10)
+                const float* src = p.lnf_part + ((int64_t)i * p.M + m) * 2;
+                __builtin_amdgcn_global_load_lds((glb_ptr)src, area + (2 + 2 * i) * 256, 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr)(src + 1), area + (3 + 2 * i) * 256, 4, 0, 0);
             }
+        }
+    };
+    // (`after` = vector-memory instructions this wave has issued behind the DMAs, at least: the wait leaves that many outstanding)
+    auto stat_read = [&](unsigned slot_off, auto after_tag) -> LnFoldRegs {
+        constexpr int after = decltype(after_tag)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(after) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        int lane_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
+        const unsigned area = (unsigned)(size_t)((lds_ptr)smem + slot_off + STAT_SCRATCH + wave * (22 * 256)) + 4 * lane_;
+        const float ws = lds_rd_f1(area), b = lds_rd_f1(area + 256);
+        float s = 0.f, qq = 0.f;
+        LnFoldRegs f = {1.f, 0.f, 0.f, 0.f};
+        if (fold) {
+            for (int i = 0; i < p.lnf_nparts; ++i) {
+                const float x = lds_rd_f1(area + (2 + 2 * i) * 256), y = lds_rd_f1(area + (3 + 2 * i) * 256);
+                lds_wait();
+                s += x; qq += y;
+            }
+        }
+        lds_wait();
+        f.ws = fold ? ws : 0.f;
+        f.b = p.bias ? b : 0.f;
+        if (fold) {
             const float inv_k = 1.0f / (float)p.K;
             const float mean = s * inv_k;
             const float var = fmaxf(qq * inv_k - mean * mean, 0.f);
@@ -2837,13 +2840,15 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
         }
         return f;
     };
+    (void)stat_floats;
 
     // ---- prologue (once per block): two pairs in flight, the first landed everywhere ----
-    LnFoldRegs lf;
-    {
-        StatRaw raw0 = stat_issue(q_cur);
-        lf = stat_finish(raw0, q_cur, int_c<0>{});
+    LnFoldRegs lf = {1.f, 0.f, 0.f, 0.f};
+    if (!late) {                                                 // (slot 4 is not part of the prologue's four k-tiles)
+        stat_dma(q_cur, (NS - 1) * STAGE);
+        lf = stat_read((NS - 1) * STAGE, int_c<0>{});
     }
+    __builtin_amdgcn_s_barrier();                                // (every read of slot 4 done before the stream reaches it)
     set_dma_tile(q_cur);
     issue_pair(0, 1);
     issue_pair(2, 3);
@@ -2976,7 +2981,8 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) st[mt] = lds_rd_f2(lst + 8 * (wave_m * WTM + mt * 16 + fr));
         const int q_next = q_cur + J;
-        StatRaw raw = stat_issue(q_next);                         // (in flight under the epilogue's arithmetic; finished behind its stores)
+        const unsigned stat_slot = (unsigned)((s0 == 0 ? NS - 1 : s0 - 1) * STAGE);
+        if (!late) stat_dma(q_next, stat_slot);                   // (in flight under the epilogue's arithmetic; read back behind its stores)
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {
             f32x4 cw[4], cb[4];                                   // (per 64-column group: 32 registers instead of 64)
@@ -3034,8 +3040,10 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
         if (stamp_it) { MOCA_STAMP(5); MOCA_STAMP_HW(); }
         ++tile_no;
 #endif
-        if (m0 + TM > p.M) lf = stat_finish(raw, q_next, int_c<0>{});
-        else lf = stat_finish(raw, q_next, int_c<(GEGLU ? 8 : 16)>{});
+        if (!late) {
+            if (m0 + TM > p.M) lf = stat_read(stat_slot, int_c<0>{});
+            else lf = stat_read(stat_slot, int_c<(GEGLU ? 8 : 16)>{});
+        }
         if (q_next >= q_cnt) break;
         q_cur = q_next;
         if (late) __builtin_amdgcn_s_barrier();                  // waves 4..7 fall one barrier behind again

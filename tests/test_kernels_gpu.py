@@ -534,6 +534,38 @@ def test_gemm_g4p(M, K, N, kind, kern, tune):
     check(out, ref, TOL16, f"g4p {M}x{N}x{K} {kind}")
 
 
+def test_gemm_sqp_lnfold_repeatable(tune):
+    """The persistent kernel fetches the NEXT tile's LayerNorm-fold statistics under the current tile's epilogue and reads them back
+    behind a counted wait.  A read that is not ordered behind its load (the first form of this path: inline-asm VGPR loads, which the
+    register allocator copies ahead of the asm wait that retires them) returns stale values whenever a load is slower than the epilogue.
+    400 launches of the 320-channel GEGLU shape with cache-evicting fills in between, every one bit-identical to the first and to torch."""
+    tune(L.MOCA_TUNE_GEMM_SQP, 1)
+    M, C, n = 81920, 320, 1280
+    x = rnd(M, C) * 3 + 1.5
+    xf = x.float()
+    part = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1).contiguous()                 # one row partial (sum, sum of squares)
+    g = rnd(C, dtype=torch.float32) * 0.3 + 1.0
+    be = rnd(C, dtype=torch.float32) * 0.3
+    wc, bc = rnd(2 * n, C, scale=C ** -0.5), rnd(2 * n, dtype=torch.float32, scale=0.1)
+    wf, bf = ops.fold_layernorm(wc, bc, g, be)
+    pwf = ops.finish_lnfold(ops.pack_geglu(wf, bf))
+    y = F.layer_norm(xf, (C,), g, be, 1e-5) @ wc.float().t() + bc
+    ref = y[:, :n] * F.gelu(y[:, n:])
+    first = torch.empty(M, n, dtype=torch.float16, device=DEV)
+    ops.gemm(x, pwf, first, M=M, lnfold=(part, 1, 1e-5))
+    check(first, ref, TOL16, "sqp lnfold geglu")
+    out = torch.empty_like(first)
+    junk = torch.empty(64 << 20, dtype=torch.float16, device=DEV)
+    bad = 0
+    for i in range(400):
+        if i % 8 == 0:
+            junk.fill_(float(i))                                 # (evicts the statistics from the caches now and then)
+        out.fill_(float("nan"))
+        ops.gemm(x, pwf, out, M=M, lnfold=(part, 1, 1e-5))
+        bad += int(not torch.equal(out, first))
+    assert bad == 0, f"{bad} of 400 launches differ from the first"
+
+
 # ---------------------------------------------------------------- LayerNorm folded into the consuming linear
 @pytest.mark.parametrize("M,C,Kp,with_res,consumers", [
     (40000, 320, 320, True, [("lin", 960), ("geglu", 1280)]),            # 160 x 320 producer (1 partial); staggered / g4 consumers

@@ -13,6 +13,8 @@ for r in rows:
     elif 'gemm_w80s' in n and re.search(r'<\d, 2>|ELi2EEE', n): k = 'gemm_w80s 256x256 (wide GEGLU)'
     elif 'gemm_w80s' in n and re.search(r'<\d, 1>|ELi1EEE', n): k = 'gemm_w80s 160x320'
     elif 'gemm_w80s' in n: k = 'gemm_w80s 320x160'
+    elif 'gemm_sqp' in n: k = 'gemm_sqp (persistent 256x256, register epilogue: GEGLU)'
+    elif 'gemm_g4p' in n or 'gemm_g4q' in n: k = 'gemm_g4p (persistent 256x128)'
     elif 'gemm_w80' in n: k = 'gemm_w80/w80b (320x160)'
     elif 'gemm_g4' in n: k = 'gemm_g4 (GEGLU K<=640)'
     elif 'gemm_glds' in n: k = 'gemm_glds (256xBN)'
@@ -35,4 +37,4 @@ for r in rows:
 tot = sum(v for k, v in grp.items() if not k.startswith('torch'))
 print(f"moca kernel time per forward: {tot/nfwd/1e6:.2f} ms")
 for k, v in sorted(grp.items(), key=lambda x: -x[1]):
-    print(f"{k:24s} {v/nfwd/1e6:7.2f} ms/fwd {100*v/tot:5.1f}%  launches/fwd {cnt[k]/nfwd:.0f}")
+    print(f"{k:56s} {v/nfwd/1e6:7.2f} ms/fwd {100*v/tot:5.1f}%  launches/fwd {cnt[k]/nfwd:.0f}  avg {v/max(cnt[k],1)/1e3:8.1f} us")
