@@ -788,29 +788,40 @@ def main():
                                      "step; no collectives; value = this GPU alone" % (emu, len(rows), len(batches), 2 * batches[0]["n"]))
         print(json.dumps(res))
         return
+    note = lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)     # (progress on stderr: a silent multi-minute run looks hung)
+    note("headline measured: %.2f UNet-steps/s" % value)
     if world == 1 and not args.no_emulate_world:
         res["emulate_world_8"] = emulate_world_leg(dm, sampler, device, T, H, W)
+        note("emulate_world_8 done")
     if world == 1 and not args.no_fifo:
         zdd = ZeroDataDenoiser(dm)
         res["fifo"] = fifo_leg(dm, device, T, H, W)
+        note("fifo leg done")
         res["fifo_prompt_mode"] = fifo_leg(dm, device, T, H, W, mode="prompt")
         res["vae_decode"], ae = vae_leg(device, H, W)
+        note("fifo prompt-mode + vae legs done")
         res["fifo"]["projected_s_per_video_incl_vae_decode"] = round(
             res["fifo"]["projected_s_per_video_148_iterations"] + res["vae_decode"]["s_per_video_148_frames"], 1)
     if world == 1 and not args.no_fifo and not args.no_video:
         res["video"] = video_leg(dm, ae, device, T, H, W)
+        note("video leg done")
     if world == 1 and not args.no_fifo:
         zdd.restore()                           # back to the headline weights
     if world == 1 and not args.no_cpu_baseline:
-        threads = args.cpu_threads or len(os.sched_getaffinity(0))            # the host cores this process may run on
+        # the host cores of ONE GPU's share of the box: min(affinity set, CPUs online / 8 GPUs per node) -- 32 of the 256 on the 8-GPU
+        # hosts of this pool.  (All 256 threads on the fp32 oracle oversubscribe the convolutions: the leg then runs for > 7 minutes.)
+        threads = args.cpu_threads or max(1, min(len(os.sched_getaffinity(0)), (os.cpu_count() or 8) // 8))
         ts = torch.full((1,), int(sampler.ddim_timesteps[S - 1]), device=device, dtype=torch.long)
+        note("cpu_baseline: 4 runs of the fp32 oracle on %d threads (~20 s each)" % threads)
         cdt, y_cpu, ctimes = cpu_baseline(dm, x, ctx, ts, threads)
         y_gpu = dm.apply_model(x, ts, cond).float().cpu()
         err = ((y_gpu - y_cpu).abs().max() / y_cpu.abs().max()).item()
         res["cpu_baseline"] = {"value": round(1.0 / cdt, 5), "unit": "UNet-steps/s", "cores": threads, "kind": "port",
                                "cpu_model": cpu_model_name(), "cpus_online": os.cpu_count(),
                                "sample": "1 UNet-step (fp32 oracle of the reference UNet, [1,4,%d,%d,%d], same weights/inputs) per run; "
-                                         "1 warm-up + %d timed runs (%s s), median; HIP-vs-oracle max rel err %.2e" % (T, H, W, len(ctimes), "/".join("%.1f" % c for c in ctimes), err)}
+                                         "1 warm-up + %d timed runs (%s s), median; HIP-vs-oracle max rel err %.2e; threads = one GPU's share of "
+                                         "the host (min(affinity set %d, %d CPUs online / 8 GPUs))" % (T, H, W, len(ctimes), "/".join("%.1f" % c for c in ctimes), err,
+                                                                                                         len(os.sched_getaffinity(0)), os.cpu_count() or 0)}
     print(json.dumps(res))
 
 

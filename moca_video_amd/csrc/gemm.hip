@@ -2720,8 +2720,23 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
         const int a = l / sub_n;
         tm = tm_base + a; tn = tn_base + (l - a * sub_n);
     };
-    int q_cur = blockIdx.x >> 3;
-    if (q_cur >= q_cnt) return;                                  // (block-uniform)
+    // walk of the XCD's set (p.reserved4_ bit 1): STRIDED -- block j takes tiles j, j + J, ...: at any time the XCD's J blocks hold J
+    // consecutive tiles of the raster (3.2 rows of 10 column tiles), every A row tile is shared by ~10 blocks that all request it at the
+    // same moment, i.e. all of them wait out the same HBM miss; or CONTIGUOUS -- block j takes tiles [j cnt / J, (j + 1) cnt / J): it walks
+    // a row's column tiles one after the other, so its A row tile misses to HBM once and is then re-read from L2 / the Infinity Cache,
+    // while the J blocks of the XCD, in step, share ONE W panel at a time.
+    int q_cur, q_step, q_end;
+    {
+        const int j = blockIdx.x >> 3;
+        if (p.reserved4_ & 2) {
+            q_cur = (int)((int64_t)q_cnt * j / J);
+            q_end = (int)((int64_t)q_cnt * (j + 1) / J);
+            q_step = 1;
+        } else {
+            q_cur = j; q_end = q_cnt; q_step = J;
+        }
+    }
+    if (q_cur >= q_end) return;                                  // (block-uniform)
     const int nk = p.K / 32;                                     // K % 64 == 0 (host-checked): an even number of k-tiles
 
     // ---- DMA stream: piece = 16 rows x 64 B; A pieces w and 8 + w, W pieces w and 8 + w of every k-tile (4 per wave) ----
@@ -2731,10 +2746,10 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, OOB_OFF, 0x00020000);
     unsigned a_off[2], w_off[2];
     int d_q = q_cur, d_k = 0;                                    // tile / even k-tile of the next pair the stream issues
-    auto set_dma_tile = [&](int q) {                             // q >= q_cnt: no tile (every lane out of range: zero fill, no traffic)
+    auto set_dma_tile = [&](int q) {                             // q >= q_end: no tile (every lane out of range: zero fill, no traffic)
         int tm, tn;
         tile_of(q, tm, tn);
-        const bool any = q < q_cnt;
+        const bool any = q < q_end;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int row = tm * TM + (g * 8 + wave) * 16 + lrow;
@@ -2756,7 +2771,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, so + A_BYTES + (g * 8 + wave) * 1024, 16, w_off[g], soff + KS * 2, 0, 0);
         }
         d_k += 2;
-        if (d_k >= nk) { d_k = 0; d_q += J; set_dma_tile(d_q); }
+        if (d_k >= nk) { d_k = 0; d_q += q_step; set_dma_tile(d_q); }
     };
 
     const int fr = lane & 15, fg = lane >> 4;
@@ -2795,7 +2810,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
     const int stat_floats = 2 + 2 * (fold ? p.lnf_nparts : 0);   // per lane: wsum, bias, (sum, sum of squares) per row partial
     auto stat_dma = [&](int q, unsigned slot_off) {              // waves 0..3 only
         int tm, tn;
-        tile_of(q < q_cnt ? q : 0, tm, tn);
+        tile_of(q < q_end ? q : 0, tm, tn);
         const int t = tid_now();
         const int n = tn * BN + sqp_perm(t);
         const int m = min(tm * TM + t, p.M - 1);
@@ -2980,7 +2995,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
         f32x2 st[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) st[mt] = lds_rd_f2(lst + 8 * (wave_m * WTM + mt * 16 + fr));
-        const int q_next = q_cur + J;
+        const int q_next = q_cur + q_step;
         const unsigned stat_slot = (unsigned)((s0 == 0 ? NS - 1 : s0 - 1) * STAGE);
         if (!late) stat_dma(q_next, stat_slot);                   // (in flight under the epilogue's arithmetic; read back behind its stores)
 #pragma unroll
@@ -3044,7 +3059,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
             if (m0 + TM > p.M) lf = stat_read(stat_slot, int_c<0>{});
             else lf = stat_read(stat_slot, int_c<(GEGLU ? 8 : 16)>{});
         }
-        if (q_next >= q_cnt) break;
+        if (q_next >= q_end) break;
         q_cur = q_next;
         if (late) __builtin_amdgcn_s_barrier();                  // waves 4..7 fall one barrier behind again
     }
@@ -3247,7 +3262,8 @@ int launch_gemm_sqp(const moca_gemm_params& p, hipStream_t st) {
     }
     moca_gemm_params pl = p;
     pl.reserved2_ = SQP_BLOCKS;
-    pl.reserved4_ = (pl.reserved4_ & 0xff) | (choose_xcd_n(p, (p.M + 255) / 256, p.N / 256, 256, 256) << 8);
+    pl.reserved4_ = (pl.reserved4_ & 0xfd) | (choose_xcd_n(p, (p.M + 255) / 256, p.N / 256, 256, 256) << 8) |
+                    (moca_tuning_get(MOCA_TUNE_SQP_WALK) ? 2 : 0);
     hipLaunchKernelGGL((gemm_sqp_kernel<GEGLU>), dim3(SQP_BLOCKS + prefetch_blocks(pl)), dim3(512), lds, st, pl);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
