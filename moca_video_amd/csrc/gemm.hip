@@ -16,7 +16,6 @@
 // fp32 LDS tile so that bias / time-embedding / residual are applied in fp32 and the
 // result leaves as full 16-byte coalesced stores.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -1386,25 +1385,6 @@ namespace {
 // LDS rows are 64 B; chunk swizzle phys = chunk ^ f((row>>2)&3), f = {0,2,3,1} (conflict-free for the four
 // 16-lane groups of ds_read_b128 on the 16x16x32 operand map; derivation in DESIGN.md).
 // =====================================================================================
-// per-CU arrival parity (index = XCC id * 256 + HW_ID[15:8] = se / sh / cu): the second block a CU receives draws 1
-__device__ unsigned g_cu_parity[8 * 256];
-__device__ __forceinline__ void skew_second_block(int cycles) {
-    // EXPERIMENT (MOCA_EXP bit 0): two co-resident blocks that start together stay in lockstep -- both in their main loops, then both
-    // in their epilogues.  The block that arrives second on a CU waits `cycles` once; every later block inherits the offset.
-    __shared__ unsigned par;
-    if (threadIdx.x == 0) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        par = atomicXor(&g_cu_parity[(xcc & 7) * 256 + ((hw >> 8) & 255)], 1u) & 1u;
-    }
-    __syncthreads();
-    if (par && (int)blockIdx.x < 512) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < cycles) __builtin_amdgcn_s_sleep(32);
-    }
-}
-
 template <int AMODE, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params p) {
     constexpr int TM = 256, BN = 128, KS = 32;
@@ -1426,7 +1406,6 @@ __global__ __launch_bounds__(256, 2) void gemm_g4_kernel(const moca_gemm_params 
     const int tiles_n = p.N / BN;
     const int nblk = tiles_m * tiles_n * p.splits;
     if (prefetch_block(p, nblk, 256)) return;
-    if (p.reserved2_ > 0) skew_second_block(p.reserved2_);
     int split = 0, tile_m, tile_n;
     if ((p.reserved4_ >> 8) > 1) {                       // 2-D XCD partition (see remap_tile_2d)
         remap_tile_2d(tiles_m, tiles_n, p.reserved4_ >> 8, tile_m, tile_n);
@@ -3200,8 +3179,6 @@ int launch_gemm_g4(const moca_gemm_params& p, hipStream_t st) {
     }
     moca_gemm_params pl = p;
     pl.reserved4_ = (pl.reserved4_ & 0xff) | (choose_xcd_n(p, tiles_m, tiles_n, 256, 128) << 8);
-    static const int skew = getenv("MOCA_G4_SKEW") ? atoi(getenv("MOCA_G4_SKEW")) : 0;
-    pl.reserved2_ = skew;
     hipLaunchKernelGGL((gemm_g4_kernel<AMODE, FAST>), dim3(nblk + 2 * prefetch_blocks(pl)), dim3(256), lds, st, pl);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
