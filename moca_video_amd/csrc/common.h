@@ -90,6 +90,27 @@ __device__ __forceinline__ f32x2 moca_geglu2(f32x2 v, f32x2 g) {
     return v * (g * 0.5f + ag * w);
 }
 #endif
+// four (value, gate) pairs at once: the same arithmetic on 4-vectors, so that two independent packed chains sit next to each other in
+// program order and fill each other's dependent-issue slots (the 2-wide form leaves an s_nop behind every step of the Horner chain)
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4g moca_geglu4(f32x4g v, f32x4g g) {
+    const f32x4g ag = {fabsf(g[0]), fabsf(g[1]), fabsf(g[2]), fabsf(g[3])};
+    const f32x4g d = ag * (0.3275911f * 0.70710678118654752f) + 1.0f;
+    const f32x4g t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+    // yn = -(a1 t + ... + a5 t^5) / 2 (negated coefficients: 1 / 2 + yn e needs no sign flip, which the 4-wide form would do with v_xor)
+    float c1n = -0.5f * 1.061405429f;
+    asm("" : "+s"(c1n));                                         // (opaque: a visible negative factor is rewritten as (-t) * |c|, i.e. 4 v_xor)
+    f32x4g yn = t * c1n + (0.5f * 1.453152027f);
+    yn = yn * t - (0.5f * 1.421413741f);
+    yn = yn * t + (0.5f * 0.284496736f);
+    yn = yn * t - (0.5f * 0.254829592f);
+    yn = yn * t;
+    const f32x4g u = g * 0.84932180028801904f;
+    const f32x4g s = u * u;                                      // (the sign rides on v_exp_f32's source modifier)
+    const f32x4g e = {__builtin_amdgcn_exp2f(-s[0]), __builtin_amdgcn_exp2f(-s[1]), __builtin_amdgcn_exp2f(-s[2]), __builtin_amdgcn_exp2f(-s[3])};
+    const f32x4g w = yn * e + 0.5f;
+    return v * (g * 0.5f + ag * w);
+}
 
 // GroupNorm statistics accumulated across blocks (MOCA_EP_GSTAT, concat with statistics): 64-bit FIXED-POINT atomics -- integer
 // addition is associative, so the finished statistics do not depend on the order in which the producer's blocks arrive and a
