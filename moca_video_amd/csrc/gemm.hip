@@ -715,6 +715,18 @@ __device__ __forceinline__ void st_out8(half_t* ptr, const half8v v, bool nt) {
 #endif
 }
 
+// Residual rows of a launch whose output streams (>= 128 MiB: out_streams) are read with non-temporal loads: they are read once and,
+// at that size, come from HBM -- same box, alternating (profiles/r05_ab_nt_loads.txt): the B = 16 `163840 x 640 x 640 +res` linears
+// 218 -> 199 us, `655360 x 320 x 320 +res` -1 %; on the B = 2 tensors (served by the Infinity Cache) the hint costs 8 %, hence the size
+// rule.  (Non-temporal LDS-DMA of an A operand that is read once measured 13 % slower.)
+// (a compile-time choice: a hinted load in one arm of a runtime branch is merged with the plain one and loses the hint, as with stores;
+//  the store loops are instantiated for both policies and chosen once per block)
+template <bool NT>
+__device__ __forceinline__ half8v ld_res8(const half_t* ptr) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const half8v*>(ptr));
+    else return *reinterpret_cast<const half8v*>(ptr);
+}
+
 // Row-add / residual operands of the store loops are fetched several chunks AHEAD of the stores.  `out` may alias `residual`, so the
 // compiler keeps every load behind the previous iteration's store, and each 16-byte chunk paid a global-load round trip plus the store
 // drain (`s_waitcnt vmcnt(0)`).  With operands served by the Infinity Cache (B = 2 forward) that costs nothing measurable; from HBM
@@ -722,12 +734,12 @@ __device__ __forceinline__ void st_out8(half_t* ptr, const half8v v, bool nt) {
 // (tools/bench_gemm.py "linear+res", BG_B=16).  A thread only ever reads the addresses it writes itself.
 constexpr int EPI_U = 8;
 
-template <int NTHREADS>
-__device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const char* stage, int pitch, int rows, int out_bn,
+template <int NTHREADS, bool NT>
+__device__ __forceinline__ void store_fp16_tile_impl(const moca_gemm_params& p, const char* stage, int pitch, int rows, int out_bn,
                                                 int m0, int on0, int tid) {
     const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
-    const bool nt_out = out_streams(p);
+    constexpr bool nt_out = NT;                        // (= out_streams(p), chosen by the wrapper below)
     const int chunks_per_row = out_bn / 8;
     const int total_chunks = rows * chunks_per_row;
     if (!rowadd && !resid) {
@@ -760,7 +772,7 @@ __device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const
             ea[u] = zero8; er[u] = zero8;
             if (ok[u]) {
                 if (rowadd) ea[u] = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
-                if (resid) er[u] = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+                if (resid) er[u] = ld_res8<NT>(resid + (int64_t)m * p.ldr + col);
             }
         }
 #pragma unroll
@@ -779,19 +791,26 @@ __device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const
     }
 }
 
+template <int NTHREADS>
+__device__ __forceinline__ void store_fp16_tile(const moca_gemm_params& p, const char* stage, int pitch, int rows, int out_bn,
+                                                int m0, int on0, int tid) {
+    if (out_streams(p)) store_fp16_tile_impl<NTHREADS, true>(p, stage, pitch, rows, out_bn, m0, on0, tid);
+    else store_fp16_tile_impl<NTHREADS, false>(p, stage, pitch, rows, out_bn, m0, on0, tid);
+}
+
 // ---- store loop of the 320 x 160 kernels with GroupNorm statistics (MOCA_EP_COLSUM): as store_fp16_tile, but every thread
 //      keeps a FIXED 16-byte column chunk (thread -> chunk tid % 20, rows tid / 20 + 25 i) so that it can accumulate the sum and
 //      the sum of squares of its 8 columns in registers on the way out (fp32 values after row add / residual, i.e. what the
 //      consumer's GroupNorm would read back, before the fp16 rounding); the 25 row subsets are then combined through LDS in a
 //      fixed order (deterministic) and the block writes colsum[tile_m][n0 .. n0+160)[2].  `red` = 32 000 B of LDS scratch
 //      behind the staged tile.
-template <int ROWS, int BNC>
-__device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p, const char* stage, float* red, int pitch,
+template <int ROWS, int BNC, bool NT>
+__device__ __forceinline__ void store_fp16_tile_colsum_impl(const moca_gemm_params& p, const char* stage, float* red, int pitch,
                                                        int m0, int n0, int tile_m, int tid) {
     constexpr int CPR = BNC / 8, RS = 512 / CPR;          // 320 x 160: 20 chunks per row, 25 row subsets; 160 x 320: 40 and 12
     const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
-    const bool nt_out = out_streams(p);
+    constexpr bool nt_out = NT;                        // (= out_streams(p), chosen by the wrapper below)
     const int ch = tid % CPR, rs = tid / CPR;
     float s[8], q[8];
 #pragma unroll
@@ -808,7 +827,7 @@ __device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p
                 ea[u] = zero8; er[u] = zero8;
                 if (row < ROWS && m < p.M) {
                     if (rowadd) ea[u] = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
-                    if (resid) er[u] = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+                    if (resid) er[u] = ld_res8<NT>(resid + (int64_t)m * p.ldr + col);
                 }
             }
 #pragma unroll
@@ -871,6 +890,13 @@ __device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p
         for (int r = 0; r < RS; ++r) a += red[r * BNC * 2 + i];
         p.colsum[((int64_t)tile_m * p.N + n0) * 2 + i] = a;
     }
+}
+
+template <int ROWS, int BNC>
+__device__ __forceinline__ void store_fp16_tile_colsum(const moca_gemm_params& p, const char* stage, float* red, int pitch,
+                                                       int m0, int n0, int tile_m, int tid) {
+    if (out_streams(p)) store_fp16_tile_colsum_impl<ROWS, BNC, true>(p, stage, red, pitch, m0, n0, tile_m, tid);
+    else store_fp16_tile_colsum_impl<ROWS, BNC, false>(p, stage, red, pitch, m0, n0, tile_m, tid);
 }
 
 // ---- store loop of the 160 x 320 tile with LayerNorm (MOCA_EP_LN, N == 320: the block owns complete rows): 8 lanes per row,
@@ -944,14 +970,14 @@ __device__ __forceinline__ void store_fp16_tile_ln(const moca_gemm_params& p, co
 //      (lane l -> 16-byte chunks l, l + LPR, ...), so the sum and the sum of squares of the stored (fp16-rounded) values of a
 //      row's BNC columns are reduced with shuffles and written to rowsum[column tile][m][2].  The consumer
 //      (MOCA_EP_LNFOLD) combines the N / BNC partials of a row. ----
-template <int NTHREADS, int BNC, int LPR>
-__device__ __forceinline__ void store_fp16_tile_rowsum(const moca_gemm_params& p, const char* stage, int pitch, int rows,
+template <int NTHREADS, int BNC, int LPR, bool NT>
+__device__ __forceinline__ void store_fp16_tile_rowsum_impl(const moca_gemm_params& p, const char* stage, int pitch, int rows,
                                                        int m0, int n0, int tid) {
     constexpr int CPL = BNC / 8 / LPR;
     static_assert(CPL * LPR * 8 == BNC, "column tile = LPR lanes x CPL chunks of 8");
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
     const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
-    const bool nt_out = out_streams(p);
+    constexpr bool nt_out = NT;                        // (= out_streams(p), chosen by the wrapper below)
     const int l = tid % LPR, rsub = tid / LPR;
     float* dst = p.rowsum + (int64_t)(n0 / BNC) * p.M * 2;
     const half8v zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -965,7 +991,7 @@ __device__ __forceinline__ void store_fp16_tile_rowsum(const moca_gemm_params& p
             fa[c] = zero8; fr[c] = zero8;
             if (row < rows && m < p.M) {
                 if (rowadd) fa[c] = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + n0 + col);
-                if (resid) fr[c] = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + n0 + col);
+                if (resid) fr[c] = ld_res8<NT>(resid + (int64_t)m * p.ldr + n0 + col);
             }
         }
     };
@@ -998,6 +1024,13 @@ __device__ __forceinline__ void store_fp16_tile_rowsum(const moca_gemm_params& p
 #pragma unroll
         for (int c = 0; c < CPL; ++c) { ea[c] = na[c]; er[c] = nr[c]; }
     }
+}
+
+template <int NTHREADS, int BNC, int LPR>
+__device__ __forceinline__ void store_fp16_tile_rowsum(const moca_gemm_params& p, const char* stage, int pitch, int rows,
+                                                       int m0, int n0, int tid) {
+    if (out_streams(p)) store_fp16_tile_rowsum_impl<NTHREADS, BNC, LPR, true>(p, stage, pitch, rows, m0, n0, tid);
+    else store_fp16_tile_rowsum_impl<NTHREADS, BNC, LPR, false>(p, stage, pitch, rows, m0, n0, tid);
 }
 
 // ---- MOCA_EP_LNFOLD, step 1: thread t < TM owns the LayerNorm statistics of A row m0 + t, thread t < BN the wsum / bias of
