@@ -85,6 +85,17 @@ def linear(lv, k, n, geglu=False, splits=None):
     return run(f"linear   L{lv} {k}->{nn}{' geglu' if geglu else ''} M={M} s={s}", fn, 2.0 * M * nn * k)
 
 
+def tattn(lv, k, heads):
+    """to_q|to_k|to_v per head + temporal attention in the epilogue (MOCA_EP_TATTN, the 320 x 192 tiling)"""
+    H, W = LV[lv]; M = F * H * W
+    x = torch.randn(M, k, device=DEV).half()
+    C = heads * 64
+    wq, wk, wv = (torch.randn(C, k, device=DEV) * k ** -0.5 for _ in range(3))
+    pw = ops.pack_qkv_per_head(wq, wk, wv, heads)
+    out = torch.empty(M, C, device=DEV, dtype=torch.float16)
+    return run(f"qkv+tattn L{lv} {k}->{3 * C} M={M}", lambda: ops.gemm(x, pw, out, M=M, tattn=(T, H * W, 0.125)), 2.0 * M * 3 * C * k)
+
+
 def linear_res(lv, k, n):
     """with residual (as in the model: attention out-proj, ff2, proj_out all add a residual)"""
     H, W = LV[lv]; M = F * H * W

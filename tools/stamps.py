@@ -16,7 +16,8 @@ shapes = {"qkv0": lambda: B.linear(0, 320, 960), "geglu0": lambda: B.linear(0, 3
           "lin0": lambda: B.linear(0, 320, 320), "ff2_0": lambda: B.linear(0, 1280, 320), "conv0": lambda: B.conv(0, 320, 320),
           "conv2": lambda: B.conv(2, 1280, 1280), "conv1": lambda: B.conv(1, 640, 640), "qkv1": lambda: B.linear(1, 640, 1920),
           "geglu1": lambda: B.linear(1, 640, 2560, geglu=True), "linres0": lambda: B.linear_res(0, 320, 320),
-          "ff2res0": lambda: B.linear_res(0, 1280, 320), "tconv0": lambda: B.tconv(0, 320)}
+          "ff2res0": lambda: B.linear_res(0, 1280, 320), "tconv0": lambda: B.tconv(0, 320),
+          "tattn0": lambda: B.tattn(0, 320, 5), "tattn1": lambda: B.tattn(1, 640, 10), "tattn2": lambda: B.tattn(2, 1280, 20)}
 dt = shapes[which]()
 torch.cuda.synchronize()
 lib = L.load()
