@@ -3082,429 +3082,6 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const moca_gemm_params
 #endif
 }
 
-// =====================================================================================
-// "w80p" kernel: the staggered 320 x 160 / 160 x 320 kernel (w80s, SHAPE 0 / 1) as a PERSISTENT kernel.  Phase stamps
-// (profiles/r05_g4_phase_stamps.txt): on the short-K launches of these tilings a block spends 3-8 k cycles before its first k-tile has
-// landed and the CU another 1-2 k between two blocks (a 150 KiB block only starts when its predecessor has left): 17-27 % of a K = 320
-// tile, ~12 % at K = 1280 -- time in which the CU neither computes nor has anything in flight.  Here one block per CU walks its tiles
-// (XCD-local raster order) and the DMA stream crosses tile boundaries:
-//   * K % 320 == 0 (every conv / temporal conv / linear of the UNet): a tile is a multiple of five k-tile pairs, so the five ring slots
-//     hold the same k-tiles (mod 5) in every tile: the next tile's first pair always lands in slots 0 / 1 and slots 2..4 (90 KiB) are
-//     free from the last MFMAe to the end of the epilogue;
-//   * the last-but-one iteration issues the NEXT tile's first pair; the last iteration issues nothing (the second pair would need
-//     slots 2 / 3); the epilogue runs in slots 2..4 on HALF tiles (160 / 80 rows: 54 KiB of staged fp16 rows + 32 KiB of column-sum
-//     scratch), i.e. stage - store - stage - store; the second pair is issued behind it and the main loop starts on a landed first pair;
-//   * the store loops are those of w80s (plain / row add / residual, column sums or finished GroupNorm statistics, row sums,
-//     LayerNorm) on half tiles: statistics tiles are 160 / 80 rows (moca_gemm_colsum_rows() says so);
-//   * the bias row of the tile is fetched by LDS-DMA into the 10 KiB of LDS behind the ring and read from there into the accumulators
-//     at the start of the tile (no VGPR is the destination of a load outside the store loops, see gemm_sqp_kernel);
-//   * waves 0..3 / 4..7 run one barrier apart in the main loop, meet before the epilogue and part again behind it.
-// Not here (the launch takes w80s): split-k, LayerNorm fold, the temporal-attention epilogue, K % 320 != 0, fewer than 256 tiles.
-// =====================================================================================
-#ifndef W80P_LOADO_PRIO
-#define W80P_LOADO_PRIO 2
-#endif
-template <int AMODE, bool WIDE>
-__global__ __launch_bounds__(512, 2) void gemm_w80p_kernel(const moca_gemm_params p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int MT = 5, NT = 5, KS = 32, RB = 64, WTM = 80, WTN = 80;
-    constexpr int TM = WIDE ? 160 : 320, BN = WIDE ? 320 : 160;
-    constexpr int A_BYTES = TM * RB, STAGE = A_BYTES + BN * RB, NS = 5, PPW = 4;
-    constexpr int NAP = WIDE ? 2 : 3;
-    constexpr int HR = TM / 2;                            // rows of a half tile
-    constexpr int pitch = BN * 2 + 16;
-    constexpr int EPI_OFF = 2 * STAGE;                    // slots 2..4
-    constexpr int BIAS_OFF = NS * STAGE;                  // [BN] floats behind the ring
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = WIDE ? wave >> 2 : wave >> 1, wave_n = WIDE ? wave & 3 : wave & 1;
-    const bool late = wave >= 4;
-    const int nper = p.reserved2_;
-    if (prefetch_block(p, nper, 512)) return;
-
-    // ---- this block's tiles (partition and walk of gemm_sqp_kernel).  Everything that is needed once per tile -- the walk, the row /
-    //      column offsets of the next tile, the store loops' parameters -- is computed FROM SCRATCH where it is needed, from kernel
-    //      arguments re-read through an opaque pointer (s_load, a few hundred cycles once per tile): read from `p` they are loaded ahead
-    //      of the tile loop and stay live through the steady-state loop, where ~30 scalars too many turn into v_readlane in the LOADo
-    //      segment -- VALU work that queues behind the raised-priority MFMAs of the SIMD's other wave (profiles/r05_ab_w80p.txt) ----
-    typedef const __attribute__((address_space(4))) moca_gemm_params* kparams_ptr;
-    auto fresh_params = [&]() __attribute__((always_inline)) -> kparams_ptr {
-        kparams_ptr kq = (kparams_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(kq));
-        return kq;
-    };
-    // q-th tile of this block's XCD; J = the walk's stride (blocks per XCD); false: past the end of the XCD's set
-    auto tile_at = [&](kparams_ptr kq, int q, int& tm, int& tn, int& J) __attribute__((always_inline)) -> bool {
-        const int tiles_n = kq->N / BN, tiles_m = (kq->M + TM - 1) / TM;
-        const int xcd_n = kq->reserved4_ >> 8;
-        J = kq->reserved2_ >> 3;
-        int q_base, q_cnt, sub_n, tm_base, tn_base;
-        const int x = blockIdx.x & 7;
-        if (xcd_n > 1) {
-            const int xm = 8 / xcd_n, sm = tiles_m / xm;
-            sub_n = tiles_n / xcd_n;
-            const int xi = x / xcd_n, xj = x - xi * xcd_n;
-            tm_base = xi * sm; tn_base = xj * sub_n;
-            q_base = 0; q_cnt = sm * sub_n;
-        } else {
-            const int ntiles = tiles_m * tiles_n, qq = ntiles >> 3, r = ntiles & 7;
-            q_base = x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq;
-            q_cnt = qq + (x < r ? 1 : 0);
-            sub_n = tiles_n; tm_base = 0; tn_base = 0;
-        }
-        const int l = q_base + q;
-        const int a = l / sub_n;
-        tm = tm_base + a; tn = tn_base + (l - a * sub_n);
-        return q < q_cnt;
-    };
-    int q_cur = blockIdx.x >> 3;
-    {
-        int tm, tn, J;
-        if (!tile_at(fresh_params(), q_cur, tm, tn, J)) return;       // (block-uniform)
-    }
-    const int nk = p.K / 32;                              // K % 320 == 0 (host-checked): a multiple of ten k-tiles
-
-    // ---- DMA stream (piece assignment of w80s) ----
-    const int lrow = lane >> 2, pch = lane & 3;
-    const int lch = pch ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
-    const bool flex_is_big = wave < 4;
-    BGather<AMODE, NAP, KS> ga(p, lch, 0, nk - 2);
-    const int small1 = wave < 6 ? 4 + wave : 2 + wave;
-    unsigned w_off[3];
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, OOB_OFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, OOB_OFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_f = (flex_is_big != WIDE) ? rsrc_a : rsrc_w;
-    // the stream moves to tile q + steps * J of this block (past the end: no tile -- every lane out of range: zero fill, no traffic)
-    auto set_dma_tile = [&](int q, int steps) __attribute__((always_inline)) {
-        kparams_ptr kq = fresh_params();
-        int tm, tn, J;
-        tile_at(kq, q, tm, tn, J);
-        const bool any = tile_at(kq, q + steps * J, tm, tn, J);
-        const int M = kq->M;
-        const int m0 = any ? tm * TM : M, n0 = tn * BN;
-        // (lane constants recomputed from an opaque lane id: kept across the main loop they are spilled, and a reload here -- in the
-        //  LOADo segment that has just issued a pair -- waits for that pair with the vmcnt(0) every scratch reload gets)
-        int ln;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-        const int lrow = ln >> 2;
-        const int lch = (ln & 3) ^ ((0x78 >> (2 * ((lrow >> 2) & 3))) & 3);
-        const int ldw = kq->ldw, lda = kq->lda;
-        auto wo = [&](int rowpiece) __attribute__((always_inline)) -> unsigned {
-            return any ? (unsigned)(((int64_t)(n0 + rowpiece * 16 + lrow) * ldw + lch * 8) * 2) : OOB_OFF;
-        };
-        // a linear's A offsets directly (BGather's per-row state would be kept -- in scratch -- for taps that never change)
-        auto ao = [&](int rowpiece) __attribute__((always_inline)) -> unsigned {
-            const int m = m0 + rowpiece * 16 + lrow;
-            return m < M ? (unsigned)(((int64_t)m * lda + lch * 8) * 2) : OOB_OFF;
-        };
-        // conv / temporal conv: the row descriptors through a BGather on the re-read parameters
-        auto rows = [&](int g, int rowpiece) __attribute__((always_inline)) {
-            const moca_gemm_params pk = *kq;
-            BGather<AMODE, NAP, KS> gt(pk, lch, 0, 0);
-            gt.init_row(g, min(m0 + rowpiece * 16 + lrow, M));
-            ga.row_off[g] = gt.row_off[g]; ga.row_y[g] = gt.row_y[g]; ga.row_x[g] = gt.row_x[g]; ga.row_ok[g] = gt.row_ok[g];
-        };
-        if constexpr (!WIDE) {
-            if constexpr (AMODE == MOCA_A_LINEAR) {
-                ga.a_off[0] = ao(wave); ga.a_off[1] = ao(8 + wave); ga.a_off[2] = ao(16 + (wave & 3));
-            } else {
-                rows(0, wave); rows(1, 8 + wave); rows(2, 16 + (wave & 3));
-            }
-            w_off[0] = wo(wave & 3); w_off[1] = wo(small1); w_off[2] = 0;
-        } else {
-            if constexpr (AMODE == MOCA_A_LINEAR) {
-                ga.a_off[0] = ao(wave & 3); ga.a_off[1] = ao(small1);
-            } else {
-                rows(0, wave & 3); rows(1, small1);
-            }
-            w_off[0] = wo(wave); w_off[1] = wo(8 + wave); w_off[2] = wo(16 + (wave & 3));
-        }
-        if constexpr (AMODE == MOCA_A_LINEAR) { ga.kt_next = 0; ga.tin = 0; }
-        else { ga.lch = lch; ga.seek(0); }
-    };
-    auto dma_piece = [&](int slot, int j, auto odd_tag) __attribute__((always_inline)) {
-        constexpr int odd = decltype(odd_tag)::value;
-        const lds_ptr sa = (lds_ptr)smem + slot * STAGE;
-        const unsigned a_s = ga.a_soff() + odd * KS * 2, w_s = ga.w_soff() + odd * KS * 2;
-        if constexpr (!WIDE) {
-            if (j < 2) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, sa + (j * 8 + wave) * 1024, 16, ga.a_off[j], a_s, 0, 0);
-            } else if (j == 2) {
-                const lds_ptr dst = flex_is_big ? sa + (16 + (wave & 3)) * 1024 : sa + A_BYTES + (wave & 3) * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_f, dst, 16, flex_is_big ? ga.a_off[2] : w_off[0], flex_is_big ? a_s : w_s, 0, 0);
-            } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, sa + A_BYTES + small1 * 1024, 16, w_off[1], w_s, 0, 0);
-            }
-        } else {
-            if (j < 2) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, sa + A_BYTES + (j * 8 + wave) * 1024, 16, w_off[j], w_s, 0, 0);
-            } else if (j == 2) {
-                const lds_ptr dst = flex_is_big ? sa + A_BYTES + (16 + (wave & 3)) * 1024 : sa + (wave & 3) * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_f, dst, 16, flex_is_big ? w_off[2] : ga.a_off[0], flex_is_big ? w_s : a_s, 0, 0);
-            } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, sa + small1 * 1024, 16, ga.a_off[1], a_s, 0, 0);
-            }
-        }
-    };
-    auto issue_pair = [&](int slot_even, int slot_odd) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            dma_piece(slot_even, j, int_c<0>{});
-            dma_piece(slot_odd, j, int_c<1>{});
-        }
-    };
-    // bias row of tile q -> LDS (4 bytes per lane, waves 0 .. BN / 64; lanes past BN read a dummy)
-    auto bias_dma = [&](int q, int steps) __attribute__((always_inline)) {
-        kparams_ptr kq = fresh_params();
-        const float* bias = kq->bias;
-        if (bias && wave * 64 < BN) {
-            int tm, tn, J;
-            tile_at(kq, q, tm, tn, J);
-            if (!tile_at(kq, q + steps * J, tm, tn, J)) tn = 0;
-            int l;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-            const int c = wave * 64 + l;
-            const float* src = c < BN ? bias + tn * BN + c : bias;
-            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)smem + BIAS_OFF + wave * 256, 4, 0, 0);
-        }
-    };
-
-    const int fr = lane & 15, fg = lane >> 4;
-    f32x4 acc[MT][NT];
-    const int swz = (fg ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
-    const int a_off0 = (wave_m * WTM + fr) * RB + swz;
-    const int b_off0 = A_BYTES + (wave_n * WTN + fr) * RB + swz;
-    half8v af[2][MT], bf[2][NT];
-    auto read_tile = [&](auto set_tag, int slot) __attribute__((always_inline)) {
-        constexpr int S = decltype(set_tag)::value;
-        const char* cur = smem + slot * STAGE;
-#pragma unroll
-        for (int r = 0; r < NT; ++r) bf[S][r] = *reinterpret_cast<const half8v*>(cur + b_off0 + r * 1024);
-#pragma unroll
-        for (int r = 0; r < MT; ++r) af[S][r] = *reinterpret_cast<const half8v*>(cur + a_off0 + r * 1024);
-    };
-
-    // ---- prologue (once per block): bias row, two pairs in flight, the first landed everywhere ----
-    const unsigned bias_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((lds_ptr)smem + BIAS_OFF));
-    if (!p.bias) {                                        // the row stays zero
-        for (int i = tid; i < BN; i += 512) lds_wr_f1(bias_lds + 4 * i, 0.f);
-        lds_wait();
-    }
-    bias_dma(q_cur, 0);
-    set_dma_tile(q_cur, 0);
-    issue_pair(0, 1);
-    ga.advance();
-    issue_pair(2, 3);
-    ga.advance();
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-    __builtin_amdgcn_s_barrier();
-    if (late) __builtin_amdgcn_s_barrier();               // from here on waves 4..7 run one barrier behind waves 0..3
-
-#ifdef MOCA_STAMPS
-    int tile_no = 0;
-    bool stamp_it = false, seg = false;
-#endif
-    // One iteration = two k-tiles: LOADe | B | MFMAe (+ reads of the odd k-tile) | B | LOADo | B | MFMAo | B.  LOADo by MODE:
-    //   0  steady state: the stream's next pair into the slots of k-tiles i - 1 and i, the stream moves on inside the tile
-    //   1  the pair is the tile's last: the stream then moves to the next tile (set_dma_tile: row / tap set-up with divisions -- cold code
-    //      that must not sit INSIDE the steady loop: its scalars would count as live there, hot ones get spilled to VGPR lanes, and every
-    //      v_readlane of the LOADo wave queues behind the MFMAs of its SIMD's other wave, which run at raised priority: LOADo 545 -> 850
-    //      cycles, i.e. longer than the MFMA segment it hides behind, profiles/r05_ab_w80p.txt)
-    //   2  the next tile's FIRST pair (slots 0 / 1)
-    //   3  the tile's last iteration issues nothing: the next tile's second pair belongs in slots 2 / 3, which the epilogue is about to use
-    int s0 = 0;
-    auto iteration = [&](auto mode_tag) __attribute__((always_inline)) {
-        constexpr int MODE = decltype(mode_tag)::value;
-        const int s1 = s0 + 1 == NS ? 0 : s0 + 1;
-        const int sp = s0 == 0 ? NS - 1 : s0 - 1;
-        // ---- LOADe ----
-#ifdef MOCA_STAMPS
-        if (seg) MOCA_STAMP_W(8, SEG_WAVE);
-#endif
-        read_tile(int_c<0>{}, s0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef MOCA_STAMPS
-        if (seg) MOCA_STAMP_W(9, SEG_WAVE);
-#endif
-        __builtin_amdgcn_s_barrier();
-#ifdef MOCA_STAMPS
-        if (seg) MOCA_STAMP_W(10, SEG_WAVE);
-#endif
-        // ---- MFMAe with the reads of k-tile i + 1 in the gaps ----
-        {
-            const char* nx = smem + s1 * STAGE;
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int j = 0; j < MT * NT; ++j) {
-                const int mt = j / NT, nt = j % NT;
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[0][nt], af[0][mt], acc[mt][nt], 0, 0, 0);
-                if (j % 2 == 0 && j / 2 < MT + NT) {
-                    const int r = j / 2;
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (r < NT) bf[1][r] = *reinterpret_cast<const half8v*>(nx + b_off0 + r * 1024);
-                    else af[1][r - NT] = *reinterpret_cast<const half8v*>(nx + a_off0 + (r - NT) * 1024);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef MOCA_STAMPS
-        if (seg) MOCA_STAMP_W(11, SEG_WAVE);
-#endif
-        __builtin_amdgcn_s_barrier();
-#ifdef MOCA_STAMPS
-        if (seg) MOCA_STAMP_W(12, SEG_WAVE);
-#endif
-        // ---- LOADo (above the priority of the MFMA segment the SIMD's other wave is in: the few VALU instructions here -- v_readlane of
-        //      spilled scalars, the flex piece's select -- otherwise queue behind its MFMAs one by one) ----
-        if constexpr (MODE != 3) {
-            __builtin_amdgcn_s_setprio(W80P_LOADO_PRIO);
-            issue_pair(sp, s0);
-            if constexpr (MODE == 1) set_dma_tile(q_cur, 1);
-            else ga.advance();
-            __builtin_amdgcn_s_setprio(0);
-        }
-#ifdef MOCA_STAMPS
-        if (seg) MOCA_STAMP_W(13, SEG_WAVE);
-#endif
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef MOCA_STAMPS
-        if (seg) MOCA_STAMP_W(14, SEG_WAVE);
-#endif
-        __builtin_amdgcn_s_barrier();
-#ifdef MOCA_STAMPS
-        if (seg) MOCA_STAMP_W(15, SEG_WAVE);
-#endif
-        // ---- MFMAo ----
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[1][nt], af[1][mt], acc[mt][nt], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        s0 = s1 + 1 == NS ? 0 : s1 + 1;
-    };
-    while (true) {
-#ifdef MOCA_STAMPS
-        stamp_it = tile_no == 3;                         // (phases: [0, 0, main loop, first half staged + stored, second half])
-        if (stamp_it) { MOCA_STAMP(0); MOCA_STAMP(1); MOCA_STAMP(2); }
-#endif
-        // accumulators start from the bias row (as in w80s: the results are bit-identical to that kernel's)
-        int ln_b;                                         // (opaque lane id: no address kept -- spilled -- across the main loop)
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln_b));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            f32x4 bv;
-            bv = lds_rd_f4(bias_lds + 4 * (wave_n * WTN + nt * 16 + 4 * (ln_b >> 4)));      // (zeros without a bias: no flag to keep)
-            lds_wait();
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
-        }
-        s0 = 0;                                            // (nk % 10 == 0: every tile starts in slot 0)
-        for (int i = 0; i < nk - 6; i += 2) {              // pairs 2 .. P - 2 go out here
-#ifdef MOCA_STAMPS
-            seg = stamp_it && i == SEG_ITER;
-#endif
-            iteration(int_c<0>{});
-        }
-#ifdef MOCA_STAMPS
-        seg = false;
-#endif
-        iteration(int_c<1>{});                             // pair P - 1; the stream switches tiles
-        iteration(int_c<2>{});                             // the next tile's pair 0
-        iteration(int_c<3>{});
-#ifdef MOCA_STAMPS
-        if (stamp_it) MOCA_STAMP(3);
-#endif
-        // ---- epilogue on half tiles in slots 2..4; the halves of the workgroup meet first ----
-        if (!late) __builtin_amdgcn_s_barrier();
-        char* const stage = smem + EPI_OFF;
-        // (the launch parameters of the store loops are re-read from the kernel-argument segment behind an opaque pointer: read from
-        //  `p` they are loaded once, ahead of the tile loop, and the ~60 scalars then live -- spilled to VGPR lanes -- through the main
-        //  loop, whose LOADo segment fills up with v_readlane: 940-1440 cycles instead of 540, profiles/r05_ab_w80p.txt)
-        kparams_ptr kp = fresh_params();
-        const moca_gemm_params pe = *kp;
-        int tm, tn, J;
-        tile_at(kp, q_cur, tm, tn, J);
-        const int m0 = tm * TM, n0 = tn * BN;
-        // (thread / lane ids of the epilogue from an opaque lane id: values derived from threadIdx.x would live across the main loop,
-        //  i.e. in scratch, and every reload inside a store loop waits for the stores before it)
-        int ln_e;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln_e));
-        const int tid_e = wave * 64 + ln_e, fr_e = ln_e & 15, fg_e = ln_e >> 4;
-        // (the tile as fp16 from here on: 50 registers instead of 100 live through the first half's store loop)
-        half4v hacc[MT][NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) hacc[mt][nt] = __builtin_convertvector(acc[mt][nt], half4v);
-        for (int h = 0; h < 2; ++h) {
-            constexpr int WM_HALF = WIDE ? 1 : 2;         // wave rows per half tile
-            if (wave_m / WM_HALF == h) {
-                const int wml = wave_m - h * WM_HALF;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int col = wave_n * WTN + nt * 16 + 4 * fg_e;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int row = wml * WTM + mt * 16 + fr_e;
-                        *reinterpret_cast<half4v*>(stage + row * pitch + col * 2) = hacc[mt][nt];
-                    }
-                }
-            }
-            __syncthreads();
-            const int mh = m0 + h * HR;
-            float* const red = reinterpret_cast<float*>(stage + HR * pitch);
-            if constexpr (WIDE) {
-                if (pe.flags & MOCA_EP_LN) store_fp16_tile_ln<HR>(pe, stage, red, pitch, mh, tid_e);
-                else if (pe.flags & (MOCA_EP_COLSUM | MOCA_EP_GSTAT)) store_fp16_tile_colsum<HR, BN>(pe, stage, red, pitch, mh, n0, 2 * tm + h, tid_e);
-                else if (pe.flags & MOCA_EP_ROWSUM) store_fp16_tile_rowsum<512, BN, 8>(pe, stage, pitch, HR, mh, n0, tid_e);
-                else store_fp16_tile<512>(pe, stage, pitch, HR, BN, mh, n0, tid_e);
-            } else {
-                if (pe.flags & (MOCA_EP_COLSUM | MOCA_EP_GSTAT)) store_fp16_tile_colsum<HR, BN>(pe, stage, red, pitch, mh, n0, 2 * tm + h, tid_e);
-                else if (pe.flags & MOCA_EP_ROWSUM) store_fp16_tile_rowsum<512, BN, 4>(pe, stage, pitch, HR, mh, n0, tid_e);
-                else store_fp16_tile<512>(pe, stage, pitch, HR, BN, mh, n0, tid_e);
-            }
-            __syncthreads();
-#ifdef MOCA_STAMPS
-            if (stamp_it && h == 0) MOCA_STAMP(4);
-#endif
-        }
-#ifdef MOCA_STAMPS
-        if (stamp_it) { MOCA_STAMP(5); MOCA_STAMP_HW(); }
-        ++tile_no;
-#endif
-        // (a wait the compiler can see: the store loops leave operand loads it still counts as pending, and it would otherwise wait
-        //  for everything -- i.e. for the pair issued below -- before the accumulators are written at the start of the next tile.
-        //  Here only the next tile's first pair is in flight, issued an iteration and an epilogue ago)
-        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
-        {
-            int tm2, tn2, J2;
-            if (!tile_at(kp, q_cur + J, tm2, tn2, J2)) break;
-        }
-        q_cur += J;
-        // ---- behind the epilogue: the next tile's bias row and SECOND pair (slots 2 / 3); its first pair has landed ----
-        bias_dma(q_cur, 0);
-        issue_pair(2, 3);
-        ga.advance();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        if (late) __builtin_amdgcn_s_barrier();           // waves 4..7 fall one barrier behind again
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-}
-
 // XCD partition (xm x xn = 8, xn returned; 1 = the 1-D partition) of a tiles_m x tiles_n grid of TM x BN tiles of a LINEAR
 // launch: estimated fabric bytes = W part + A part.  W: an XCD whose W sub-range ((tiles_n / xn) BN x K) fits its L2 (<= 3 MB)
 // fetches it once -> xm |W| in total; one that does not streams it again for every M tile it owns -> tiles_m |W| whatever
@@ -3617,43 +3194,8 @@ static inline bool takes_w80t_ln(const moca_gemm_params& p) {     // the 160 x 3
     return p.a_mode == MOCA_A_LINEAR && p.N == 320 && p.splits == 1 && takes_w80s(p) && !(p.flags & (MOCA_EP_COLSUM | MOCA_EP_GSTAT));
 }
 
-// the persistent form of the staggered 320 x 160 / 160 x 320 kernel (gemm_w80p_kernel; MOCA_TUNE_GEMM_W80P = 0: never, 1: every call it
-// can run): no split-k, K a multiple of 320 (ten k-tiles: the ring position repeats from tile to tile), every CU gets a tile, and the
-// epilogues of the half-tile store loops (none of LayerNorm fold / GEGLU / fp32 output / temporal attention)
-constexpr int W80P_BLOCKS = 256;
-static inline bool takes_w80p(const moca_gemm_params& p) {
-    if (!moca_tuning_get(MOCA_TUNE_GEMM_W80P) || !takes_w80s(p) || p.splits != 1 || p.K % 320) return false;
-    if (p.flags & (MOCA_EP_LNFOLD | MOCA_EP_TATTN | MOCA_EP_GEGLU | MOCA_EP_OUT_F32 | MOCA_EP_GELU)) return false;
-    if (p.a_mode != MOCA_A_LINEAR && p.C % 64) return false;
-    const bool wide = w80s_wide(p);
-    const int tm = wide ? 160 : 320, bn = wide ? 320 : 160;
-    return ((p.M + tm - 1) / tm) * (p.N / bn) >= W80P_BLOCKS;
-}
-template <int AMODE, bool WIDE>
-int launch_gemm_w80p(const moca_gemm_params& p, hipStream_t st) {
-    constexpr int TM = WIDE ? 160 : 320, BN = WIDE ? 320 : 160;
-    constexpr int lds = 5 * (TM + BN) * 64 + BN * 4;     // the ring + the tile's bias row
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w80p_kernel<AMODE, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return MOCA_E_LAUNCH;
-        attr_set = true;
-    }
-    moca_gemm_params pl = p;
-    pl.reserved2_ = W80P_BLOCKS;
-    pl.reserved4_ = (pl.reserved4_ & 0xff) | (choose_xcd_n(p, (p.M + TM - 1) / TM, p.N / BN, TM, BN) << 8);
-    hipLaunchKernelGGL((gemm_w80p_kernel<AMODE, WIDE>), dim3(W80P_BLOCKS + prefetch_blocks(pl)), dim3(512), lds, st, pl);
-    MOCA_CHECK_LAUNCH();
-    return MOCA_OK;
-}
-
 int launch_gemm_w80_mode(const moca_gemm_params& p, hipStream_t st) {
     const bool wide = w80s_wide(p);
-    if (takes_w80p(p)) {
-        if (p.a_mode == MOCA_A_LINEAR) return wide ? launch_gemm_w80p<MOCA_A_LINEAR, true>(p, st) : launch_gemm_w80p<MOCA_A_LINEAR, false>(p, st);
-        if (p.a_mode == MOCA_A_CONV3X3) return wide ? launch_gemm_w80p<MOCA_A_CONV3X3, true>(p, st) : launch_gemm_w80p<MOCA_A_CONV3X3, false>(p, st);
-        return wide ? launch_gemm_w80p<MOCA_A_TCONV3, true>(p, st) : launch_gemm_w80p<MOCA_A_TCONV3, false>(p, st);
-    }
     if (p.a_mode == MOCA_A_LINEAR) return wide ? launch_gemm_w80s<MOCA_A_LINEAR, 1>(p, st) : launch_gemm_w80s<MOCA_A_LINEAR, 0>(p, st);
     if (p.a_mode == MOCA_A_CONV3X3) return wide ? launch_gemm_w80s<MOCA_A_CONV3X3, 1>(p, st) : launch_gemm_w80s<MOCA_A_CONV3X3, 0>(p, st);
     return wide ? launch_gemm_w80s<MOCA_A_TCONV3, 1>(p, st) : launch_gemm_w80s<MOCA_A_TCONV3, 0>(p, st);
@@ -3804,7 +3346,7 @@ static int takes_glds_bn(const moca_gemm_params& p) {
 // 256 on the 256-row kernel (fp16 output, no GEGLU, no split-k)
 static int colsum_rows(const moca_gemm_params& p) {
     if (p.splits != 1) return 0;
-    if (takes_w80s(p)) return (w80s_wide(p) ? 160 : 320) >> (takes_w80p(p) ? 1 : 0);      // (the persistent form stores half tiles)
+    if (takes_w80s(p)) return w80s_wide(p) ? 160 : 320;
     if (!(p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32)) && takes_glds_bn(p) != 0) return 256;
     return 0;
 }

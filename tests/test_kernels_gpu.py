@@ -197,7 +197,7 @@ def test_gemm_colsum_feeds_groupnorm(mode, Fr, HW, C, N, fps, with_res):
     if res is not None:
         ref = ref + res.float()
     rows = ops.gemm_colsum_rows(a, pw, M=M, residual=res, **kw)
-    assert rows in (80, 160, 256, 320) and M % rows == 0, "this shape is expected on the 320 x 160 / 160 x 320 (half tiles in the persistent form) / 256-row kernel"
+    assert rows in (160, 256, 320) and M % rows == 0, "this shape is expected on the 320 x 160 / 160 x 320 / 256-row kernel"
     assert (rows == 256) == (HW == 160)
     out = torch.empty(M, N, dtype=torch.float16, device=DEV)
     cs = torch.full((M // rows, 2 * N), float("nan"), dtype=torch.float32, device=DEV)
@@ -532,134 +532,6 @@ def test_gemm_g4p(M, K, N, kind, kern, tune):
         if res is not None:
             ref = ref + res.float()
     check(out, ref, TOL16, f"g4p {M}x{N}x{K} {kind}")
-
-
-W80P_CASES = [
-    # name, mode, dims, N, epilogue
-    ("lin320 +res tail", "linear", (82020, 320), 320, "res"),
-    ("lin320 rowsum", "linear", (41000, 320), 320, "rowsum+res"),
-    ("lin320 K=1280 LN", "linear", (41000, 1280), 320, "ln+res"),
-    ("lin640 rowadd+res", "linear", (20517, 640), 640, "rowadd+res"),
-    ("lin320 tall tiles, no bias", "linear", (82020, 320), 320, "tall+nobias"),
-    ("lin640 no bias", "linear", (20517, 1280), 640, "nobias"),
-    ("lin640 gstat", "linear", (20480, 320), 640, "gstat+res"),
-    ("conv 320->640 gstat", "conv", (8, 320, 64, 40, 1, 0), 640, "gstat"),
-    ("conv 640->320 colsum +rowadd", "conv", (16, 640, 64, 40, 1, 0), 320, "colsum+rowadd"),
-    ("conv stride 2", "conv", (64, 320, 64, 40, 2, 0), 320, "plain"),
-    ("conv up gather", "conv", (16, 320, 32, 20, 1, 1), 320, "plain"),
-    ("upconv phase 3", "conv", (64, 320, 32, 20, 1, 0), 320, "phase"),
-    ("tconv +res gstat", "tconv", (2, 16, 1280, 320), 320, "gstat+res"),
-    ("tconv 640 wide", "tconv", (2, 16, 640, 640), 640, "wide+res"),
-    ("conv wide", "conv", (16, 320, 64, 40, 1, 0), 320, "wide+colsum"),
-]
-
-
-@pytest.mark.parametrize("name,mode,dims,N,epi", W80P_CASES, ids=[c[0] for c in W80P_CASES])
-def test_gemm_w80p_matches_w80s(name, mode, dims, N, epi, tune):
-    """MOCA_TUNE_GEMM_W80P: the persistent form of the staggered 320 x 160 / 160 x 320 kernel (DMA stream across tile boundaries,
-    half-tile epilogues in the three free ring slots) against the one-tile-per-block form: same k order, same MFMA order, bias in the
-    accumulators -- outputs, row sums and LayerNorm rows must be bit-identical; column sums / GroupNorm statistics are sums over half
-    tiles (other partials: compared after reduction).  And against torch."""
-    if "wide" in epi or "tall" in epi:
-        tune(L.MOCA_TUNE_GEMM_WIDE, 2 if "wide" in epi else 0)
-    b = None if "nobias" in epi else rnd(N, dtype=torch.float32)
-    kw = {}
-    if mode == "linear":
-        M, K = dims
-        a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
-        pw = ops.pack_linear(w, b)
-        ref = a.float() @ w.float().t() + (b if b is not None else 0)
-        gs_rows = 2560
-    elif mode == "conv":
-        Fr, C, H, W, stride, up = dims
-        x = rnd(Fr, C, H, W)
-        w = rnd(N, C, 3, 3, scale=(9 * C) ** -0.5)
-        a = nhwc(x)
-        if epi == "phase":
-            pw = ops.pack_upconv_phases(w, b)[2]
-            M = Fr * H * W
-            kw = dict(mode=L.MOCA_A_CONV3X3, conv=(C, H, W, H, W, 1, 0), up_phase=3)
-            ref = None
-        else:
-            pw = ops.pack_conv3x3(w, b)
-            xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if up else x.float()
-            r4 = F.conv2d(xin, w.float(), b, stride=stride, padding=1)
-            oH, oW = r4.shape[-2:]
-            M = Fr * oH * oW
-            kw = dict(mode=L.MOCA_A_CONV3X3, conv=(C, H, W, oH, oW, stride, up))
-            ref = r4.permute(0, 2, 3, 1).reshape(M, N)
-            gs_rows = oH * oW
-    else:
-        B_, T, HW, C = dims
-        x = rnd(B_, C, T, HW, 1)
-        w = rnd(N, C, 3, 1, 1, scale=(3 * C) ** -0.5)
-        pw = ops.pack_tconv3(w, b)
-        a = x[..., 0].permute(0, 2, 3, 1).contiguous()
-        M = B_ * T * HW
-        kw = dict(mode=L.MOCA_A_TCONV3, tconv=(C, T, HW))
-        ref = F.conv3d(x.float(), w.float(), b, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(M, N)
-        gs_rows = T * HW
-    res = rnd(M, N) if "res" in epi else None
-    ra = rnd((M + 319) // 320, N) if "rowadd" in epi else None
-    if ref is not None:
-        if ra is not None:
-            ref = ref + ra.float().repeat_interleave(320, dim=0)[:M]
-        if res is not None:
-            ref = ref + res.float()
-    g, be = rnd(N, dtype=torch.float32) * 0.2 + 1.0, rnd(N, dtype=torch.float32) * 0.2
-    common = dict(M=M, residual=res, rowadd=ra, rowadd_div=320 if ra is not None else 1, **kw)
-
-    def run(persistent):
-        L.set_tuning(L.MOCA_TUNE_GEMM_W80P, persistent)
-        r = {}
-        rows_out = 4 * M if epi == "phase" else M
-        out = torch.full((rows_out, N), float("nan"), dtype=torch.float16, device=DEV)
-        extra = {}
-        if "rowsum" in epi:
-            cols = ops.gemm_rowsum_cols(a, pw, rowsum=True, **common)
-            assert cols in (160, 320)
-            r["rowsum"] = torch.full((N // cols * M, 2), float("nan"), dtype=torch.float32, device=DEV)
-            extra["rowsum"] = r["rowsum"]
-        if "ln" in epi:
-            assert ops.gemm_ln_ok(a, pw, ln=(g, be, None, 1e-5), **common)
-            r["ln"] = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
-            extra["ln"] = (g, be, r["ln"], 1e-5)
-        if "colsum" in epi:
-            rows = ops.gemm_colsum_rows(a, pw, **common)
-            base = 160 if (N % 320 == 0 and (mode == "linear" or "wide" in epi)) else 320
-            assert rows == (base // 2 if persistent else base), (rows, base)
-            assert M % rows == 0
-            cs = torch.full((M // rows, 2 * N), float("nan"), dtype=torch.float32, device=DEV)
-            extra["colsum"] = cs
-        if "gstat" in epi:
-            r["gstat"] = torch.zeros(M // gs_rows * 64, dtype=torch.int64, device=DEV)
-            extra["gstat"] = (r["gstat"], gs_rows)
-        ops.gemm(a, pw, out, **common, **extra)
-        r["out"] = out
-        if "colsum" in epi:
-            r["colsum320"] = cs.view(M // 320, 320 // rows, 2 * N).sum(1)
-        return r
-
-    tune(L.MOCA_TUNE_GEMM_W80P, 1)                       # (restored by the fixture)
-    r0, r1 = run(0), run(1)
-    if ref is not None:
-        check(r1["out"], ref, TOL16, f"w80p {name}")
-    else:
-        written = torch.isfinite(r0["out"].float())
-        assert torch.equal(written, torch.isfinite(r1["out"].float())) and written.any()
-    assert torch.equal(r0["out"].view(torch.int16), r1["out"].view(torch.int16)), f"{name}: output differs from the one-tile-per-block kernel"
-    for key in ("rowsum", "ln"):
-        if key in r0:
-            assert torch.isfinite(r1[key].float()).all()
-            assert torch.equal(r0[key], r1[key]), f"{name}: {key} differs"
-    if "colsum320" in r0:
-        assert relerr(r1["colsum320"], r0["colsum320"]) < 1e-5
-    if "gstat" in r0:
-        sc = torch.tensor([2.0 ** -30, 2.0 ** -16], dtype=torch.float64, device=DEV)
-        g0, g1 = r0["gstat"].view(-1, 32, 2).double() * sc, r1["gstat"].view(-1, 32, 2).double() * sc
-        assert relerr(g1[..., 0], g0[..., 0]) < 1e-5 and relerr(g1[..., 1], g0[..., 1]) < 1e-6
-        xg = r1["out"].float().view(M // gs_rows, gs_rows, 32, N // 32)
-        assert relerr(g1[..., 1], (xg * xg).sum(dim=(1, 3))) < 1e-3
 
 
 def test_gemm_sqp_lnfold_repeatable(tune):
