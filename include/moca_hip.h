@@ -129,6 +129,16 @@ typedef struct moca_gemm_params {
                               land on the same input pixel, summed (ops.pack_upconv_phases); K = 4 C, inH x inW = outH x outW = the
                               low-resolution grid, `out` = the [F][2H][2W][N] tensor (rows scattered by the kernel); 4/9 of the FLOPs */
     int32_t     reserved4_;
+    const void* a2;        /* MOCA_A_LINEAR only, optional: the A operand is the VIRTUAL torch.cat([a, a2], dim=channels) of
+                              openaimodel3d.py:571 -- columns [0, k1) of a row come from a (row stride lda >= k1), columns [k1, K) from a2
+                              (fp16 [M][lda2], lda2 >= K - k1); k1 % 64 == 0, (K - k1) % 64 == 0, no split-K; only where
+                              moca_gemm_cat_ok() != 0 (the staggered 320 x 160 / 160 x 320 kernels: the skip_connection 1x1 convs of the
+                              320- / 640-channel output blocks).  NULL: the plain linear.                                       */
+    int32_t     lda2;
+    int32_t     k1;
+    int32_t     gstat_cpg; /* MOCA_EP_GSTAT: columns per GroupNorm channel group (0 = N / 32) and the channel index of column 0 inside the   */
+    int32_t     gstat_coff;/* consumer's tensor (0): a producer whose output is ONE SOURCE of a virtual concat accumulates the statistics of  */
+                           /* the concat's groups, group (gstat_coff + n) / gstat_cpg (< 32), straight into the concat's accumulators        */
 } moca_gemm_params;
 
 /* Replaces F.conv2d 3x3 (openaimodel3d.py:152,177,66-70,96-106,376,531),
@@ -154,6 +164,9 @@ int moca_gemm_lnfold_ok(const moca_gemm_params* p);
 /* 1 when this call can run as MOCA_EP_TATTN (linear, K % 64 == 0, N % 192 == 0, T == 16, HW % 20 == 0, M % (16 HW) == 0,
  * no split-K / residual / row add); else 0 (the caller then runs the projection and moca_temporal_attention_f16).       */
 int moca_gemm_tattn_ok(const moca_gemm_params* p);
+/* 1 when this call (a2 / lda2 / k1 set) can read its A operand from two sources (see moca_gemm_params.a2); else 0 (the caller
+ * then materialises the concat with moca_concat_channels*_f16).                                                          */
+int moca_gemm_cat_ok(const moca_gemm_params* p);
 /* bytes of split-K workspace moca_gemm_f16 needs for (M,N,splits) */
 int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits);
 
@@ -186,6 +199,20 @@ int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gamma, const f
  * follows (openaimodel3d.py:149) is then one moca_groupnorm_gstat_f16 launch.                                        */
 int moca_concat_channels_gstat_f16(const void* a, const void* b, void* out, int32_t F, int32_t HW, int32_t C1, int32_t C2,
                                    int32_t frames_per_stat, int64_t* gstat, void* stream);
+/* The VIRTUAL torch.cat (openaimodel3d.py:571) in front of ResBlock.in_layers[0] (:149): GroupNorm(32)(+SiLU) of cat([a, b], channels),
+ * a [F*HW][C1], b [F*HW][C2], y [F*HW][C1+C2] -- the concatenated tensor itself is never written.  Statistics (per-frame or per
+ * frames_per_stat frames): gstat_cat i64 [F / frames_per_stat][32][2] in the CONCAT's grouping (groups of (C1+C2)/32 channels) holds
+ * the contribution of a (a MOCA_EP_GSTAT producer with gstat_cpg = (C1+C2)/32, or moca_gstat_accum_f16) and, when gstat_b is NULL,
+ * that of b as well; else gstat_b i64 [..][32][2] holds b's OWN finished statistics (groups of C2/32 channels: what b's producer
+ * left for b's other consumer) and they are merged here: needs ((C1+C2)/32) % (C2/32) == 0 and (C1 % ((C1+C2)/32)) % (C2/32) == 0.
+ * Fb (0 = F): gstat_b covers Fb frames and b is F / Fb copies of them (the skip connection out of the shared guidance prefix).   */
+int moca_groupnorm_gstat_cat_f16(const void* a, const void* b, void* y, const float* gamma, const float* beta,
+                                 const int64_t* gstat_cat, const int64_t* gstat_b, int32_t Fb, int32_t F, int32_t HW, int32_t C1,
+                                 int32_t C2, int32_t frames_per_stat, float eps, int32_t silu, void* stream);
+/* statistics only: adds the sums / sums of squares of x [F*HW][C] to gstat [F / frames_per_stat][32][2], channel c to group
+ * (coff + c) / cpg (< 32) -- the share of one source of a virtual concat whose producer could not leave them (zero before the launch) */
+int moca_gstat_accum_f16(const void* x, int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat, int32_t cpg, int32_t coff,
+                         int64_t* gstat, void* stream);
 /* zero `bytes` bytes at the 16-byte aligned `ptr` on the stream (the MOCA_EP_GSTAT accumulators of a forward are zeroed by one call) */
 int moca_memset_zero(void* ptr, int64_t bytes, void* stream);
 

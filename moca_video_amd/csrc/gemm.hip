@@ -25,6 +25,7 @@ struct no_t { static constexpr bool value = false; };
 
 constexpr int BM = 128;
 constexpr int BK = 64;
+constexpr int MOCA_A_LINEAR2 = 3;      // internal: MOCA_A_LINEAR with moca_gemm_params.a2 (two-source A = virtual torch.cat), staggered kernels only
 constexpr int ROW_BYTES = BK * 2;  // 128 B per LDS row
 
 struct Geo {
@@ -618,14 +619,21 @@ struct BGather {
     // The k range is walked tap-major (the packing order of W): all channels of tap 0, then tap 1, ...  A channel-major walk (the
     // nine taps of one 64-channel slice before the next slice, so that the taps hit L2) was measured in round 2: -8 % GEMM fabric
     // reads, +2-5 % on some convs in isolation, -0.4 % on the whole step (profiles/r02_ab_conv_channel_major.txt) -- removed.
+    // MOCA_A_LINEAR2 (internal: MOCA_A_LINEAR with p.a2): the virtual torch.cat([a, a2], channels) -- two "taps" of k1 / KS and
+    // (K - k1) / KS tiles; tap 0 walks the rows of a (row stride lda), tap 1 those of a2 (lda2).  The kernel switches the buffer
+    // descriptor with the tap (`tap` is block-uniform); k1 % 64 == 0, so a k-tile pair never straddles the sources.
     __device__ __forceinline__ BGather(const moca_gemm_params& p_, int lch_, int kt_begin, int kt_last_pair)
-        : p(p_), lch(lch_), tiles_per_tap(AMODE == MOCA_A_LINEAR ? (1 << 30) : p_.C / KS), kt_next(kt_begin), kt_last(kt_last_pair) {}
+        : p(p_), lch(lch_), tiles_per_tap(AMODE == MOCA_A_LINEAR ? (1 << 30) : (AMODE == MOCA_A_LINEAR2 ? p_.k1 / KS : p_.C / KS)),
+          kt_next(kt_begin), kt_last(kt_last_pair) {}
 
     __device__ __forceinline__ void init_row(int g, int m) {
         row_ok[g] = m < p.M;
         const int mm = row_ok[g] ? m : 0;
         if (AMODE == MOCA_A_LINEAR) {
             row_off[g] = (int64_t)mm * p.lda;
+            row_y[g] = row_x[g] = 0;
+        } else if (AMODE == MOCA_A_LINEAR2) {
+            row_off[g] = mm;
             row_y[g] = row_x[g] = 0;
         } else if (AMODE == MOCA_A_CONV3X3) {
             const int ohw = p.outH * p.outW;
@@ -659,6 +667,11 @@ struct BGather {
         if (AMODE == MOCA_A_LINEAR) {
 #pragma unroll
             for (int g = 0; g < NAP; ++g) a_off[g] = row_ok[g] ? (unsigned)((row_off[g] + lch * 8) * 2) : OOB_OFF;
+        } else if (AMODE == MOCA_A_LINEAR2) {
+            const int ld = t ? p.lda2 : p.lda;
+            if (t) tiles_per_tap = 1 << 30;                  // (the second source runs to the end of the k range)
+#pragma unroll
+            for (int g = 0; g < NAP; ++g) a_off[g] = row_ok[g] ? (unsigned)((row_off[g] * ld + lch * 8) * 2) : OOB_OFF;
         } else if (AMODE == MOCA_A_CONV3X3) {
             const int ky = p.up_phase ? t >> 1 : t / 3, kx = p.up_phase ? t & 1 : t - ky * 3;      // (up_phase: see AGather::set_tap)
             const int limH = p.up ? 2 * p.inH : p.inH, limW = p.up ? 2 * p.inW : p.inW;
@@ -682,7 +695,7 @@ struct BGather {
     // position the stream on the pair whose even tile is kt (one integer division, prologue only)
     __device__ __forceinline__ void seek(int kt) {
         kt_next = kt;
-        const int t = kt / tiles_per_tap;
+        const int t = AMODE == MOCA_A_LINEAR2 ? (kt >= tiles_per_tap ? 1 : 0) : kt / tiles_per_tap;
         tin = kt - t * tiles_per_tap;
         set_tap(t);
     }
@@ -812,6 +825,8 @@ __device__ __forceinline__ void store_fp16_tile_colsum_impl(const moca_gemm_para
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
     constexpr bool nt_out = NT;                        // (= out_streams(p), chosen by the wrapper below)
     const int ch = tid % CPR, rs = tid / CPR;
+    // (up_phase: rows scattered to the upsampled grid as in store_fp16_tile; a row tile of the low-resolution grid lies inside one frame)
+    const int upW = p.up_phase ? p.outW : 0, upC = p.up_phase ? 2 * p.outW * ((p.up_phase - 1) >> 1) + ((p.up_phase - 1) & 1) : 0;
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
@@ -845,7 +860,8 @@ __device__ __forceinline__ void store_fp16_tile_colsum_impl(const moca_gemm_para
                 half8v o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { o[j] = (half_t)v[j]; s[j] += v[j]; q[j] += v[j] * v[j]; }
-                st_out8(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col, o, nt_out);
+                const int64_t mo = upW ? 4 * (int64_t)m - 2 * (m % upW) + upC : m;
+                st_out8(reinterpret_cast<half_t*>(p.out) + mo * p.ldo + col, o, nt_out);
             }
         }
 #pragma unroll
@@ -872,11 +888,13 @@ __device__ __forceinline__ void store_fp16_tile_colsum_impl(const moca_gemm_para
             if (i < 2 * BNC) red[i] = a[h];
         }
         __syncthreads();
-        const int cpg = p.N / 32;
-        const int g0 = n0 / cpg, g1 = (n0 + BNC - 1) / cpg;
+        // (gstat_cpg / gstat_coff: this output is one source of a virtual concat and its columns are channels coff + n of the consumer's
+        //  tensor, whose groups are cpg wide -- a group at the seam is completed by the other source's producer)
+        const int cpg = p.gstat_cpg > 0 ? p.gstat_cpg : p.N / 32, coff = p.gstat_coff;
+        const int g0 = (coff + n0) / cpg, g1 = (coff + n0 + BNC - 1) / cpg;
         if (tid < 2 * (g1 - g0 + 1)) {
             const int g = g0 + (tid >> 1), comp = tid & 1;
-            const int c0 = max(g * cpg, n0) - n0, c1 = min((g + 1) * cpg, n0 + BNC) - n0;
+            const int c0 = max(g * cpg - coff, n0) - n0, c1 = min((g + 1) * cpg - coff, n0 + BNC) - n0;
             float t = 0.f;
             for (int c = c0; c < c1; ++c) t += red[c * 2 + comp];
             const int sg = m0 / p.gstat_rows;
@@ -2318,9 +2336,19 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         w_off[1] = (unsigned)(((int64_t)(n0 + (8 + wave) * 16 + lrow) * p.ldw + lch * 8) * 2);       // j = 1
         w_off[2] = (unsigned)(((int64_t)(n0 + (16 + (wave & 3)) * 16 + lrow) * p.ldw + lch * 8) * 2); // j = 2 (waves 0..3)
     }
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, OOB_OFF, 0x00020000);
+    // (two-source A, MOCA_A_LINEAR2: the A descriptor follows the gather's block-uniform source index -- `sync_src()` behind every
+    //  ga.seek() / ga.advance(); one scalar compare per k-tile pair, the other modes compile to the constant descriptors)
+    __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, OOB_OFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, OOB_OFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_f = (flex_is_big != WIDE) ? rsrc_a : rsrc_w;      // descriptor of this wave's j = 2 piece
+    __amdgpu_buffer_rsrc_t rsrc_f = (flex_is_big != WIDE) ? rsrc_a : rsrc_w;            // descriptor of this wave's j = 2 piece
+    auto sync_src = [&]() {
+        if constexpr (AMODE == MOCA_A_LINEAR2) {
+            if (ga.tap == 1) {
+                rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a2), 0, OOB_OFF, 0x00020000);
+                if (flex_is_big != WIDE) rsrc_f = rsrc_a;
+            }
+        }
+    };
 
     auto dma_piece = [&](int slot, int j, auto odd_tag) {
         constexpr int odd = decltype(odd_tag)::value;
@@ -2395,8 +2423,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     LnFoldRaw lraw = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
     if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, grow(tid), n0, tid);
     ga.seek(kt_begin);
+    sync_src();
     issue_pair(0, 1);
     ga.advance();
+    sync_src();
     issue_pair(2, 3);
     LnFoldRegs lf = {0.f, 0.f, 0.f, 0.f};
     if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, grow(tid), tid);
@@ -2492,6 +2522,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
 #endif
         // ---- LOADo ----
         ga.advance();
+        sync_src();
         issue_pair(sp, s0);
 #ifdef MOCA_STAMPS
         if (seg) MOCA_STAMP_W(13, SEG_WAVE);
@@ -3132,6 +3163,7 @@ static inline int64_t a_span_bytes(const moca_gemm_params& p) {
     return ((int64_t)p.M * p.C + 64) * 2;
 }
 static inline bool buffer_addressable(const moca_gemm_params& p) {
+    if (p.a2 && ((int64_t)p.M * p.lda2 + 64) * 2 >= (1ll << 31)) return false;
     return a_span_bytes(p) < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
 }
 
@@ -3196,6 +3228,7 @@ static inline bool takes_w80t_ln(const moca_gemm_params& p) {     // the 160 x 3
 
 int launch_gemm_w80_mode(const moca_gemm_params& p, hipStream_t st) {
     const bool wide = w80s_wide(p);
+    if (p.a2) return wide ? launch_gemm_w80s<MOCA_A_LINEAR2, 1>(p, st) : launch_gemm_w80s<MOCA_A_LINEAR2, 0>(p, st);
     if (p.a_mode == MOCA_A_LINEAR) return wide ? launch_gemm_w80s<MOCA_A_LINEAR, 1>(p, st) : launch_gemm_w80s<MOCA_A_LINEAR, 0>(p, st);
     if (p.a_mode == MOCA_A_CONV3X3) return wide ? launch_gemm_w80s<MOCA_A_CONV3X3, 1>(p, st) : launch_gemm_w80s<MOCA_A_CONV3X3, 0>(p, st);
     return wide ? launch_gemm_w80s<MOCA_A_TCONV3, 1>(p, st) : launch_gemm_w80s<MOCA_A_TCONV3, 0>(p, st);
@@ -3391,6 +3424,22 @@ extern "C" int moca_gemm_tattn_ok(const moca_gemm_params* pp) {
     return tattn_ok(p) ? 1 : 0;
 }
 
+// two-source A (the virtual torch.cat in front of a ResBlock's skip_connection): a plain linear on the staggered kernels, sources
+// split at a multiple of 64 columns, nothing but bias / residual / row add / row sums / GroupNorm statistics in the epilogue
+static bool cat_ok(const moca_gemm_params& p) {
+    if (!p.a2 || p.a_mode != MOCA_A_LINEAR || p.splits != 1) return false;
+    if (p.k1 <= 0 || p.k1 >= p.K || p.k1 % 64 || (p.K - p.k1) % 64 || p.lda % 8 || p.lda2 % 8 || p.lda < p.k1 || p.lda2 < p.K - p.k1) return false;
+    if (p.flags & ~(MOCA_EP_COLSUM | MOCA_EP_GSTAT | MOCA_EP_ROWSUM)) return false;
+    return takes_w80s(p);
+}
+extern "C" int moca_gemm_cat_ok(const moca_gemm_params* pp) {
+    if (!pp) return 0;
+    moca_gemm_params p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
+    normalise_splits(p);
+    return cat_ok(p) ? 1 : 0;
+}
+
 extern "C" int moca_gemm_rowsum_cols(const moca_gemm_params* pp) {
     if (!pp) return 0;
     moca_gemm_params p = *pp;
@@ -3445,7 +3494,9 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     if (p.up_phase && p.a_mode != MOCA_A_CONV3X3) return MOCA_E_BADARG;
     switch (p.a_mode) {
         case MOCA_A_LINEAR:
-            if (p.lda % 8 || p.lda < p.K) return MOCA_E_BADARG;
+            if (p.a2) {                               // ask moca_gemm_cat_ok() first
+                if (!cat_ok(p)) return MOCA_E_BADARG;
+            } else if (p.lda % 8 || p.lda < p.K) return MOCA_E_BADARG;
             break;
         case MOCA_A_CONV3X3:
             if (p.up_phase < 0 || p.up_phase > 4) return MOCA_E_BADARG;
@@ -3453,7 +3504,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
             // one phase of upsample + conv: a 2 x 2 conv on the low-resolution grid, rows scattered by the plain store loop of the
             // 256- / 320-row kernels (fast gather), nothing else in the epilogue
             if (p.up_phase && (p.stride != 1 || p.up || p.nopad_lo || p.splits != 1 || p.M <= 160 || !fast_gather(p) || p.residual || p.rowadd ||
-                               (p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_GSTAT | MOCA_EP_ROWSUM | MOCA_EP_LN | MOCA_EP_LNFOLD |
+                               (p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_ROWSUM | MOCA_EP_LN | MOCA_EP_LNFOLD |
                                           MOCA_EP_TATTN | MOCA_EP_GELU | MOCA_FORCE_SMALL_TILE)) || (p.N % 128 && p.N % 160))) return MOCA_E_BADARG;
             if (p.stride != 1 && p.stride != 2) return MOCA_E_BADARG;
             if (p.nopad_lo != 0 && (p.nopad_lo != 1 || p.stride != 2 || p.up || (p.inH | p.inW) & 1)) return MOCA_E_BADARG;
@@ -3468,6 +3519,8 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
         default:
             return MOCA_E_BADARG;
     }
+    if (p.a2 && p.a_mode != MOCA_A_LINEAR) return MOCA_E_BADARG;
+    if (p.gstat_cpg < 0 || p.gstat_coff < 0 || ((p.gstat_cpg || p.gstat_coff) && !(p.flags & MOCA_EP_GSTAT))) return MOCA_E_BADARG;
     hipStream_t st = moca_stream(stream);
     const bool wide = (p.N % 128 == 0);
     int rc;
@@ -3487,7 +3540,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     if (p.flags & MOCA_EP_GSTAT) {                    // same kernels as MOCA_EP_COLSUM; a row tile must lie inside one statistics group
         const int rows = colsum_rows(p);
         if (!(p.gstat && rows != 0 && !(p.flags & MOCA_EP_COLSUM) && p.gstat_rows > 0 && p.gstat_rows % rows == 0 && p.M % p.gstat_rows == 0 &&
-              p.N % 32 == 0)) return MOCA_E_BADARG;
+              (p.gstat_cpg > 0 ? (p.gstat_coff + p.N - 1) / p.gstat_cpg < 32 : (p.N % 32 == 0 && p.gstat_coff == 0)))) return MOCA_E_BADARG;
     }
     if ((p.flags & MOCA_EP_ROWSUM) && !(p.rowsum && rowsum_cols(p) != 0)) return MOCA_E_BADARG;             // ask moca_gemm_rowsum_cols() first
     p.reserved4_ = 0;                                 // (bits 8.. carry the XCD partition chosen by the launcher)
@@ -3498,7 +3551,9 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
         return launch_gemm_w80s<MOCA_A_LINEAR, 3>(p, st);
     }
     if ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1 && lnfold_ok(p))) return MOCA_E_BADARG;   // ask moca_gemm_lnfold_ok() first
-    if (takes_sqp(p)) {
+    if (p.a2) {                                       // (cat_ok: a staggered-kernel call)
+        rc = launch_gemm_w80_mode(p, st);
+    } else if (takes_sqp(p)) {
         rc = (p.flags & MOCA_EP_GEGLU) ? launch_gemm_sqp<true>(p, st) : launch_gemm_sqp<false>(p, st);
     } else if (takes_g4p(p)) {
         rc = (p.flags & MOCA_EP_GEGLU) ? launch_gemm_g4p<true>(p, st) : launch_gemm_g4p<false>(p, st);

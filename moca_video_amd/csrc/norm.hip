@@ -310,6 +310,134 @@ __global__ void concat_gstat_kernel(const half_t* __restrict__ a, const half_t* 
     }
 }
 
+// ---- the VIRTUAL torch.cat (openaimodel3d.py:571) in front of ResBlock.in_layers[0]: GroupNorm(+SiLU) of cat([a, b], channels) reading a
+// and b where their producers left them; only the normalised concat is written.  Thread cx owns 8 channels of the concatenated row (C1 % 8
+// == 0: from one source), as in concat_gstat_kernel.  Statistics: gstat_cat (the concat's grouping) holds a's share -- accumulated by a's
+// producer (MOCA_EP_GSTAT with gstat_cpg = C / 32) or by gstat_accum_kernel -- and either b's share too (gstat_b == NULL) or b's OWN
+// finished statistics are merged here (groups of cpg2 = C2 / 32 channels: cpg % cpg2 == 0 and (C1 % cpg) % cpg2 == 0, host-checked, so
+// every group of b lies inside one group of the concat). ----
+template <bool STREAM>
+__global__ void gn_apply_gstat_cat_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, half_t* __restrict__ y,
+                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          const int64_t* __restrict__ gstat_cat, const int64_t* __restrict__ gstat_b,
+                                          int HW, int C1, int C2, int nchunk, int frames_per_stat, int sgb_mod, double inv_count, float eps, int silu) {
+    __shared__ float s_mr[2 * GN_GROUPS];
+    const int C = C1 + C2;
+    const int f = blockIdx.x, chunk = blockIdx.y;
+    const int cx = threadIdx.x, py = threadIdx.y, ppb = blockDim.y;
+    const int tid = py * blockDim.x + cx;
+    const int pc = (HW + nchunk - 1) / nchunk;
+    const int p_begin = chunk * pc, p_end = min(p_begin + pc, HW);
+    if (p_begin >= p_end) return;
+    const int cpg = C / GN_GROUPS;
+    const int sg = f / frames_per_stat;
+    const bool from_a = cx * 8 < C1;
+    const half_t* src = from_a ? a + ((int64_t)f * HW) * C1 + cx * 8 : b + ((int64_t)f * HW) * C2 + (cx * 8 - C1);
+    const int ld = from_a ? C1 : C2;
+    const int64_t off = ((int64_t)f * HW) * C + cx * 8;
+    auto load4 = [&](half8v (&v)[4], int pp) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8v*>(src + (int64_t)min(pp + u * ppb, p_end - 1) * ld);
+    };
+    int pp = p_begin + py;
+    half8v cur[4], nxt[4];
+    load4(cur, pp);
+    if (tid < GN_GROUPS) {
+        const int64_t* ga = gstat_cat + ((int64_t)sg * GN_GROUPS + tid) * 2;
+        double sa = moca_gstat_get(ga, 0), sq = moca_gstat_get(ga + 1, 1);
+        if (gstat_b) {
+            const int cpg2 = C2 / GN_GROUPS;
+            const int lo = max(tid * cpg - C1, 0), hi = min((tid + 1) * cpg - C1, C2);     // b's channels inside concat group tid
+            for (int j = lo / cpg2; j * cpg2 < hi; ++j) {
+                const int64_t* gb = gstat_b + ((int64_t)(sg % sgb_mod) * GN_GROUPS + j) * 2;   // (b = `reps` copies of Fb frames: the shared prefix)
+                sa += moca_gstat_get(gb, 0); sq += moca_gstat_get(gb + 1, 1);
+            }
+        }
+        const double mean = sa * inv_count;
+        double var = sq * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mr[2 * tid] = (float)mean;
+        s_mr[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cx * 8 + j;
+        const int g = c / cpg;
+        sc[j] = s_mr[2 * g + 1] * gamma[c];
+        sh[j] = beta[c] - s_mr[2 * g] * sc[j];
+    }
+    auto norm8 = [&](const half8v& v) {
+        half8v o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = (float)v[j] * sc[j] + sh[j];
+            if (silu) t = moca_silu(t);
+            o[j] = (half_t)t;
+        }
+        return o;
+    };
+    for (; pp < p_end; pp += 4 * ppb) {
+        const bool more = pp + 4 * ppb < p_end;
+        if (more) load4(nxt, pp + 4 * ppb);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (pp + u * ppb < p_end) gn_st8<STREAM>(y + off + (int64_t)(pp + u * ppb) * C, norm8(cur[u]));
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+        }
+    }
+}
+
+// ---- statistics only: the share of ONE source x [F][HW][C] of a virtual concat in the concat's GroupNorm statistics, for a source whose
+// producer could not leave them (an `Upsample`, the repeat of the shared prefix): channel c counts for group (coff + c) / cpg of
+// gstat [statistics group][32][2].  A read-only pass (half the traffic of the copy it replaces); accumulation as concat_gstat_kernel. ----
+__global__ void gstat_accum_kernel(const half_t* __restrict__ x, int64_t* __restrict__ gstat, int HW, int C, int nchunk,
+                                   int frames_per_stat, int cpg, int coff) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* s_sum = reinterpret_cast<float*>(smem_raw);   // [ppb][C]
+    float* s_sq = s_sum + blockDim.y * C;                 // [ppb][C]
+    const int f = blockIdx.x, chunk = blockIdx.y;
+    const int cx = threadIdx.x, py = threadIdx.y, ppb = blockDim.y;
+    const int pc = (HW + nchunk - 1) / nchunk;
+    const int p_begin = chunk * pc, p_end = min(p_begin + pc, HW);
+    const half_t* src = x + ((int64_t)f * HW) * C + cx * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    int pp = p_begin + py;
+    for (; pp + 3 * ppb < p_end; pp += 4 * ppb) {
+        half8v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8v*>(src + (int64_t)(pp + u * ppb) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float t = (float)v[u][j]; s[j] += t; q[j] += t * t; }
+    }
+    for (; pp < p_end; pp += ppb) {
+        const half8v v = *reinterpret_cast<const half8v*>(src + (int64_t)pp * C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = (float)v[j]; s[j] += t; q[j] += t * t; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s_sum[py * C + cx * 8 + j] = s[j]; s_sq[py * C + cx * 8 + j] = q[j]; }
+    __syncthreads();
+    const int tid = py * blockDim.x + cx;
+    const int g0 = coff / cpg, g1 = (coff + C - 1) / cpg;
+    if (tid < 2 * (g1 - g0 + 1)) {
+        const int g = g0 + (tid >> 1), comp = tid & 1;
+        const int c0 = max(g * cpg - coff, 0), c1 = min((g + 1) * cpg - coff, C);
+        const float* base = comp ? s_sq : s_sum;
+        float t = 0.f;
+        for (int yy = 0; yy < ppb; ++yy)
+            for (int c = c0; c < c1; ++c) t += base[yy * C + c];
+        moca_gstat_add(gstat + ((int64_t)(f / frames_per_stat) * GN_GROUPS + g) * 2 + comp, comp, t);
+    }
+}
+
 // ---- single-launch GroupNorm for small tensors ------------------------------------
 // A statistics slab = (statistics group sg, channel group g): R = frames_per_stat*HW consecutive rows x cpg channels.
 // S blocks share one slab: each of them reduces the WHOLE slab (redundantly -- a slab is at most a few hundred KB and
@@ -661,6 +789,53 @@ extern "C" int moca_concat_channels_gstat_f16(const void* a, const void* b, void
     hipLaunchKernelGGL(streams ? concat_gstat_kernel<true> : concat_gstat_kernel<false>, dim3(F, nchunk), dim3(nch8, ppb), lds, moca_stream(stream),
                        reinterpret_cast<const half_t*>(a), reinterpret_cast<const half_t*>(b), reinterpret_cast<half_t*>(out), gstat, HW, C1, C2,
                        nchunk, frames_per_stat);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_groupnorm_gstat_cat_f16(const void* a, const void* b, void* y, const float* gamma, const float* beta,
+                                            const int64_t* gstat_cat, const int64_t* gstat_b, int32_t Fb, int32_t F, int32_t HW, int32_t C1,
+                                            int32_t C2, int32_t frames_per_stat, float eps, int32_t silu, void* stream) {
+    if (!a || !b || !y || !gamma || !beta || !gstat_cat) return MOCA_E_BADARG;
+    if (Fb <= 0) Fb = F;
+    if (Fb > F || F % Fb || Fb % frames_per_stat) return MOCA_E_BADARG;
+    if (F <= 0 || HW <= 0 || C1 <= 0 || C2 <= 0 || C1 % 8 || C2 % 8 || frames_per_stat <= 0 || F % frames_per_stat) return MOCA_E_BADARG;
+    const int C = C1 + C2;
+    if (C % GN_GROUPS) return MOCA_E_BADARG;
+    if (gstat_b) {                                                       // b's own groups must nest in the concat's
+        const int cpg = C / GN_GROUPS, cpg2 = C2 / GN_GROUPS;
+        if (C2 % GN_GROUPS || cpg % cpg2 || (C1 % cpg) % cpg2) return MOCA_E_BADARG;
+    }
+    const int nch8 = C / 8;
+    if (nch8 > 1024) return MOCA_E_BADARG;
+    int ppb = 256 / nch8;
+    if (ppb < 1) ppb = 1;
+    if (nch8 * ppb < GN_GROUPS) return MOCA_E_BADARG;
+    const int nchunk = gn_nchunk(F, HW);
+    const double inv_count = 1.0 / ((double)frames_per_stat * HW * (C / GN_GROUPS));
+    const dim3 grid(F, nchunk), block(nch8, ppb);
+    const bool streams = (int64_t)F * HW * C * 2 >= (128ll << 20);
+    hipLaunchKernelGGL(streams ? gn_apply_gstat_cat_kernel<true> : gn_apply_gstat_cat_kernel<false>, grid, block, 0, moca_stream(stream),
+                       reinterpret_cast<const half_t*>(a), reinterpret_cast<const half_t*>(b), reinterpret_cast<half_t*>(y), gamma, beta,
+                       gstat_cat, gstat_b, HW, C1, C2, nchunk, frames_per_stat, Fb / frames_per_stat, inv_count, eps, silu);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
+extern "C" int moca_gstat_accum_f16(const void* x, int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat, int32_t cpg, int32_t coff,
+                                    int64_t* gstat, void* stream) {
+    if (!x || !gstat || F <= 0 || HW <= 0 || C <= 0 || C % 8 || frames_per_stat <= 0 || F % frames_per_stat) return MOCA_E_BADARG;
+    if (cpg <= 0 || coff < 0 || (coff + C - 1) / cpg >= GN_GROUPS) return MOCA_E_BADARG;
+    const int nch8 = C / 8;
+    if (nch8 > 1024) return MOCA_E_BADARG;
+    int ppb = 256 / nch8;
+    if (ppb < 1) ppb = 1;
+    if (nch8 * ppb < 2 * ((coff + C - 1) / cpg - coff / cpg + 1)) return MOCA_E_BADARG;
+    const int nchunk = gn_nchunk(F, HW);
+    const size_t lds = (size_t)ppb * C * 2 * sizeof(float);
+    if (lds > 64 * 1024) return MOCA_E_BADARG;
+    hipLaunchKernelGGL(gstat_accum_kernel, dim3(F, nchunk), dim3(nch8, ppb), lds, moca_stream(stream),
+                       reinterpret_cast<const half_t*>(x), gstat, HW, C, nchunk, frames_per_stat, cpg, coff);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

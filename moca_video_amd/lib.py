@@ -49,6 +49,7 @@ class GemmParams(C.Structure):
         ("lnf_nparts", C.c_int32), ("reserved2_", C.c_int32),
         ("gstat", C.c_void_p), ("gstat_rows", C.c_int32), ("tattn_scale", C.c_float),
         ("prefetch", C.c_void_p), ("up_phase", C.c_int32), ("reserved4_", C.c_int32),
+        ("a2", C.c_void_p), ("lda2", C.c_int32), ("k1", C.c_int32), ("gstat_cpg", C.c_int32), ("gstat_coff", C.c_int32),
     ]
 
 
@@ -81,6 +82,9 @@ SIGNATURES = {
     "moca_gemm_rowsum_cols": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_lnfold_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_tattn_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "moca_gemm_cat_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "moca_groupnorm_gstat_cat_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "moca_gstat_accum_f16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "moca_groupnorm_colsum_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "moca_groupnorm_nhwc_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "moca_groupnorm_ws_bytes": (_i64, [_i32, _i32, _i32]),

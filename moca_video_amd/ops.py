@@ -155,9 +155,11 @@ def finish_lnfold(pw: PackedWeight) -> PackedWeight:
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
                  residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None,
-                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, up_phase=0, prefetch=None):
+                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, up_phase=0, prefetch=None, a2=None):
     p = _l.GemmParams()
     p.up_phase = up_phase
+    if a2 is not None:                       # (second A source fp16 [M][lda2], columns of `a`): A = the virtual cat([a, a2], channels)
+        p.a2, p.lda2, p.k1 = a2[0].data_ptr(), a2[0].stride(-2), a2[1]
     if prefetch is not None:                 # tensor the launch's spare blocks stream into the memory-side cache (the NEXT heavy launch's weights)
         p.prefetch, p.prefetch_kib = prefetch.data_ptr(), (prefetch.numel() * prefetch.element_size()) >> 10
     p.a, p.w, p.out = a.data_ptr(), pw.w.data_ptr(), (out.data_ptr() if out is not None else None)
@@ -194,10 +196,12 @@ def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR
     if tattn is not None:                    # (T, HW, softmax scale): projection + temporal attention in one launch (MOCA_EP_TATTN)
         p.flags |= _l.MOCA_EP_TATTN
         p.T, p.HW, p.tattn_scale = tattn
-    if gstat is not None:                    # (i64 [M / rows][32][2] fixed-point accumulators, zeroed before the launch; rows per statistics group)
-        p.flags |= _l.MOCA_EP_GSTAT
+    if gstat is not None:                    # (i64 [M / rows][32][2] fixed-point accumulators, zeroed before the launch; rows per statistics group
+        p.flags |= _l.MOCA_EP_GSTAT         #  [, columns per channel group, channel of column 0]: one source of a virtual concat)
         p.gstat = gstat[0].data_ptr()
         p.gstat_rows = gstat[1]
+        if len(gstat) > 2:
+            p.gstat_cpg, p.gstat_coff = gstat[2], gstat[3]
     if lnfold is not None:                   # (row partials f32 [nparts][M][2] or None when only probing, nparts, eps); pw.wsum required
         p.flags |= _l.MOCA_EP_LNFOLD
         p.lnf_part = lnfold[0].data_ptr() if lnfold[0] is not None else None
@@ -253,6 +257,12 @@ def pack_qkv_per_head(wq, wk, wv, heads, bias=None, device="cuda"):
     return _finish(w, b, device)
 
 
+def gemm_cat_ok(a, pw: PackedWeight, **kw):
+    """can this linear read its A operand from two sources (a2 = (second source, columns of the first): the virtual torch.cat)?"""
+    p = _gemm_params(a, pw, None, **kw)
+    return bool(_l.load().moca_gemm_cat_ok(C.byref(p)))
+
+
 def gemm_colsum_rows(a, pw: PackedWeight, **kw):
     """rows per row tile of the MOCA_EP_COLSUM output of this call, 0 if it cannot produce column sums"""
     p = _gemm_params(a, pw, None, **kw)
@@ -285,6 +295,22 @@ def concat_channels_gstat(a, b, out, gstat, *, F, HW, C1, C2, frames_per_stat):
     _l.check(_l.load().moca_concat_channels_gstat_f16(_l.ptr(a), _l.ptr(b), _l.ptr(out), F, HW, C1, C2, frames_per_stat,
                                                       _l.ptr(gstat), _st()), "moca_concat_channels_gstat_f16")
     return out
+
+
+def groupnorm_gstat_cat(a, b, y, gamma, beta, gstat_cat, gstat_b, *, F, HW, C1, C2, frames_per_stat, eps, silu, Fb=0):
+    """GroupNorm(+SiLU) of the virtual cat([a, b], channels): statistics from gstat_cat (the concat's grouping) [+ b's own gstat_b,
+    which covers Fb frames when b is F / Fb copies of them]"""
+    _l.check(_l.load().moca_groupnorm_gstat_cat_f16(_l.ptr(a), _l.ptr(b), _l.ptr(y), _l.ptr(gamma), _l.ptr(beta), _l.ptr(gstat_cat),
+                                                    _l.ptr(gstat_b) if gstat_b is not None else None, Fb, F, HW, C1, C2, frames_per_stat,
+                                                    eps, 1 if silu else 0, _st()), "moca_groupnorm_gstat_cat_f16")
+    return y
+
+
+def gstat_accum(x, gstat, *, F, HW, Cn, frames_per_stat, cpg, coff):
+    """statistics only: x's share of a virtual concat's GroupNorm statistics (channel c -> group (coff + c) / cpg)"""
+    _l.check(_l.load().moca_gstat_accum_f16(_l.ptr(x), F, HW, Cn, frames_per_stat, cpg, coff, _l.ptr(gstat), _st()),
+             "moca_gstat_accum_f16")
+    return gstat
 
 
 def memset_zero(t):

@@ -20,7 +20,7 @@ import torch
 
 from . import lib as _l
 from . import ops
-from .unet import (_BasicTransformerBlock, _Downsample, _FMap, _Pool, _ResBlock, _SpatialTransformer,
+from .unet import (_BasicTransformerBlock, _CatMap, _Downsample, _FMap, _Pool, _ResBlock, _SpatialTransformer,
                    _TemporalTransformer, _Upsample)
 
 N_CU = 256
@@ -59,6 +59,8 @@ def gemm_splits(M, pw):
 # the environment variables exist for such A/B runs only)
 PREFETCH_MIN_BYTES = int(float(os.environ.get("MOCA_PREFETCH_MIN_MB", "4")) * (1 << 20))
 PREFETCH_HOST_FLOP = float(os.environ.get("MOCA_PREFETCH_HOST_GF", "50")) * 1e9
+# virtual torch.cat in the output blocks (A/B switch: MOCA_VCAT=0 materialises every concat as before round 5)
+VIRTUAL_CAT = os.environ.get("MOCA_VCAT", "1") != "0"
 
 
 class _LNRef:
@@ -189,11 +191,19 @@ class _PlanBase:
         if phases is None or M < 5120 or self._splits(M, phases[0]) != 1:       # (below: split-k per phase costs more than it saves)
             return self.conv(fm, self.P[id(conv)], up=1)
         out = self.pool.get(4 * M, phases[0].N)
+        kw = dict(M=M, mode=_l.MOCA_A_CONV3X3, conv=(fm.C, fm.H, fm.W, fm.H, fm.W, 1, 0), splits=1)
+        idx = []
         for ph, pw in enumerate(phases):
             self._note_gemm(pw)
-            self._emit(ops.gemm, fm.buf, pw, out, M=M, mode=_l.MOCA_A_CONV3X3, conv=(fm.C, fm.H, fm.W, fm.H, fm.W, 1, 0), splits=1,
-                       up_phase=ph + 1)
-        return _FMap(out, fm.F, fm.H * 2, fm.W * 2, phases[0].N, None)
+            idx.append(len(self.steps))
+            self._emit(ops.gemm, fm.buf, pw, out, up_phase=ph + 1, **kw)
+        up = _FMap(out, fm.F, fm.H * 2, fm.W * 2, phases[0].N, None)
+        # the four launches can leave GroupNorm statistics of the upsampled map behind (a consumer that is a virtual concat re-targets
+        # them): a row tile of the LOW-resolution grid lies inside one frame
+        up.cs_rows = ops.gemm_colsum_rows(fm.buf, phases[0], **kw)
+        if up.cs_rows > 0:
+            up.src = tuple(idx)
+        return up
 
     def tconv(self, fm, pw, residual=None):
         out, cs = self._gemm(fm.buf, pw, fm.M, mode=_l.MOCA_A_TCONV3, tconv=(fm.C, self.T, fm.H * fm.W), residual=residual,
@@ -203,6 +213,12 @@ class _PlanBase:
     def gn(self, fm, gb, *, fps, eps, silu):
         """GroupNorm(32) (+SiLU).  With `fm.colsum` (left by the producing GEMM) and row tiles that do not straddle frames the
         statistics pass over x disappears: finalize-from-column-sums + apply; otherwise the three-launch / slab path."""
+        if isinstance(fm, _CatMap):                            # the virtual concat: both sources read in place, statistics finished
+            y = self.pool.get(fm.M, fm.C)
+            self._emit(ops.groupnorm_gstat_cat, fm.h.buf, fm.skip.buf, y, gb[0], gb[1], fm.gcat, fm.gb, F=fm.F, HW=fm.H * fm.W,
+                       C1=fm.h.C, C2=fm.skip.C, frames_per_stat=fps, eps=eps, silu=silu, Fb=fm.Fb)
+            assert fps == 1
+            return y
         y = self.pool.get(fm.M, fm.C)
         HW = fm.H * fm.W
         ws = self.pool.get(1, ops.groupnorm_ws_floats(fm.F, HW, fm.C), torch.float32)
@@ -221,6 +237,7 @@ class _PlanBase:
             self.steps[fm.src] = functools.partial(prod.func, *prod.args, **kw)
             self.pool.put(cs[0])
             fm.colsum = None
+            fm.gstat_own = (slot, fps)
             self._emit(ops.groupnorm_gstat, fm.buf, y, gb[0], gb[1], slot, F=fm.F, HW=HW, Cn=fm.C, frames_per_stat=fps,
                        eps=eps, silu=silu)
         elif cs is not None and (fps * HW) % cs[1] == 0:      # no row tile straddles two statistics groups
@@ -342,11 +359,16 @@ class _Plan(_PlanBase):
         self._drop_colsum(h1)
         if isinstance(mod.skip_connection, torch.nn.Identity):
             sk = x.buf
+        elif isinstance(x, _CatMap):                             # 1x1 conv over the virtual concat: two A sources, split at h's channels
+            pw = P[id(mod.skip_connection)]
+            sk = self.pool.get(x.M, pw.N)
+            self._note_gemm(pw)
+            self._emit(ops.gemm, x.h.buf, pw, sk, M=x.M, lda=x.h.buf.stride(-2), splits=1, a2=(x.skip.buf, x.h.C))
         else:
             sk = self.linear(x.buf, x.M, P[id(mod.skip_connection)])
         h2 = self.conv(_FMap(g2, x.F, x.H, x.W, mod.cout), P[id(mod.out_layers[3])], residual=sk)
         self._release(g2)
-        if sk is not x.buf:
+        if isinstance(x, _CatMap) or sk is not x.buf:
             self._release(sk)
         if not mod.use_temporal_conv:
             return h2
@@ -594,8 +616,11 @@ class _Plan(_PlanBase):
                 nh = self.upconv(h, layer.conv)
             else:
                 raise TypeError(type(layer))
-            self._release(h.buf)
-            self._drop_colsum(h)
+            if isinstance(h, _CatMap):
+                self._release(h.h.buf, h.skip.buf)
+            else:
+                self._release(h.buf)
+                self._drop_colsum(h)
             h = nh
         return h
 
@@ -656,7 +681,14 @@ class _Plan(_PlanBase):
                 wide = self._expand(skip.buf, skip.M, skip.C)
                 self._drop_colsum(skip)
                 self._release(skip.buf)
+                own, own_F = skip.gstat_own, skip.F
                 skip = _FMap(wide, h.F, skip.H, skip.W, skip.C)
+                skip.gstat_own, skip.own_F = own, own_F          # (the copies share the statistics of the frames they repeat)
+            vc = self._virtual_cat(module, h, skip)
+            if vc is not None:
+                self._pinned.discard(skip.buf.data_ptr())
+                h = self.run_seq(module, vc)                     # (run_seq releases h.buf and skip.buf behind the ResBlock)
+                continue
             cat = self.pool.get(h.M, h.C + skip.C)
             gst = None
             Cc = h.C + skip.C
@@ -681,6 +713,58 @@ class _Plan(_PlanBase):
         self._emit(ops.nhwc_to_ncthw, o.buf, o.C, self.out, B=B, Cout=m.out_channels, T=T, HW=H * W)
         self._release(o.buf)
         self._finish_prefetch()
+
+    def _virtual_cat(self, module, h, skip):
+        """torch.cat([h, skip], dim=1) (openaimodel3d.py:571) WITHOUT the copy, where both consumers can read two sources: the
+        ResBlock's in_layers GroupNorm (moca_groupnorm_gstat_cat_f16) and its skip_connection 1x1 conv (moca_gemm_params.a2, the
+        staggered kernels: the 320- / 640-channel levels).  The statistics of the concat's 32 groups come from the producers: h's
+        last GEMM is re-targeted to accumulate ITS share in the concat's grouping (gstat_cpg); skip's share is its own finished
+        per-frame statistics when its producer already left them for the input path (merged by the GroupNorm), else its producer
+        is re-targeted likewise; a source without such a producer (an `Upsample`, the repeat that ends the shared prefix) gets a
+        read-only statistics pass.  Returns a _CatMap, or None (the caller materialises the concat)."""
+        if not VIRTUAL_CAT or not isinstance(module[0], _ResBlock) or isinstance(module[0].skip_connection, torch.nn.Identity):
+            return None
+        Cc, HW = h.C + skip.C, h.H * h.W
+        if Cc % 32 or h.C % 64 or skip.C % 64 or Cc // 8 > 1024 or h.F != skip.F:
+            return None
+        pw = self.P[id(module[0].skip_connection)]
+        if self._splits(h.M, pw) != 1 or not ops.gemm_cat_ok(h.buf, pw, M=h.M, lda=h.buf.stride(-2), splits=1, a2=(skip.buf, h.C)):
+            return None
+        gw = Cc // 32
+        slot = self._gstat_slot(h.F * 64)
+
+        def retarget(fm, coff):
+            """fm's producer accumulates fm's share of the concat's per-frame statistics (a row tile must lie inside one frame)"""
+            rows = fm.colsum[1] if fm.colsum is not None else fm.cs_rows
+            phases = isinstance(fm.src, tuple)                   # an `Upsample` as four 2 x 2 convs on the low-resolution grid
+            grp = HW // 4 if phases else HW                     # GEMM rows per frame
+            if fm.src is None or rows <= 0 or grp % rows or fm.gstat_own is not None or fm.cs_used:
+                return False
+            for i in (fm.src if phases else (fm.src,)):
+                prod = self.steps[i]
+                kw = dict(prod.keywords)
+                if kw.get("gstat") is not None or kw.get("rowsum") is not None:
+                    return False
+                kw["colsum"] = None
+                kw["gstat"] = (slot, grp, gw, coff)
+                self.steps[i] = functools.partial(prod.func, *prod.args, **kw)
+            if fm.colsum is not None:
+                self.pool.put(fm.colsum[0])
+                fm.colsum = None
+            fm.src = None
+            return True
+
+        if not retarget(h, 0):
+            self._drop_colsum(h)
+            self._emit(ops.gstat_accum, h.buf, slot, F=h.F, HW=HW, Cn=h.C, frames_per_stat=1, cpg=gw, coff=0)
+        gb, Fb = None, 0
+        cpg2 = skip.C // 32
+        if skip.gstat_own is not None and skip.gstat_own[1] == 1 and skip.C % 32 == 0 and gw % cpg2 == 0 and (h.C % gw) % cpg2 == 0:
+            gb, Fb = skip.gstat_own[0], skip.own_F
+        elif not retarget(skip, h.C):
+            self._drop_colsum(skip)
+            self._emit(ops.gstat_accum, skip.buf, slot, F=skip.F, HW=HW, Cn=skip.C, frames_per_stat=1, cpg=gw, coff=h.C)
+        return _CatMap(h, skip, slot, gb, Fb)
 
     def set_context(self, context):
         """context [B, L, D], or one [n_i, L_i, D] tensor per segment"""

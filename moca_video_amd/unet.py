@@ -180,17 +180,36 @@ class _Pool:
 class _FMap:
     """channels-last feature map: buf [F*H*W][C] fp16; `colsum` = (f32 [row tiles][C][2] buffer, rows per tile) when the
     GEMM that produced it also left per-(row tile, channel) sums and sums of squares behind (GroupNorm statistics)"""
-    __slots__ = ("buf", "F", "H", "W", "C", "colsum", "src", "gstat", "cs_used")
+    __slots__ = ("buf", "F", "H", "W", "C", "colsum", "src", "gstat", "cs_used", "cs_rows", "gstat_own", "own_F")
 
     def __init__(self, buf, F, H, W, C, colsum=None, src=None, gstat=None):
         self.buf, self.F, self.H, self.W, self.C, self.colsum = buf, F, H, W, C, colsum
         self.src = src          # index of the recorded GEMM launch that produced buf (with colsum): plan.gn() may re-target it
         self.gstat = gstat      # (f64 accumulators, frames_per_stat) when the producer already accumulated finished statistics
         self.cs_used = False    # a GroupNorm consumed the column sums (else the producer is re-recorded without them)
+        self.cs_rows = colsum[1] if colsum is not None else 0   # rows per tile of the producer's statistics epilogue (kept when colsum is dropped)
+        self.gstat_own = None   # (accumulators, frames_per_stat): the producer was re-targeted to FINISHED statistics of this map (32 groups of C / 32)
+        self.own_F = 0          # > 0: gstat_own covers own_F frames and buf is F / own_F copies of them (the repeat that ends the shared prefix)
 
     @property
     def M(self):
         return self.F * self.H * self.W
+
+
+class _CatMap:
+    """the VIRTUAL torch.cat([h, skip], dim=channels) of openaimodel3d.py:571: never materialised -- its two consumers (ResBlock.in_layers[0]
+    and ResBlock.skip_connection, :149,190-195) read h and skip where their producers left them.  `gcat` = statistics accumulators in the
+    concat's grouping (h's share, and skip's unless `gb` = skip's own finished statistics is merged by the GroupNorm)"""
+    __slots__ = ("h", "skip", "gcat", "gb", "Fb")
+
+    def __init__(self, h, skip, gcat, gb, Fb=0):
+        self.h, self.skip, self.gcat, self.gb, self.Fb = h, skip, gcat, gb, Fb
+
+    F = property(lambda self: self.h.F)
+    H = property(lambda self: self.h.H)
+    W = property(lambda self: self.h.W)
+    C = property(lambda self: self.h.C + self.skip.C)
+    M = property(lambda self: self.h.M)
 
 
 

@@ -418,7 +418,8 @@ def test_gemm_random_sweep_forced_kernels(kernel, env, tune):
 
 # ---------------------------------------------------------------- Upsample as four 2x2 phase convs
 @pytest.mark.parametrize("Fr,H,W,C,N", [(32, 10, 16, 1280, 1280),      # the 1280-channel Upsample of the B=2 forward (256-row kernel)
-                                        (8, 20, 32, 640, 640),         # 640 channels (320 x 160 tiles)
+                                        (8, 20, 32, 640, 640),         # 640 channels
+                                        (32, 20, 32, 640, 640),        # the 640-channel Upsample of the B=2 forward (320 x 160 tiles: statistics epilogue)
                                         (3, 7, 9, 64, 320), (5, 6, 11, 128, 256)])   # odd grids, M tails
 def test_gemm_upconv_phases(Fr, H, W, C, N):
     """nearest x2 + conv3x3 (openaimodel3d.py:96-106) as four 2x2 convs on the low-resolution grid with pre-summed taps
@@ -437,6 +438,22 @@ def test_gemm_upconv_phases(Fr, H, W, C, N):
     one = torch.empty_like(out)
     ops.gemm(a, ops.pack_conv3x3(w, b), one, M=4 * M, mode=L.MOCA_A_CONV3X3, conv=(C, H, W, 2 * H, 2 * W, 1, 1))
     check(out, one.float(), TOL16, "phases vs the 3x3 conv with the upsampling gather")
+    # the four launches accumulating the per-frame GroupNorm statistics of the upsampled map, as one source of a virtual concat
+    # (groups of `gw` channels starting at channel `coff`): same outputs, statistics = those of the values stored
+    rows = ops.gemm_colsum_rows(a, ops.pack_upconv_phases(w, b)[0], M=M, mode=L.MOCA_A_CONV3X3, conv=(C, H, W, H, W, 1, 0))
+    if rows > 0 and (H * W) % rows == 0:
+        gw, coff = (N + 320) // 32, 0
+        gst = torch.zeros(Fr * 64, dtype=torch.int64, device=DEV)
+        out2 = torch.full_like(out, float("nan"))
+        for ph, pw in enumerate(ops.pack_upconv_phases(w, b)):
+            ops.gemm(a, pw, out2, M=M, mode=L.MOCA_A_CONV3X3, conv=(C, H, W, H, W, 1, 0), up_phase=ph + 1, gstat=(gst, H * W, gw, coff))
+        assert torch.equal(out2, out)
+        acc = torch.zeros_like(gst)
+        ops.gstat_accum(out, acc, F=Fr, HW=4 * H * W, Cn=N, frames_per_stat=1, cpg=gw, coff=coff)
+        sc = torch.tensor([2.0 ** -30, 2.0 ** -16], dtype=torch.float64, device=DEV)
+        assert relerr(gst.view(Fr, 32, 2).double() * sc, acc.view(Fr, 32, 2).double() * sc) < 2e-3
+    else:
+        assert (Fr, H, W) != (32, 20, 32), "the 640-channel Upsample of the B = 2 forward is expected to take the statistics epilogue"
 
 
 # ---------------------------------------------------------------- CLIP text tower kernels
@@ -684,6 +701,112 @@ def test_concat_with_groupnorm_statistics(Fr, HW, C1, C2):
         keep[1, gi] = False
         assert torch.equal(yv.permute(0, 2, 1, 3)[keep], gref.view(Fr, HW, 32, cpg).permute(0, 2, 1, 3)[keep].to(y.dtype)) or \
             relerr(yv.permute(0, 2, 1, 3)[keep], gref.view(Fr, HW, 32, cpg).permute(0, 2, 1, 3)[keep]) < TOL16
+
+
+# ---------------------------------------------------------------- the virtual torch.cat of the output blocks (openaimodel3d.py:571)
+@pytest.mark.parametrize("M,C1,C2,N,res", [(81920, 640, 320, 320, False), (81920, 320, 320, 320, True), (20480, 1280, 640, 640, False),
+                                           (20480, 640, 320, 640, True), (20000, 640, 640, 640, False), (40960, 512, 256, 320, False)])
+def test_gemm_two_source_a(M, C1, C2, N, res):
+    """moca_gemm_params.a2: the skip_connection 1x1 conv reads cat([h, skip], channels) from its two sources -- bit-identical to
+    the same kernel on the materialised concat (same k order), and against torch"""
+    h, sk = rnd(M, C1) * 1.2 + 0.1, rnd(M, C2) * 0.8 - 0.2
+    K = C1 + C2
+    w, b = rnd(N, K, scale=K ** -0.5), rnd(N, dtype=torch.float32)
+    r = rnd(M, N) if res else None
+    pw = ops.pack_linear(w, b)
+    assert ops.gemm_cat_ok(h, pw, M=M, residual=r, a2=(sk, C1)), "expected a staggered-kernel launch"
+    cat = torch.cat([h, sk], dim=1).contiguous()
+    ref_k = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(cat, pw, ref_k, M=M, residual=r)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(h, pw, out, M=M, residual=r, a2=(sk, C1))
+    assert torch.equal(out, ref_k), "two-source A differs from the materialised concat"
+    ref = cat.float() @ w.float().t() + b
+    if res:
+        ref = ref.half().float() + r.float()
+    check(out, ref, TOL16, "linear over the virtual concat")
+    # sources with wider row strides (views of larger buffers)
+    hb, sb = torch.zeros(M, C1 + 64, dtype=torch.float16, device=DEV), torch.zeros(M, C2 + 128, dtype=torch.float16, device=DEV)
+    hb[:, :C1] = h
+    sb[:, :C2] = sk
+    out2 = torch.empty_like(out)
+    ops.gemm(hb[:, :C1], pw, out2, M=M, residual=r, a2=(sb[:, :C2], C1))
+    assert torch.equal(out2, ref_k)
+    # refused: a split that is no multiple of 64 columns, split-K, a GEGLU / LayerNorm-fold epilogue
+    assert not ops.gemm_cat_ok(h, pw, M=M, a2=(sk, C1 - 32))
+    assert not ops.gemm_cat_ok(h, pw, M=M, splits=2, a2=(sk, C1))
+    assert L.load().moca_gemm_f16 is not None
+    with pytest.raises(L.MocaHipError):
+        ops.gemm(h, pw, out2, M=M, a2=(sk, C1 - 32))
+
+
+@pytest.mark.parametrize("Fr,HW,C1,C2,own", [(32, 2560, 640, 320, True), (32, 2560, 320, 320, True), (32, 640, 1280, 640, True),
+                                             (32, 640, 640, 640, False), (32, 2560, 640, 320, False), (16, 2560, 320, 320, False)])
+def test_groupnorm_virtual_cat(Fr, HW, C1, C2, own):
+    """GroupNorm(+SiLU) of the never-materialised cat([h, skip]): h's producer accumulates its share of the concat's statistics in the
+    concat's grouping (gstat_cpg), skip's share is either its own finished 32-group statistics (merged by the GroupNorm: `own`) or
+    accumulated by its producer with a channel offset (gstat_coff); and the read-only statistics pass for producer-less sources"""
+    M, C = Fr * HW, C1 + C2
+    gw = C // 32
+    pws, srcs, outs = [], [], []
+    for Cn in (C1, C2):
+        a, w, b = rnd(M, Cn), rnd(Cn, Cn, scale=Cn ** -0.5), rnd(Cn, dtype=torch.float32) * 0.5
+        pws.append(ops.pack_linear(w, b)); srcs.append(a); outs.append(torch.empty(M, Cn, dtype=torch.float16, device=DEV))
+    for (a, pw) in zip(srcs, pws):
+        assert ops.gemm_colsum_rows(a, pw, M=M) > 0 and HW % ops.gemm_colsum_rows(a, pw, M=M) == 0
+    gcat = torch.zeros(Fr * 64, dtype=torch.int64, device=DEV)
+    gown = torch.zeros(Fr * 64, dtype=torch.int64, device=DEV)
+    ops.gemm(srcs[0], pws[0], outs[0], M=M, gstat=(gcat, HW, gw, 0))
+    if own:
+        ops.gemm(srcs[1], pws[1], outs[1], M=M, gstat=(gown, HW))
+    else:
+        ops.gemm(srcs[1], pws[1], outs[1], M=M, gstat=(gcat, HW, gw, C1))
+    h, sk = outs
+    ref_cat = torch.cat([h, sk], dim=1)
+    g, be = rnd(C, dtype=torch.float32) * 0.2 + 1.0, rnd(C, dtype=torch.float32) * 0.2
+    y = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    ops.groupnorm_gstat_cat(h, sk, y, g, be, gcat, gown if own else None, F=Fr, HW=HW, C1=C1, C2=C2, frames_per_stat=1, eps=1e-5, silu=True)
+    gref = F.silu(F.group_norm(ref_cat.float().view(Fr, HW, C).permute(0, 2, 1), 32, g, be, 1e-5)).permute(0, 2, 1).reshape(M, C)
+    check(y, gref, TOL16, "groupnorm of the virtual concat (statistics from the producers)")
+    # against the materialising path on the same tensors (statistics of the fp16 values instead of the producers' fp32 ones)
+    out = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    gst = torch.zeros(Fr * 64, dtype=torch.int64, device=DEV)
+    ops.concat_channels_gstat(h, sk, out, gst, F=Fr, HW=HW, C1=C1, C2=C2, frames_per_stat=1)
+    y0 = torch.empty_like(y)
+    ops.groupnorm_gstat(out, y0, g, be, gst, F=Fr, HW=HW, Cn=C, frames_per_stat=1, eps=1e-5, silu=True)
+    assert relerr(y, y0) < 2e-3
+    # the read-only statistics pass: both shares from moca_gstat_accum_f16 == the statistics the concat kernel leaves
+    gacc = torch.zeros(Fr * 64, dtype=torch.int64, device=DEV)
+    ops.gstat_accum(h, gacc, F=Fr, HW=HW, Cn=C1, frames_per_stat=1, cpg=gw, coff=0)
+    ops.gstat_accum(sk, gacc, F=Fr, HW=HW, Cn=C2, frames_per_stat=1, cpg=gw, coff=C1)
+    sc = torch.tensor([2.0 ** -30, 2.0 ** -16], dtype=torch.float64, device=DEV)
+    assert relerr(gacc.view(Fr, 32, 2).double() * sc, gst.view(Fr, 32, 2).double() * sc) < 1e-6
+    y1 = torch.empty_like(y)
+    ops.groupnorm_gstat_cat(h, sk, y1, g, be, gacc, None, F=Fr, HW=HW, C1=C1, C2=C2, frames_per_stat=1, eps=1e-5, silu=True)
+    assert relerr(y1, y0) < 1e-3
+    # skip = two copies of Fr / 2 frames whose own statistics cover the distinct frames only (the skip connection out of the shared prefix)
+    if gw % (C2 // 32) == 0 and (C1 % gw) % (C2 // 32) == 0:
+        Fb = Fr // 2
+        skr = torch.cat([sk[:Fb * HW], sk[:Fb * HW]], dim=0).contiguous()
+        gb = torch.zeros(Fb * 64, dtype=torch.int64, device=DEV)
+        ops.gstat_accum(skr, gb, F=Fb, HW=HW, Cn=C2, frames_per_stat=1, cpg=C2 // 32, coff=0)
+        gh = torch.zeros(Fr * 64, dtype=torch.int64, device=DEV)
+        ops.gstat_accum(h, gh, F=Fr, HW=HW, Cn=C1, frames_per_stat=1, cpg=gw, coff=0)
+        y2 = torch.empty_like(y)
+        ops.groupnorm_gstat_cat(h, skr, y2, g, be, gh, gb, F=Fr, HW=HW, C1=C1, C2=C2, frames_per_stat=1, eps=1e-5, silu=True, Fb=Fb)
+        rref = torch.cat([h, skr], dim=1)
+        gref2 = F.silu(F.group_norm(rref.float().view(Fr, HW, C).permute(0, 2, 1), 32, g, be, 1e-5)).permute(0, 2, 1).reshape(M, C)
+        check(y2, gref2, TOL16, "virtual concat with a repeated skip source")
+    # a poisoned source poisons exactly the concat groups it belongs to
+    sk2 = sk.clone()
+    sk2[HW + 5, 3] = float("nan")
+    gacc.zero_()
+    ops.gstat_accum(h, gacc, F=Fr, HW=HW, Cn=C1, frames_per_stat=1, cpg=gw, coff=0)
+    ops.gstat_accum(sk2, gacc, F=Fr, HW=HW, Cn=C2, frames_per_stat=1, cpg=gw, coff=C1)
+    ops.groupnorm_gstat_cat(h, sk2, y1, g, be, gacc, None, F=Fr, HW=HW, C1=C1, C2=C2, frames_per_stat=1, eps=1e-5, silu=True)
+    yv = y1.view(Fr, HW, 32, gw)
+    gi = (C1 + 3) // gw
+    assert torch.isnan(yv[1, :, gi]).all() and torch.isfinite(yv[0]).all() and torch.isfinite(yv[1, :, :gi]).all()
 
 
 # ---------------------------------------------------------------- q|k|v projection + temporal attention in one launch

@@ -70,7 +70,7 @@ def describe(s):
               (" +colsum" if kw.get("colsum") is not None else "") + (" +LN" if kw.get("ln") is not None else "") + \
               (" +rowsum" if kw.get("rowsum") is not None else "") + (" lnfold" if kw.get("lnfold") is not None else "") + \
               (" +gstat" if kw.get("gstat") is not None else "") + (" +tattn" if kw.get("tattn") is not None else "") + \
-              (f" up{kw['up_phase']}" if kw.get("up_phase") else "")
+              (f" up{kw['up_phase']}" if kw.get("up_phase") else "") + (" cat2" if kw.get("a2") is not None else "")
         M = kw["M"]
         flop = 2.0 * M * pw.N * pw.K
         n_out = (pw.n_out if pw.geglu else pw.N) if kw.get("tattn") is None else pw.N // 3
@@ -85,6 +85,12 @@ def describe(s):
         rows = kw["F"] * kw["HW"]
         return f"{tag} F={kw['F']} HW={kw['HW']} C={kw['Cn']} fps={kw['frames_per_stat']}", 0.0, \
             2.0 * rows * kw["Cn"] * (3 if fn == "groupnorm" else 2)
+    if fn == "groupnorm_gstat_cat":
+        rows = kw["F"] * kw["HW"]
+        return f"groupnorm(gstat, virtual cat) F={kw['F']} HW={kw['HW']} C={kw['C1']}+{kw['C2']} fps={kw['frames_per_stat']}", 0.0, \
+            4.0 * rows * (kw["C1"] + kw["C2"])
+    if fn == "gstat_accum":
+        return f"gstat_accum F={kw['F']} HW={kw['HW']} C={kw['Cn']}", 0.0, 2.0 * kw["F"] * kw["HW"] * kw["Cn"]
     if fn == "layernorm":
         return f"layernorm M={kw['M']} C={kw['Cn']}", 0.0, 4.0 * kw["M"] * kw["Cn"]
     if fn == "attention":
