@@ -74,6 +74,10 @@ extern "C" {
                            /* left behind): LayerNorm never touches memory                    */
                            /* (attention.py:216-220); only where moca_gemm_lnfold_ok() != 0   */
 
+#define MOCA_EP_SLABS 1024 /* split-K only (splits > 1 after normalisation, no other flag): leave the fp32 partial  */
+                           /* slabs in splitk_ws and launch NO reduce -- the caller finishes them, bias / row add /  */
+                           /* residual included, with moca_gemm_splitk_groupnorm_f16 (same params)                  */
+
 typedef struct moca_gemm_params {
     const void* a;         /* fp16 activations (gather source)                              */
     const void* w;         /* fp16 weights [N][ldw], K-contiguous, zero padded to ldw       */
@@ -167,6 +171,14 @@ int moca_gemm_tattn_ok(const moca_gemm_params* p);
 /* 1 when this call (a2 / lda2 / k1 set) can read its A operand from two sources (see moca_gemm_params.a2); else 0 (the caller
  * then materialises the concat with moca_concat_channels*_f16).                                                          */
 int moca_gemm_cat_ok(const moca_gemm_params* p);
+/* The split-K reduce of a MOCA_EP_SLABS call AND the GroupNorm(32)(+SiLU) that consumes its output (openaimodel3d.py:149-153,173-178,
+ * 252-263 at the 5 x 8-latent level, where every conv runs split-K) in one launch: x = fp16(sum of slabs + bias + row add + residual)
+ * exactly as moca_gemm_f16 would have stored it, y [M][N] = GroupNorm(x) over frames_per_stat frames of HW rows; x itself is written to
+ * p->out only with write_x != 0.  `p` = the params of the MOCA_EP_SLABS call.  Only where moca_gemm_splitk_groupnorm_ok() != 0
+ * (a (statistics group, channel group) slab of at most 4096 16-byte chunks, N / 32 a multiple of 8).                               */
+int moca_gemm_splitk_groupnorm_ok(const moca_gemm_params* p, int32_t HW, int32_t frames_per_stat);
+int moca_gemm_splitk_groupnorm_f16(const moca_gemm_params* p, void* y, const float* gamma, const float* beta, int32_t HW,
+                                   int32_t frames_per_stat, float eps, int32_t silu, int32_t write_x, void* stream);
 /* bytes of split-K workspace moca_gemm_f16 needs for (M,N,splits) */
 int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits);
 

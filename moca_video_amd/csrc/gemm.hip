@@ -416,6 +416,99 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const moca_gemm_para
     }
 }
 
+// ---- split-K reduce + the GroupNorm(+SiLU) that consumes the result, in ONE launch (moca_gemm_splitk_groupnorm_f16): at the
+// 5 x 8-latent level (M = 1280 at B = 2: 50 tiles per launch, every conv / temporal conv runs split-K) a ResBlock is a chain of
+// GEMM -> reduce -> GroupNorm launches of 5-9 us each on tensors of 3 MB.  One block per (statistics group, channel group) slab, as
+// gn_slab_reg_kernel: a thread sums the split-K slabs of its <= CPT 16-byte output chunks (+ bias / row add / residual: the epilogue of
+// splitk_reduce_kernel, same order), rounds them to fp16 -- the value the two-launch path stores and normalises --, optionally
+// writes them (write_x: the residual of a later launch), the block reduces sum / sum of squares and normalises from registers.
+template <int CPT>
+__global__ __launch_bounds__(1024) void splitk_gn_kernel(const moca_gemm_params p, half_t* __restrict__ y, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int R, int cpg, double inv_count, float eps,
+                                                         int silu, int write_x) {
+    __shared__ float s_red[2][16];
+    __shared__ float s_sc[128], s_sh[128];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int slab = blockIdx.x, sg = slab / 32, g = slab % 32;
+    const int vpr = cpg / 8, nchunks = R * vpr;
+    const int N = p.N;
+    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
+    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    half8v v[CPT];
+    int mrow[CPT], ccol[CPT];
+    float s = 0.f, q = 0.f;
+    // (chunk by chunk, split by split.  Prefetching the next split's loads of all CPT chunks -- two register sets -- measured SLOWER, 23.1 against
+    //  18.6 us on the 16-frame slabs: what bounds a block is not the dependent round trips but 160-byte row segments of the fp32 slabs at a
+    //  5 KiB stride on the 64 CUs the 64 slabs occupy; profiles/r05_ab_splitk_groupnorm.txt)
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int idx = tid + i * nthr;
+        mrow[i] = -1;
+        if (idx < nchunks) {
+            const int row = idx / vpr, c = idx - row * vpr;
+            const int m = sg * R + row, col = g * cpg + c * 8;
+            mrow[i] = m; ccol[i] = col;
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = p.bias ? p.bias[col + j] : 0.f;
+            for (int sp = 0; sp < p.splits; ++sp) {
+                const float* w = p.splitk_ws + ((int64_t)sp * p.M + m) * N + col;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(w), a1 = *reinterpret_cast<const f32x4*>(w + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a[j] += a0[j]; a[4 + j] += a1[j]; }
+            }
+            if (rowadd) {
+                const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += (float)e[j];
+            }
+            if (resid) {
+                const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += (float)e[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = (half_t)a[j];
+            if (write_x) *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+        if (mrow[i] >= 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float a = (float)v[i][j]; s += a; q += a * a; }
+        }
+    s = wave_sum(s); q = wave_sum(q);
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = s; s_red[1][tid >> 6] = q; }
+    __syncthreads();
+    if (tid < cpg) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < (nthr >> 6); ++w) { a += (double)s_red[0][w]; b += (double)s_red[1][w]; }
+        const double mean = a * inv_count;
+        double var = b * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const int c = g * cpg + tid;
+        const float sc = rstd * gamma[c];
+        s_sc[tid] = sc;
+        s_sh[tid] = beta[c] - (float)mean * sc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+        if (mrow[i] >= 0) {
+            const int c0 = ccol[i] - g * cpg;
+            half8v r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = (float)v[i][j] * s_sc[c0 + j] + s_sh[c0 + j];
+                if (silu) a = moca_silu(a);
+                r[j] = (half_t)a;
+            }
+            *reinterpret_cast<half8v*>(y + (int64_t)mrow[i] * N + ccol[i]) = r;
+        }
+}
+
 
 // =====================================================================================
 // Large-tile kernel: 256 x BN x 64 block tile (BN = 128 or 160), 512 threads = 8
@@ -3472,6 +3565,44 @@ extern "C" int moca_gemm_ln_ok(const moca_gemm_params* pp) {
     return takes_w80t_ln(p) ? 1 : 0;
 }
 
+// can moca_gemm_splitk_groupnorm_f16 finish this (validated, split-normalised) MOCA_EP_SLABS call?  fp16 plain epilogue, one block per
+// (statistics group, channel group) slab with the slab in registers
+static bool splitk_gn_ok(const moca_gemm_params& p, int HW, int fps) {
+    if (p.splits < 2 || (p.flags & ~MOCA_EP_SLABS) || p.N % 32 || (p.N / 32) % 8 || p.N / 32 > 128 || p.up_phase) return false;
+    if (HW <= 0 || fps <= 0 || p.M % (HW * fps)) return false;
+    const int64_t nchunks = (int64_t)HW * fps * (p.N / 32 / 8);
+    return nchunks >= 64 && nchunks <= 4096;
+}
+extern "C" int moca_gemm_splitk_groupnorm_ok(const moca_gemm_params* pp, int32_t HW, int32_t frames_per_stat) {
+    if (!pp) return 0;
+    moca_gemm_params p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
+    normalise_splits(p);
+    return splitk_gn_ok(p, HW, frames_per_stat) ? 1 : 0;
+}
+extern "C" int moca_gemm_splitk_groupnorm_f16(const moca_gemm_params* pp, void* y, const float* gamma, const float* beta, int32_t HW,
+                                              int32_t frames_per_stat, float eps, int32_t silu, int32_t write_x, void* stream) {
+    if (!pp || !y || !gamma || !beta) return MOCA_E_BADARG;
+    moca_gemm_params p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8 || !p.splitk_ws || (write_x && !p.out)) return MOCA_E_BADARG;
+    if (p.ldo % 8 || (p.residual && p.ldr % 8) || (p.rowadd && (p.ld_rowadd % 8 || p.rowadd_div <= 0))) return MOCA_E_BADARG;
+    normalise_splits(p);
+    if (!splitk_gn_ok(p, HW, frames_per_stat)) return MOCA_E_BADARG;
+    const int cpg = p.N / 32, R = HW * frames_per_stat;
+    const int nchunks = R * (cpg / 8);
+    const int cpt = (nchunks + 1023) / 1024;
+    const int thr = ((nchunks + cpt - 1) / cpt + 63) / 64 * 64;
+    const int n_slabs = (p.M / R) * 32;
+    const double inv_count = 1.0 / ((double)R * cpg);
+    hipStream_t st = moca_stream(stream);
+    half_t* yo = reinterpret_cast<half_t*>(y);
+#define MOCA_SKGN(CPT) hipLaunchKernelGGL(splitk_gn_kernel<CPT>, dim3(n_slabs), dim3(thr), 0, st, p, yo, gamma, beta, R, cpg, inv_count, eps, silu, write_x)
+    if (cpt == 1) MOCA_SKGN(1); else if (cpt == 2) MOCA_SKGN(2); else if (cpt == 3) MOCA_SKGN(3); else MOCA_SKGN(4);
+#undef MOCA_SKGN
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
 extern "C" int64_t moca_gemm_splitk_ws_bytes(int32_t M, int32_t N, int32_t splits) {
     return splits > 1 ? (int64_t)splits * M * N * 4 : 0;
 }
@@ -3491,6 +3622,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     // the plain-GELU epilogue (CLIP text MLP) exists in the 128-row kernel only
     if ((p.flags & MOCA_EP_GELU) && (geglu || p.splits != 1 || !((p.flags & MOCA_FORCE_SMALL_TILE) || p.M <= 128))) return MOCA_E_BADARG;
     normalise_splits(p);
+    if ((p.flags & MOCA_EP_SLABS) && (p.splits < 2 || (p.flags & ~MOCA_EP_SLABS))) return MOCA_E_BADARG;   // ask moca_gemm_splitk_groupnorm_ok() first
     if (p.up_phase && p.a_mode != MOCA_A_CONV3X3) return MOCA_E_BADARG;
     switch (p.a_mode) {
         case MOCA_A_LINEAR:
@@ -3583,7 +3715,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
         else rc = launch_gemm<64, MOCA_A_TCONV3>(p, st);
     }
     if (rc != MOCA_OK) return rc;
-    if (p.splits > 1) {
+    if (p.splits > 1 && !(p.flags & MOCA_EP_SLABS)) {
         const int out_n = geglu ? p.N / 2 : p.N;
         const int64_t total = (int64_t)p.M * (out_n / 8);
         int blocks = (int)((total + 255) / 256);

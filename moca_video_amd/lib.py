@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("MOCA_HIP_LIB") or os.path.join(_HERE, "libmoca_hip.so
 
 MOCA_A_LINEAR, MOCA_A_CONV3X3, MOCA_A_TCONV3 = 0, 1, 2
 MOCA_EP_GEGLU, MOCA_EP_OUT_F32, MOCA_FORCE_SMALL_TILE, MOCA_EP_GELU, MOCA_EP_COLSUM, MOCA_EP_LN = 1, 2, 4, 8, 16, 32
-MOCA_EP_ROWSUM, MOCA_EP_LNFOLD, MOCA_EP_GSTAT, MOCA_EP_TATTN = 64, 128, 256, 512
+MOCA_EP_ROWSUM, MOCA_EP_LNFOLD, MOCA_EP_GSTAT, MOCA_EP_TATTN, MOCA_EP_SLABS = 64, 128, 256, 512, 1024
 MOCA_TUNE_GEMM_W80, MOCA_TUNE_GEMM_G4, MOCA_TUNE_GEMM_SQ256, MOCA_TUNE_GEMM_WIDE, MOCA_TUNE_GN_SLAB, MOCA_TUNE_GEMM_G4P, MOCA_TUNE_GEMM_MF32, MOCA_TUNE_GEMM_SQP, MOCA_TUNE_SQP_WALK = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 _ERR = {0: "ok", -1: "bad argument (shape/alignment contract)", -2: "HIP launch/runtime error",
@@ -83,6 +83,8 @@ SIGNATURES = {
     "moca_gemm_lnfold_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_tattn_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_cat_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "moca_gemm_splitk_groupnorm_ok": (C.c_int, [C.POINTER(GemmParams), _i32, _i32]),
+    "moca_gemm_splitk_groupnorm_f16": (C.c_int, [C.POINTER(GemmParams), _vp, _vp, _vp, _i32, _i32, _f32, _i32, _i32, _vp]),
     "moca_groupnorm_gstat_cat_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "moca_gstat_accum_f16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "moca_groupnorm_colsum_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),

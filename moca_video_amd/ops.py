@@ -155,7 +155,7 @@ def finish_lnfold(pw: PackedWeight) -> PackedWeight:
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
                  residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None,
-                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, up_phase=0, prefetch=None, a2=None):
+                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, up_phase=0, prefetch=None, a2=None, slabs=False):
     p = _l.GemmParams()
     p.up_phase = up_phase
     if a2 is not None:                       # (second A source fp16 [M][lda2], columns of `a`): A = the virtual cat([a, a2], channels)
@@ -208,6 +208,8 @@ def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR
         p.lnf_nparts = lnfold[1]
         p.ln_eps = lnfold[2]
         p.lnf_wsum = pw.wsum.data_ptr() if pw.wsum is not None else None
+    if slabs:                                # split-K without the reduce launch: gemm_splitk_groupnorm() finishes the slabs
+        p.flags |= _l.MOCA_EP_SLABS
     p.splits = splits
     return p
 
@@ -255,6 +257,22 @@ def pack_qkv_per_head(wq, wk, wv, heads, bias=None, device="cuda"):
     if bias is not None:
         b = torch.stack([bias[:C_].reshape(heads, 64), bias[C_:2 * C_].reshape(heads, 64), bias[2 * C_:].reshape(heads, 64)], dim=1).reshape(-1)
     return _finish(w, b, device)
+
+
+def gemm_splitk_groupnorm_ok(a, pw: PackedWeight, *, HW, frames_per_stat, **kw):
+    """can the split-K reduce of this call be fused into the GroupNorm that consumes it (gemm_splitk_groupnorm)?"""
+    p = _gemm_params(a, pw, None, slabs=True, **kw)
+    return bool(_l.load().moca_gemm_splitk_groupnorm_ok(C.byref(p), HW, frames_per_stat))
+
+
+def gemm_splitk_groupnorm(a, pw: PackedWeight, out, y, gamma, beta, *, HW, frames_per_stat, eps, silu, write_x, **kw):
+    """finish a `gemm(..., slabs=True)` call: x = its output (written to `out` only with write_x), y = GroupNorm(+SiLU)(x); `kw` = the
+    keywords of that gemm call"""
+    kw = {k: v for k, v in kw.items() if k not in ("slabs", "colsum", "prefetch")}
+    p = _gemm_params(a, pw, out, slabs=True, **kw)
+    _l.check(_l.load().moca_gemm_splitk_groupnorm_f16(C.byref(p), _l.ptr(y), _l.ptr(gamma), _l.ptr(beta), HW, frames_per_stat, eps,
+                                                      1 if silu else 0, 1 if write_x else 0, _st()), "moca_gemm_splitk_groupnorm_f16")
+    return y
 
 
 def gemm_cat_ok(a, pw: PackedWeight, **kw):

@@ -61,6 +61,9 @@ PREFETCH_MIN_BYTES = int(float(os.environ.get("MOCA_PREFETCH_MIN_MB", "4")) * (1
 PREFETCH_HOST_FLOP = float(os.environ.get("MOCA_PREFETCH_HOST_GF", "50")) * 1e9
 # virtual torch.cat in the output blocks (A/B switch: MOCA_VCAT=0 materialises every concat as before round 5)
 VIRTUAL_CAT = os.environ.get("MOCA_VCAT", "1") != "0"
+# split-K reduce inside the GroupNorm that consumes it (the 5 x 8-latent level of the B = 2 forward; A/B switch MOCA_SKGN=0)
+SPLITK_GN = os.environ.get("MOCA_SKGN", "1") != "0"
+SPLITK_GN_ALL = os.environ.get("MOCA_SKGN", "1") == "2"     # (A/B: also the 16-frame GroupNorms of the temporal convs)
 
 
 class _LNRef:
@@ -74,6 +77,7 @@ class _LNRef:
 
 class _PlanBase:
     """pool + recorded launch list + hipGraph capture/replay, shared by the UNet plan and the VAE-decoder plan"""
+    _defer_slabs = False     # (UNet plan only: every feature map it creates reaches gn() or _drop_colsum(), which release the deferred workspace)
 
     def __init__(self, model, device):
         self.model = model
@@ -87,6 +91,7 @@ class _PlanBase:
         self.graph_failed = False
         self.n_runs = 0
         self._gstat_buf, self._gstat_used, self._last_gemm_step = None, 0, None
+        self._last_slabs = None
         self._gstat_full = []
         self.reps = 1            # > 1: the batch is `reps` context variants of the same Bx latents (_Plan: shared prefix)
         self._prefetch_at = {}   # during the build: index of a recorded GEMM step -> weights of later launches to prefetch in front of it
@@ -161,8 +166,12 @@ class _PlanBase:
                 cs = (self.pool.get((M + rows - 1) // rows, 2 * pw.N, torch.float32), rows)
         self._note_gemm(pw)
         self._emit(ops.gemm, a, pw, out, M=M, splits=splits, splitk_ws=ws, colsum=None if cs is None else cs[0], **kw)
+        self._last_slabs = None
         if ws is not None:
-            self.pool.put(ws)
+            if want_colsum and SPLITK_GN and self._defer_slabs:   # conv / tconv: the workspace stays reserved until the consumer is known
+                self._last_slabs = (ws, self._last_gemm_step)   # (_FMap.slabs; released by gn() / _drop_colsum())
+            else:
+                self.pool.put(ws)
         return (out, cs) if want_colsum else out
 
     def linear(self, a, M, pw, residual=None, lda=None, want_colsum=False):
@@ -179,7 +188,9 @@ class _PlanBase:
         M = fm.F * oH * oW
         out, cs = self._gemm(fm.buf, pw, M, mode=_l.MOCA_A_CONV3X3, conv=(fm.C, fm.H, fm.W, oH, oW, stride, up),
                              rowadd=rowadd, rowadd_div=rowadd_div, residual=residual, want_colsum=True)
-        return _FMap(out, fm.F, oH, oW, pw.N, cs, src=self._last_gemm_step if cs is not None else None)
+        o = _FMap(out, fm.F, oH, oW, pw.N, cs, src=self._last_gemm_step if cs is not None else None)
+        o.slabs = self._last_slabs
+        return o
 
     def upconv(self, fm, conv):
         """`Upsample` (openaimodel3d.py:96-106: nearest x2, then conv3x3).  With enough low-resolution rows to fill the chip per
@@ -208,9 +219,11 @@ class _PlanBase:
     def tconv(self, fm, pw, residual=None):
         out, cs = self._gemm(fm.buf, pw, fm.M, mode=_l.MOCA_A_TCONV3, tconv=(fm.C, self.T, fm.H * fm.W), residual=residual,
                              want_colsum=True)
-        return _FMap(out, fm.F, fm.H, fm.W, pw.N, cs, src=self._last_gemm_step if cs is not None else None)
+        o = _FMap(out, fm.F, fm.H, fm.W, pw.N, cs, src=self._last_gemm_step if cs is not None else None)
+        o.slabs = self._last_slabs
+        return o
 
-    def gn(self, fm, gb, *, fps, eps, silu):
+    def gn(self, fm, gb, *, fps, eps, silu, x_dead=False):
         """GroupNorm(32) (+SiLU).  With `fm.colsum` (left by the producing GEMM) and row tiles that do not straddle frames the
         statistics pass over x disappears: finalize-from-column-sums + apply; otherwise the three-launch / slab path."""
         if isinstance(fm, _CatMap):                            # the virtual concat: both sources read in place, statistics finished
@@ -219,6 +232,24 @@ class _PlanBase:
                        C1=fm.h.C, C2=fm.skip.C, frames_per_stat=fps, eps=eps, silu=silu, Fb=fm.Fb)
             assert fps == 1
             return y
+        if getattr(fm, "slabs", None) is not None:
+            # the producer ran split-K: its reduce launch moves into this GroupNorm (x_dead: nobody else reads fm.buf -- it is not written)
+            wsk, src = fm.slabs
+            prod = self.steps[src]
+            kw = dict(prod.keywords)
+            fm.slabs = None
+            # (only per-frame statistics: 1024 slabs fill the chip and the launch beats reduce + GroupNorm by 2.3 us; the 64 slabs of the
+            #  16-frame GroupNorms are slower fused, 18.6 against 7.9 + 7.9 us -- profiles/r05_ab_splitk_groupnorm.txt)
+            if (fps == 1 or SPLITK_GN_ALL) and \
+                    ops.gemm_splitk_groupnorm_ok(prod.args[0], prod.args[1], HW=fm.H * fm.W, frames_per_stat=fps, **kw):
+                y = self.pool.get(fm.M, fm.C)
+                kw["slabs"] = True
+                self.steps[src] = functools.partial(prod.func, *prod.args, **kw)
+                self._emit(ops.gemm_splitk_groupnorm, prod.args[0], prod.args[1], prod.args[2], y, gb[0], gb[1], HW=fm.H * fm.W,
+                           frames_per_stat=fps, eps=eps, silu=silu, write_x=not x_dead, **kw)
+                self.pool.put(wsk)
+                return y
+            self.pool.put(wsk)
         y = self.pool.get(fm.M, fm.C)
         HW = fm.H * fm.W
         ws = self.pool.get(1, ops.groupnorm_ws_floats(fm.F, HW, fm.C), torch.float32)
@@ -264,6 +295,9 @@ class _PlanBase:
 
     def _drop_colsum(self, fm):
         """the statistics buffer of a feature map goes back to the pool once its GroupNorm consumer has been recorded"""
+        if getattr(fm, "slabs", None) is not None:             # a split-K producer whose consumer was no GroupNorm: its own reduce stays
+            self.pool.put(fm.slabs[0])
+            fm.slabs = None
         if fm.colsum is not None:
             if not fm.cs_used and fm.src is not None:          # nobody read the column sums (the consumer was a conv / a concat /
                 prod = self.steps[fm.src]                      # a GroupNorm whose statistics groups the row tiles straddle):
@@ -319,6 +353,8 @@ class _PlanBase:
 
 
 class _Plan(_PlanBase):
+    _defer_slabs = True
+
     def __init__(self, model, B, T, H, W, L, in_dtype, device, shared_x=False):
         """shared_x: the B videos are `len(L)` context variants of the SAME B / len(L) latents (the two `apply_model` calls of
         classifier-free guidance, ddim.py:298-299,366-369, on one x): `x_in` holds the distinct latents only, everything up to the
@@ -354,7 +390,7 @@ class _Plan(_PlanBase):
         emb_out = self.emb_all[:, off:off + width]               # this block's columns of the fused emb_layers GEMM
         h1 = self.conv(_FMap(g1, x.F, x.H, x.W, x.C), P[id(mod.in_layers[2])], rowadd=emb_out, rowadd_div=HW)
         self._release(g1)
-        g2 = self.gn(h1, P[id(mod.out_layers[0])], fps=1, eps=1e-5, silu=True)
+        g2 = self.gn(h1, P[id(mod.out_layers[0])], fps=1, eps=1e-5, silu=True, x_dead=True)
         self._release(h1.buf)
         self._drop_colsum(h1)
         if isinstance(mod.skip_connection, torch.nn.Identity):
@@ -377,7 +413,7 @@ class _Plan(_PlanBase):
         cur = h2
         for i, (name, idx) in enumerate((("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3))):
             sq = getattr(tc, name)
-            g = self.gn(cur, P[id(sq[0])], fps=self.T, eps=1e-5, silu=True)
+            g = self.gn(cur, P[id(sq[0])], fps=self.T, eps=1e-5, silu=True, x_dead=cur is not h2)
             self._drop_colsum(cur)
             nxt = self.tconv(_FMap(g, cur.F, cur.H, cur.W, cur.C), P[id(sq[idx])], residual=h2.buf if i == 3 else None)
             self._release(g)

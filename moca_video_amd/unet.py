@@ -180,7 +180,7 @@ class _Pool:
 class _FMap:
     """channels-last feature map: buf [F*H*W][C] fp16; `colsum` = (f32 [row tiles][C][2] buffer, rows per tile) when the
     GEMM that produced it also left per-(row tile, channel) sums and sums of squares behind (GroupNorm statistics)"""
-    __slots__ = ("buf", "F", "H", "W", "C", "colsum", "src", "gstat", "cs_used", "cs_rows", "gstat_own", "own_F")
+    __slots__ = ("buf", "F", "H", "W", "C", "colsum", "src", "gstat", "cs_used", "cs_rows", "gstat_own", "own_F", "slabs")
 
     def __init__(self, buf, F, H, W, C, colsum=None, src=None, gstat=None):
         self.buf, self.F, self.H, self.W, self.C, self.colsum = buf, F, H, W, C, colsum
@@ -190,6 +190,7 @@ class _FMap:
         self.cs_rows = colsum[1] if colsum is not None else 0   # rows per tile of the producer's statistics epilogue (kept when colsum is dropped)
         self.gstat_own = None   # (accumulators, frames_per_stat): the producer was re-targeted to FINISHED statistics of this map (32 groups of C / 32)
         self.own_F = 0          # > 0: gstat_own covers own_F frames and buf is F / own_F copies of them (the repeat that ends the shared prefix)
+        self.slabs = None       # (split-K workspace, index of the recorded GEMM launch): buf's producer ran split-K and its reduce may still move into the consuming GroupNorm
 
     @property
     def M(self):

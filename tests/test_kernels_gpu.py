@@ -703,6 +703,54 @@ def test_concat_with_groupnorm_statistics(Fr, HW, C1, C2):
             relerr(yv.permute(0, 2, 1, 3)[keep], gref.view(Fr, HW, 32, cpg).permute(0, 2, 1, 3)[keep]) < TOL16
 
 
+# ---------------------------------------------------------------- split-K reduce inside the consuming GroupNorm (the 5 x 8-latent level)
+@pytest.mark.parametrize("Fr,HW,fps,mode,splits,res,radd", [(32, 40, 16, "tconv", 4, False, False), (32, 40, 16, "conv", 5, True, False),
+                                                           (32, 40, 1, "conv", 5, False, True), (16, 40, 16, "tconv", 4, True, False),
+                                                           (32, 40, 1, "lin", 4, True, False)])
+def test_gemm_splitk_groupnorm(Fr, HW, fps, mode, splits, res, radd):
+    """MOCA_EP_SLABS + moca_gemm_splitk_groupnorm_f16 against the three-launch path (GEMM, reduce, GroupNorm): x bit-identical when it is
+    written, y to the fp16 tolerance (same fp16 x, statistics summed in another order)"""
+    C, N, M = 1280, 1280, Fr * HW
+    H, W = (5, 8) if HW == 40 else (HW // 8, 8)
+    if mode == "tconv":
+        a, K, kw = rnd(M, C), 3 * C, dict(mode=L.MOCA_A_TCONV3, tconv=(C, 16, HW))
+        pw = ops.pack_tconv3(rnd(N, C, 3, 1, 1, scale=K ** -0.5), rnd(N, dtype=torch.float32))
+    elif mode == "conv":
+        a, K, kw = rnd(M, C), 9 * C, dict(mode=L.MOCA_A_CONV3X3, conv=(C, H, W, H, W, 1, 0))
+        pw = ops.pack_conv3x3(rnd(N, C, 3, 3, scale=K ** -0.5), rnd(N, dtype=torch.float32))
+    else:
+        a, K, kw = rnd(M, 2 * C), 2 * C, dict()
+        pw = ops.pack_linear(rnd(N, K, scale=K ** -0.5), rnd(N, dtype=torch.float32))
+    r = rnd(M, N) if res else None
+    ra = rnd(Fr, N) if radd else None
+    kw.update(M=M, splits=splits, residual=r, rowadd=ra, rowadd_div=HW if radd else 1)
+    ws = torch.empty(splits * M * N, dtype=torch.float32, device=DEV)
+    g, be = rnd(N, dtype=torch.float32) * 0.2 + 1.0, rnd(N, dtype=torch.float32) * 0.2
+    x0 = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(a, pw, x0, splitk_ws=ws, **kw)
+    y0 = torch.empty_like(x0)
+    wsg = torch.empty(ops.groupnorm_ws_floats(Fr, HW, N), dtype=torch.float32, device=DEV)
+    ops.groupnorm(x0, y0, g, be, F=Fr, HW=HW, Cn=N, frames_per_stat=fps, eps=1e-5, silu=True, ws=wsg)
+    assert ops.gemm_splitk_groupnorm_ok(a, pw, HW=HW, frames_per_stat=fps, splitk_ws=ws, **kw)
+    for write_x in (True, False):
+        x1 = torch.full_like(x0, float("nan"))
+        y1 = torch.empty_like(x0)
+        ws.fill_(float("nan"))
+        ops.gemm(a, pw, x1, splitk_ws=ws, slabs=True, **kw)
+        assert torch.isnan(x1).all(), "a MOCA_EP_SLABS launch must not write its output"
+        ops.gemm_splitk_groupnorm(a, pw, x1, y1, g, be, HW=HW, frames_per_stat=fps, eps=1e-5, silu=True, write_x=write_x, splitk_ws=ws, **kw)
+        if write_x:
+            assert torch.equal(x1, x0)
+        else:
+            assert torch.isnan(x1).all()
+        check(y1, y0.float(), 1e-3, f"split-K reduce + GroupNorm ({mode}, write_x={write_x})")
+    # refused: no split-K, or another epilogue flag
+    kw1 = dict(kw, splits=1)
+    assert not ops.gemm_splitk_groupnorm_ok(a, pw, HW=HW, frames_per_stat=fps, **kw1)
+    with pytest.raises(L.MocaHipError):
+        ops.gemm(a, pw, x0, slabs=True, **kw1)
+
+
 # ---------------------------------------------------------------- the virtual torch.cat of the output blocks (openaimodel3d.py:571)
 @pytest.mark.parametrize("M,C1,C2,N,res", [(81920, 640, 320, 320, False), (81920, 320, 320, 320, True), (20480, 1280, 640, 640, False),
                                            (20480, 640, 320, 640, True), (20000, 640, 640, 640, False), (40960, 512, 256, 320, False)])

@@ -70,7 +70,8 @@ def describe(s):
               (" +colsum" if kw.get("colsum") is not None else "") + (" +LN" if kw.get("ln") is not None else "") + \
               (" +rowsum" if kw.get("rowsum") is not None else "") + (" lnfold" if kw.get("lnfold") is not None else "") + \
               (" +gstat" if kw.get("gstat") is not None else "") + (" +tattn" if kw.get("tattn") is not None else "") + \
-              (f" up{kw['up_phase']}" if kw.get("up_phase") else "") + (" cat2" if kw.get("a2") is not None else "")
+              (f" up{kw['up_phase']}" if kw.get("up_phase") else "") + (" cat2" if kw.get("a2") is not None else "") + \
+              (" slabs" if kw.get("slabs") else "")
         M = kw["M"]
         flop = 2.0 * M * pw.N * pw.K
         n_out = (pw.n_out if pw.geglu else pw.N) if kw.get("tattn") is None else pw.N // 3
@@ -89,6 +90,10 @@ def describe(s):
         rows = kw["F"] * kw["HW"]
         return f"groupnorm(gstat, virtual cat) F={kw['F']} HW={kw['HW']} C={kw['C1']}+{kw['C2']} fps={kw['frames_per_stat']}", 0.0, \
             4.0 * rows * (kw["C1"] + kw["C2"])
+    if fn == "gemm_splitk_groupnorm":
+        pw = s.args[1]
+        return f"splitk reduce + groupnorm M={kw['M']} N={pw.N} splits={kw['splits']} fps={kw['frames_per_stat']}" + \
+            (" +x" if kw.get("write_x") else ""), 0.0, 4.0 * kw["splits"] * kw["M"] * pw.N + 2.0 * kw["M"] * pw.N * (2 if kw.get("write_x") else 1)
     if fn == "gstat_accum":
         return f"gstat_accum F={kw['F']} HW={kw['HW']} C={kw['Cn']}", 0.0, 2.0 * kw["F"] * kw["HW"] * kw["Cn"]
     if fn == "layernorm":
