@@ -107,6 +107,11 @@ def linear_res(lv, k, n):
 
 if __name__ == "__main__":
     ops.set_stream(None)
+    if os.environ.get("BG_PROBE") == "1":     # shapes outside the UNet: what the persistent register-epilogue kernel (knob 7:2) does on short-K, HBM-bound linears
+        for n in (256, 512):
+            linear(0, 320, n); linear_res(0, 320, n); linear_res(0, 1280, n); linear_res(1, 640, n)
+        linear(0, 320, 320); linear_res(0, 320, 320); linear_res(0, 1280, 320); linear_res(1, 640, 640)
+        sys.exit(0)
     conv(0, 320, 320); conv(0, 640, 320); conv(0, 960, 320)
     conv(1, 320, 640); conv(1, 640, 640); conv(1, 1280, 640); conv(1, 1920, 640)
     conv(2, 640, 1280); conv(2, 1280, 1280); conv(2, 2560, 1280); conv(2, 1920, 1280)
