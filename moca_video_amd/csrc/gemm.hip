@@ -2318,6 +2318,38 @@ __global__ __launch_bounds__(256, 2) void gemm_g4q_kernel(const moca_gemm_params
 }
 
 
+// cross-lane steps of the in-epilogue temporal attention as VALU lane swaps (v_permlane16_swap / v_permlane32_swap: with both operands
+// equal to x, the two results hold x and its partner 16 / 32 lanes away in every lane -- cdna_hip_programming.md T12 / T21) instead of
+// ds_bpermute round trips through the LDS pipe; and the V^T operand by the transposing LDS read (attention.hip: tr_read)
+typedef short tq_short4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) tq_short4v* tq_lds_s4_ptr;
+__device__ __forceinline__ half4v tattn_tr_read(const char* addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const tq_short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tq_lds_s4_ptr)addr);
+    return __builtin_bit_cast(half4v, v);
+#else
+    return half4v{0, 0, 0, 0};
+#endif
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MOCA_XLANE(NAME, SWAP, OP)                                                                         \
+    __device__ __forceinline__ float NAME(float x) {                                                       \
+        const auto r = SWAP(__float_as_uint(x), __float_as_uint(x), false, false);                         \
+        const float a = __uint_as_float(r[0]), b = __uint_as_float(r[1]);                                  \
+        return OP;                                                                                         \
+    }
+MOCA_XLANE(xlane16_max, __builtin_amdgcn_permlane16_swap, fmaxf(a, b))
+MOCA_XLANE(xlane32_max, __builtin_amdgcn_permlane32_swap, fmaxf(a, b))
+MOCA_XLANE(xlane16_sum, __builtin_amdgcn_permlane16_swap, a + b)
+MOCA_XLANE(xlane32_sum, __builtin_amdgcn_permlane32_swap, a + b)
+#undef MOCA_XLANE
+#else
+__device__ __forceinline__ float xlane16_max(float x) { return x; }
+__device__ __forceinline__ float xlane32_max(float x) { return x; }
+__device__ __forceinline__ float xlane16_sum(float x) { return x; }
+__device__ __forceinline__ float xlane32_sum(float x) { return x; }
+#endif
+
 // =====================================================================================
 // "w80s" kernel: the 320 x 160 x 32 tile / 80 x 80 wave tile / 5-slot ring of w80b, with the main loop cut into
 // LOAD and MFMA SEGMENTS and the two waves of every SIMD running half an iteration apart.
@@ -2731,43 +2763,70 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         // + two cross-lane steps, O^T = V^T.P^T by v_mfma_f32_16x16x16_f16.  Only O (64 of the 192 columns) goes to memory.
         const float sl2e = p.tattn_scale * 1.4426950408889634f;
         half_t* outp = reinterpret_cast<half_t*>(p.out);
-        for (int pix = wave; pix < 20; pix += 8) {
-            const char* base = smem + (pix * 16) * pitch;
-            half8v kf[2], qf[2];
+        // Round 5 (profiles/r05_ab_tattn_epilogue.txt): this epilogue was 5.0 k of a tile's 30 k cycles -- a wave ran its 2-3 pixels one
+        // after the other, each a chain of LDS reads -> MFMA -> cross-lane maximum -> exp -> cross-lane sum -> 64 two-byte LDS reads of V ->
+        // MFMA.  Now (a) the wave's three pixel slots are computed side by side (uniform control flow: slot 2 of waves 4..7 repeats pixel
+        // 19 and only skips its stores), so the chains overlap; (b) the cross-lane steps are v_permlane16/32_swap (VALU) instead of
+        // ds_bpermute; (c) V^T fragments come from ONE ds_read_b64_tr_b16 per 16 columns instead of 16 two-byte reads.  Same values, same
+        // order of additions.
+        constexpr int NPX = 3;
+        int pixs[NPX];
+        half8v kf[NPX][2], qf[NPX][2];
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            pixs[i] = min(wave + 8 * i, 19);
+            const char* base = smem + (pixs[i] * 16) * pitch;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                qf[ks] = *reinterpret_cast<const half8v*>(base + fr * pitch + (ks * 32 + fg * 8) * 2);
-                kf[ks] = *reinterpret_cast<const half8v*>(base + fr * pitch + (64 + ks * 32 + fg * 8) * 2);
+                qf[i][ks] = *reinterpret_cast<const half8v*>(base + fr * pitch + (ks * 32 + fg * 8) * 2);
+                kf[i][ks] = *reinterpret_cast<const half8v*>(base + fr * pitch + (64 + ks * 32 + fg * 8) * 2);
             }
-            f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-            sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[0], sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[1], sc, 0, 0, 0);
-            float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));          // lane: S^T[key = 4 fg + r][query = fr]
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        }
+        half4v vfr[NPX][4];                                   // V^T fragments: lane (d = fr, keys 4 fg .. 4 fg + 3) of column block dt
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            const char* base = smem + (pixs[i] * 16) * pitch;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                vfr[i][dt] = tattn_tr_read(base + (4 * fg + (fr >> 2)) * pitch + (128 + dt * 16 + 4 * (fr & 3)) * 2);
+        }
+        f32x4 sc[NPX];
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            sc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            sc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i][0], qf[i][0], sc[i], 0, 0, 0);
+            sc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i][1], qf[i][1], sc[i], 0, 0, 0);
+        }
+        half4v pf[NPX];
+        float inv[NPX];
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            float mx = fmaxf(fmaxf(sc[i][0], sc[i][1]), fmaxf(sc[i][2], sc[i][3]));       // lane: S^T[key = 4 fg + r][query = fr]
+            mx = xlane16_max(mx);
+            mx = xlane32_max(mx);
             float sum = 0.f;
-            half4v pf;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pv = exp2f((sc[r] - mx) * sl2e);
+                const float pv = exp2f((sc[i][r] - mx) * sl2e);
                 sum += pv;
-                pf[r] = (half_t)pv;
+                pf[i][r] = (half_t)pv;
             }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.0f / sum;
-            half_t* ob = outp + (int64_t)grow(pix * 16 + fr) * p.ldo + tile_n * 64;
+            sum = xlane16_sum(sum);
+            sum = xlane32_sum(sum);
+            inv[i] = 1.0f / sum;
+        }
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            half_t* ob = outp + (int64_t)grow(pixs[i] * 16 + fr) * p.ldo + tile_n * 64;
+            const bool live = wave + 8 * i < 20;               // (wave-uniform)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                half4v vf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) vf[j] = *reinterpret_cast<const half_t*>(base + (4 * fg + j) * pitch + (128 + dt * 16 + fr) * 2);
                 f32x4 o4 = {0.f, 0.f, 0.f, 0.f};
-                o4 = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, o4, 0, 0, 0);     // lane: O^T[d = 16 dt + 4 fg + r][query = fr]
+                o4 = __builtin_amdgcn_mfma_f32_16x16x16f16(vfr[i][dt], pf[i], o4, 0, 0, 0);     // lane: O^T[d = 16 dt + 4 fg + r][query = fr]
                 half4v h4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h4[r] = (half_t)(o4[r] * inv);
-                *reinterpret_cast<half4v*>(ob + dt * 16 + 4 * fg) = h4;
+                for (int r = 0; r < 4; ++r) h4[r] = (half_t)(o4[r] * inv[i]);
+                if (live) *reinterpret_cast<half4v*>(ob + dt * 16 + 4 * fg) = h4;
             }
         }
     } else if constexpr (SQ) {

@@ -22,7 +22,7 @@ LV = {0: (40, 64), 1: (20, 32), 2: (10, 16), 3: (5, 8)}
 FILTER = [a for a in sys.argv[1:]]
 
 
-def run(name, fn, flops, iters=20):
+def run(name, fn, flops, iters=int(os.environ.get("BG_ITERS", "20"))):
     if FILTER and not any(f in name for f in FILTER):
         return 0.0
     for _ in range(3):
@@ -107,6 +107,9 @@ def linear_res(lv, k, n):
 
 if __name__ == "__main__":
     ops.set_stream(None)
+    if os.environ.get("BG_PROBE") == "tattn":  # the fused q|k|v + temporal attention launches of the four levels
+        tattn(0, 320, 5); tattn(1, 640, 10); tattn(2, 1280, 20); tattn(3, 1280, 20)
+        sys.exit(0)
     if os.environ.get("BG_PROBE") == "1":     # shapes outside the UNet: what the persistent register-epilogue kernel (knob 7:2) does on short-K, HBM-bound linears
         for n in (256, 512):
             linear(0, 320, n); linear_res(0, 320, n); linear_res(0, 1280, n); linear_res(1, 640, n)
