@@ -7,7 +7,10 @@ rows = list(csv.DictReader(open(f)))
 grp, cnt = {}, {}
 for r in rows:
     n = r['Name']
-    if any(x in n for x in ('distribution_elementwise', 'rocclr', 'FillFunctor', 'direct_copy', 'float16_copy', 'CatArray', 'index_', 'arange', 'gather_kernel', 'reduce_kernel', 'AbsFunctor', 'CompareEq', 'MulFunctor', 'CUDAFunctorOnSelf')):
+    if 'splitk_gn' in n: k = 'splitk reduce + GroupNorm (one launch)'
+    elif 'splitk_reduce' in n: k = 'splitk_reduce'            # (before the torch filter below: its 'reduce_kernel' pattern matched this kernel until round 5)
+    elif 'gstat_accum' in n: k = 'statistics pass (virtual concat source)'
+    elif any(x in n for x in ('distribution_elementwise', 'rocclr', 'FillFunctor', 'direct_copy', 'float16_copy', 'CatArray', 'index_', 'arange', 'gather_kernel', 'reduce_kernel', 'AbsFunctor', 'CompareEq', 'MulFunctor', 'CUDAFunctorOnSelf')):
         k = 'torch(init/host glue)'
     elif 'gemm_w80s' in n and re.search(r'<\d, 3>|ELi3EEE', n): k = 'gemm_w80s 320x192 (q|k|v + temporal attention)'
     elif 'gemm_w80s' in n and re.search(r'<\d, 2>|ELi2EEE', n): k = 'gemm_w80s 256x256 (wide GEGLU)'
@@ -19,7 +22,6 @@ for r in rows:
     elif 'gemm_g4' in n: k = 'gemm_g4 (GEGLU K<=640)'
     elif 'gemm_glds' in n: k = 'gemm_glds (256xBN)'
     elif 'gemm_f16' in n: k = 'gemm_small'
-    elif 'splitk' in n: k = 'splitk_reduce'
     elif 'temporal_attention' in n: k = 'temporal_attn'
     elif 'attention_v4' in n: k = 'attention_v4 (long keys)'
     elif 'attention_short' in n: k = 'attention_short (77-token context)'
