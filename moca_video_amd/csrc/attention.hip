@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256, 2) void attention_short_kernel(
 //     unrolled over the two buffers); the staging pointers advance by one 64-bit add per tile.
 // What is left per element: 0.5 max3 + exp + 0.5 cvt_pk + 0.5 dot2.  121 VGPRs: four waves per SIMD.  Tiles, LDS images and fragment maps are those of attention_kernel.
 [[maybe_unused]] constexpr float LAZY_THR = 8.0f;
+[[maybe_unused]] constexpr float REF0_BAND = 6.0f;     // first-tile maxima inside [-6, 6] (in log2 units) leave the reference at 0
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void attention_v4_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; osum[r] = 0.f; negm[r] = 0.f; }
     float m_ref = 0.f;
+    bool ref_zero = true;      // (wave-uniform) no query of this wave has moved its reference off 0
     float lsum = 0.f;          // this lane's share of the row sum (its 32 of the 64 keys of every tile)
     half8v ones;
 #pragma unroll
@@ -484,24 +486,38 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void attention_v4_kernel(
     const int nkt = (Nk + KT - 1) / KT;
 
     // scores of one key tile: S'' = K.Q'^T - m_ref (the accumulator input of the first MFMA of each chain is -m_ref)
-    auto qk = [&](const char* kbuf, f32x16 (&s)[2]) {
+    auto qk = [&](const char* kbuf, f32x16 (&s)[2], auto zero_tag) {
+        constexpr bool ZERO_REF = decltype(zero_tag)::value != 0;    // the reference of every query of this wave is 0: the accumulator input is the inline constant
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const half8v kf = *reinterpret_cast<const half8v*>(kbuf + k_off[ks] + sub * 32 * ROWB);
-                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? negm : s[sub], 0, 0, 0);
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? (ZERO_REF ? zero16 : negm) : s[sub], 0, 0, 0);
             }
     };
     // one key tile (K and V in slot B): scores, lazy reference, exp2/pack in four 16-key groups each followed by its 3 MFMAs
     // (row sum + two O tiles), so a group's MFMAs run under the next group's exp2
     auto tile = [&](auto b_tag, f32x16 (&sc)[2], int kt) {
         constexpr int VB = decltype(b_tag)::value;
+        // Round 5: while the reference of every query of the wave is still 0 (`ref_zero`, wave-uniform) the score MFMAs take the inline
+        // constant 0 as their accumulator input and the 16 v_mov that rebuild the -m_ref operand per tile (64 of the tile's 960 issue-port
+        // cycles) are not executed.  The reference starts at 0 unless the first tile's maximum lies outside [-REF0_BAND, REF0_BAND] (then
+        // it is that maximum, as before) and moves, as before, when a tile maximum exceeds it by more than LAZY_THR: P <= 2^8 and the
+        // row's largest P >= 2^-REF0_BAND either way.
+#ifndef MOCA_ATTN_NO_ZERO_REF
+        if (ref_zero) {
+            qk(sK + VB * TILE, sc, int_c<1>{});
+        } else
+#endif
+        {
 #ifndef MOCA_ATTN_NEGM_PERSISTENT   // -m_ref rebuilt per tile (16 v_mov) instead of living across it: 141 -> 121 VGPRs = 4 waves per SIMD, +3.5 %
 #pragma unroll
-        for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
+            for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
 #endif
-        qk(sK + VB * TILE, sc);
+            qk(sK + VB * TILE, sc, int_c<0>{});
+        }
         if ((kt + 1) * KT > Nk) {                     // keys beyond Nk (last tile only)
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
@@ -524,8 +540,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void attention_v4_kernel(
         }
         float tmax = vmax3(vmax3(t4[0], t4[1], t4[2]), t4[3], t4[3]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));      // both key halves of this query: the two lanes agree from here on
-        if (kt == 0 || __any(tmax > LAZY_THR)) {      // move the reference (always on the first tile)
+        if (kt == 0 || __any(tmax > LAZY_THR)) {      // move the reference (first tile: to its maximum unless that lies in the zero band)
+#ifndef MOCA_ATTN_NO_ZERO_REF
+            const float delta = kt == 0 ? (fabsf(tmax) > REF0_BAND ? tmax : 0.f) : fmaxf(tmax, 0.f);
+#else
             const float delta = kt == 0 ? tmax : fmaxf(tmax, 0.f);
+#endif
             const float alpha = __builtin_amdgcn_exp2f(-delta);          // (kt == 0: O and l are still zero)
             m_ref += delta;
 #pragma unroll
@@ -537,6 +557,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 2) void attention_v4_kernel(
                 negm[r] = -m_ref;
 #endif
             }
+            ref_zero = !__any(m_ref != 0.f);
         }
         const char* vbuf = sV + VB * TILE;
 #pragma unroll

@@ -310,6 +310,35 @@ def test_attention_peaky():
     check(out, ref, TOL16, "attention peaky")
 
 
+@pytest.mark.parametrize("regime", ["low", "high", "late_peak", "mixed", "band_edge"])
+def test_attention_reference_regimes(regime):
+    """the long-key kernel keeps its softmax reference at 0 while every first-tile maximum of a wave lies inside [-6, 6] (log2 units)
+    and takes the score MFMAs' accumulator input from the inline constant; outside the band, or once a later tile exceeds the
+    reference by more than 8, it moves the reference as before.  Rows whose scores are all strongly negative / positive, a late
+    dominant key, both kinds of row in one wavefront, and first-tile maxima right at the band's edge."""
+    Bq, heads, Nq, Nk = 2, 2, 256, 512
+    q, k, v = rnd(Bq, Nq, heads * 64), rnd(Bq, Nk, heads * 64), rnd(Bq, Nk, heads * 64)
+    scale = 0.125
+    l2e = 1.4426950408889634
+    if regime in ("low", "high", "mixed", "band_edge"):
+        # shift every score of selected query rows by a constant: add c * u to q and make every key carry a component along u
+        u = torch.zeros(heads * 64, device=DEV)
+        u[0::64] = 1.0                                            # channel 0 of every head
+        k = k.clone(); k[..., 0::64] = 1.0
+        target = {"low": -14.0, "high": 11.0, "mixed": -14.0, "band_edge": 6.0}[regime]      # log2 units
+        shift = target / (scale * l2e)
+        rows = slice(None) if regime != "mixed" else slice(0, Nq, 3)
+        q = q.clone(); q[:, rows, 0::64] = shift
+    if regime == "late_peak":
+        k = k.clone(); k[:, 400] = q[:, 7] * 6.0                    # one key far above everything, six tiles in
+        k[:, 30] = q[:, 7] * 1.5
+    out = torch.empty(Bq, Nq, heads * 64, dtype=torch.float16, device=DEV)
+    ops.attention(q, k, v, out, Bq=Bq, heads=heads, Nq=Nq, Nk=Nk, ldq=heads * 64, ldk=heads * 64, ldv=heads * 64, ldo=heads * 64, kv_div=1, scale=scale)
+    sp = lambda t, n: t.float().view(Bq, n, heads, 64).permute(0, 2, 1, 3)
+    ref = sdpa_ref(sp(q, Nq), sp(k, Nk), sp(v, Nk), scale).permute(0, 2, 1, 3).reshape(Bq, Nq, heads * 64)
+    check(out, ref, TOL16, f"attention, reference regime {regime}")
+
+
 @pytest.mark.parametrize("B,T,HW,heads", [(2, 16, 50, 5), (1, 8, 64, 8), (1, 16, 2560, 5), (3, 5, 7, 2)])
 def test_temporal_attention(B, T, HW, heads):
     C = heads * 64
