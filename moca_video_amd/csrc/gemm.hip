@@ -434,6 +434,7 @@ __global__ __launch_bounds__(1024) void splitk_gn_kernel(const moca_gemm_params 
     const int N = p.N;
     const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
     const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
+    const float gm_t = tid < cpg ? gamma[g * cpg + tid] : 0.f, bt_t = tid < cpg ? beta[g * cpg + tid] : 0.f;   // (in flight under the slab loads)
     half8v v[CPT];
     int mrow[CPT], ccol[CPT];
     float s = 0.f, q = 0.f;
@@ -488,10 +489,9 @@ __global__ __launch_bounds__(1024) void splitk_gn_kernel(const moca_gemm_params 
         double var = b * inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const int c = g * cpg + tid;
-        const float sc = rstd * gamma[c];
+        const float sc = rstd * gm_t;
         s_sc[tid] = sc;
-        s_sh[tid] = beta[c] - (float)mean * sc;
+        s_sh[tid] = bt_t - (float)mean * sc;
     }
     __syncthreads();
 #pragma unroll

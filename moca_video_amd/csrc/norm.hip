@@ -214,6 +214,10 @@ __global__ void gn_apply_gstat_kernel(const half_t* __restrict__ x, half_t* __re
     int pp = p_begin + py;
     half8v cur[4], nxt[4];
     load4(cur, pp);
+    // (the affine parameters are fetched BEFORE the statistics hand-off: behind the barrier they were a third dependent round trip of
+    //  a block whose whole life is one batch of x -- profiles/r05_ab_gn_apply_prologue.txt)
+    const f32x4 gm0 = *reinterpret_cast<const f32x4*>(gamma + cx * 8), gm1 = *reinterpret_cast<const f32x4*>(gamma + cx * 8 + 4);
+    const f32x4 bt0 = *reinterpret_cast<const f32x4*>(beta + cx * 8), bt1 = *reinterpret_cast<const f32x4*>(beta + cx * 8 + 4);
     if (tid < GN_GROUPS) {
         const double a = moca_gstat_get(gstat + ((int64_t)sg * GN_GROUPS + tid) * 2, 0), b = moca_gstat_get(gstat + ((int64_t)sg * GN_GROUPS + tid) * 2 + 1, 1);
         const double mean = a * inv_count;
@@ -228,8 +232,8 @@ __global__ void gn_apply_gstat_kernel(const half_t* __restrict__ x, half_t* __re
     for (int j = 0; j < 8; ++j) {
         const int c = cx * 8 + j;
         const int g = c / cpg;
-        sc[j] = s_mr[2 * g + 1] * gamma[c];
-        sh[j] = beta[c] - s_mr[2 * g] * sc[j];
+        sc[j] = s_mr[2 * g + 1] * (j < 4 ? gm0[j & 3] : gm1[j & 3]);
+        sh[j] = (j < 4 ? bt0[j & 3] : bt1[j & 3]) - s_mr[2 * g] * sc[j];
     }
     auto norm8 = [&](const half8v& v) {
         half8v o;
@@ -342,6 +346,8 @@ __global__ void gn_apply_gstat_cat_kernel(const half_t* __restrict__ a, const ha
     int pp = p_begin + py;
     half8v cur[4], nxt[4];
     load4(cur, pp);
+    const f32x4 gm0 = *reinterpret_cast<const f32x4*>(gamma + cx * 8), gm1 = *reinterpret_cast<const f32x4*>(gamma + cx * 8 + 4);
+    const f32x4 bt0 = *reinterpret_cast<const f32x4*>(beta + cx * 8), bt1 = *reinterpret_cast<const f32x4*>(beta + cx * 8 + 4);
     if (tid < GN_GROUPS) {
         const int64_t* ga = gstat_cat + ((int64_t)sg * GN_GROUPS + tid) * 2;
         double sa = moca_gstat_get(ga, 0), sq = moca_gstat_get(ga + 1, 1);
@@ -365,8 +371,8 @@ __global__ void gn_apply_gstat_cat_kernel(const half_t* __restrict__ a, const ha
     for (int j = 0; j < 8; ++j) {
         const int c = cx * 8 + j;
         const int g = c / cpg;
-        sc[j] = s_mr[2 * g + 1] * gamma[c];
-        sh[j] = beta[c] - s_mr[2 * g] * sc[j];
+        sc[j] = s_mr[2 * g + 1] * (j < 4 ? gm0[j & 3] : gm1[j & 3]);
+        sh[j] = (j < 4 ? bt0[j & 3] : bt1[j & 3]) - s_mr[2 * g] * sc[j];
     }
     auto norm8 = [&](const half8v& v) {
         half8v o;
@@ -461,6 +467,7 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const half_t* __restrict__
     const int dr = 256 / vpr, dv = 256 % vpr;             // advancing a flat index by 256 = dr rows + dv vectors
     const int64_t base = (int64_t)sg * R * C + g * cpg;
     const half_t* xs = x + base;
+    const float gm_t = tid < cpg ? gamma[g * cpg + tid] : 0.f, bt_t = tid < cpg ? beta[g * cpg + tid] : 0.f;   // (in flight under the statistics pass)
     // ---- pass 1: sum / sum of squares of the whole slab ----
     float s = 0.f, q = 0.f;
     {
@@ -484,10 +491,9 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const half_t* __restrict__
         double var = b * inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const int c = g * cpg + tid;
-        const float sc = rstd * gamma[c];
+        const float sc = rstd * gm_t;
         s_sc[tid] = sc;
-        s_sh[tid] = beta[c] - (float)mean * sc;
+        s_sh[tid] = bt_t - (float)mean * sc;
     }
     __syncthreads();
     // ---- pass 2: normalise rows [r0, r1) of the slab ----
@@ -528,6 +534,7 @@ __global__ __launch_bounds__(1024) void gn_slab_reg_kernel(const half_t* __restr
     const int slab = blockIdx.x, sg = slab / GN_GROUPS, g = slab % GN_GROUPS;
     const int vpr = cpg / 8, nchunks = R * vpr;
     const int64_t base = (int64_t)sg * R * C + g * cpg;
+    const float gm_t = tid < cpg ? gamma[g * cpg + tid] : 0.f, bt_t = tid < cpg ? beta[g * cpg + tid] : 0.f;   // (in flight under the slab's loads)
     half8v v[CPT];
     int off[CPT];
     float s = 0.f, q = 0.f;
@@ -557,10 +564,9 @@ __global__ __launch_bounds__(1024) void gn_slab_reg_kernel(const half_t* __restr
         double var = b * inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const int c = g * cpg + tid;
-        const float sc = rstd * gamma[c];
+        const float sc = rstd * gm_t;
         s_sc[tid] = sc;
-        s_sh[tid] = beta[c] - (float)mean * sc;
+        s_sh[tid] = bt_t - (float)mean * sc;
     }
     __syncthreads();
 #pragma unroll
