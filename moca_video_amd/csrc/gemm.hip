@@ -545,6 +545,16 @@ __device__ unsigned long long g_stamps[STAMP_BLOCKS * STAMP_SLOTS];
             g_stamps[blockIdx.x * STAMP_SLOTS + (k)] = t__;                                        \
         }                                                                                          \
     } while (0)
+#define MOCA_STAMP_P(k, dep)                                                                       \
+    do {                                                                                           \
+        int dep__ = (dep);                                                                         \
+        asm volatile("" : "+v"(dep__));                                                            \
+        if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {                                       \
+            unsigned long long t__;                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
+            g_stamps[blockIdx.x * STAMP_SLOTS + (k)] = t__ + (dep__ & 0);                          \
+        }                                                                                          \
+    } while (0)
 #define MOCA_STAMP_HW()                                                                            \
     do {                                                                                           \
         if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS) {                                       \
@@ -557,6 +567,7 @@ __device__ unsigned long long g_stamps[STAMP_BLOCKS * STAMP_SLOTS];
     } while (0)
 #else
 #define MOCA_STAMP(k) do {} while (0)
+#define MOCA_STAMP_P(k, dep) do {} while (0)
 #define MOCA_STAMP_HW() do {} while (0)
 #endif
 
@@ -1243,6 +1254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int m0 = tile_m * TM, n0 = tile_n * BN;
     const int nk = kt_end - kt_begin;
+    MOCA_STAMP_P(8, m0 + n0 + nk);
 
     const half_t* __restrict__ Wptr = reinterpret_cast<const half_t*>(p.w);
 
@@ -1255,6 +1267,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     AGather<AMODE, FAST, 4, BK> ga(p, lch);
 #pragma unroll
     for (int g = 0; g < 4; ++g) ga.init_row(g, m0 + (g * 8 + wave) * 8 + lrow);
+    MOCA_STAMP_P(9, (int)ga.row_ok[0]);
     // W rows of this lane: group q = g*8 + wave (valid while q < B_GROUPS)
     const half_t* w_row[3];
 #pragma unroll
@@ -1336,7 +1349,9 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
 
     LnFoldRaw lraw = {float2{0.f, 0.f}, float2{0.f, 0.f}, 0.f, 0.f};
     if (p.flags & MOCA_EP_LNFOLD) lraw = lnfold_issue<TM, BN>(p, m0 + tid, n0, tid);
+    MOCA_STAMP_P(10, a_row_b[0] + b_row_b[0]);
     if (nk > 0) issue(kt_begin, 0);
+    MOCA_STAMP_P(11, 0);
     if (nk > 1) issue(kt_begin + 1, 1);
     LnFoldRegs lf = {0.f, 0.f, 0.f, 0.f};
     if (p.flags & MOCA_EP_LNFOLD) lf = lnfold_finish<TM, BN>(p, lraw, m0 + tid, tid);

@@ -17,6 +17,7 @@ shapes = {"qkv0": lambda: B.linear(0, 320, 960), "geglu0": lambda: B.linear(0, 3
           "conv2": lambda: B.conv(2, 1280, 1280), "conv1": lambda: B.conv(1, 640, 640), "qkv1": lambda: B.linear(1, 640, 1920),
           "geglu1": lambda: B.linear(1, 640, 2560, geglu=True), "linres0": lambda: B.linear_res(0, 320, 320),
           "ff2res0": lambda: B.linear_res(0, 1280, 320), "tconv0": lambda: B.tconv(0, 320),
+          "tconv3": lambda: B.tconv(3, 1280), "conv3": lambda: B.conv(3, 1280, 1280), "tconv2": lambda: B.tconv(2, 1280), "lin3": lambda: B.linear(3, 5120, 1280),
           "tattn0": lambda: B.tattn(0, 320, 5), "tattn1": lambda: B.tattn(1, 640, 10), "tattn2": lambda: B.tattn(2, 1280, 20)}
 dt = shapes[which]()
 torch.cuda.synchronize()
@@ -28,13 +29,17 @@ NS = int(os.environ.get('STAMP_SLOTS', '16'))
 buf = np.zeros((nb, NS), dtype=np.uint64)
 assert lib.moca_debug_stamps(buf.ctypes.data_as(C.c_void_p), nb) == 0
 ok = buf[:, 5] > 0
+LAST = 5
+if ok.sum() == 0:                      # split-K blocks leave through the fp32 slab store before stamps 4 / 5: report up to the end of the main loop
+    ok = buf[:, 3] > 0
+    LAST = 3
 s = buf[ok].astype(np.int64)
-print("blocks stamped:", ok.sum())
+print("blocks stamped:", ok.sum(), "(split-K: prologue and main loop only)" if LAST == 3 else "")
 tick_us = 1.0           # s_memtime ticks are SHADER cycles on gfx950 (MI355X_MICROARCH.md): everything below is printed in cycles
-span = float(s[:, 5].max() - s[:, 0].min())
+span = float(s[:, LAST].max() - s[:, 0].min())
 print(f"kernel span from stamps: {span:.0f} cycles; host-timed {dt*1e6:.1f} us -> {span / (dt * 1e9):.2f} GHz if the span covers the launch")
 names = ["start->issued", "issued->tile0 landed", "main loop", "stage1+sync", "stage2 (stores)"]
-for i, n in enumerate(names):
+for i, n in enumerate(names[:LAST]):
     d = (s[:, i + 1] - s[:, i]) * tick_us
     print(f"{n:24s} mean {d.mean():8.0f} cyc  p50 {np.median(d):8.0f}  p90 {np.percentile(d, 90):8.0f}")
 if NS > 8 and (s[:, 15] > 0).any():
@@ -47,7 +52,11 @@ if NS > 8 and (s[:, 15] > 0).any():
         for n, a, b in (("MFMAo", 15, 1), ("barrier", 1, 2)):
             d = (ss[:, b] - ss[:, a]).astype(np.float64)
             print(f"   seg {n:20s} mean {d.mean():8.0f} cyc  p50 {np.median(d):8.0f}  p90 {np.percentile(d, 90):8.0f}")
-tot = (s[:, 5] - s[:, 0]) * tick_us
+if (s[:, 11] > 0).all() and (s[:, 8] > 0).all() and (s[:, 8] < s[:, 1]).all():       # glds prologue stamps (8..11)
+    for n, a, b in (("  start->tile coords", 0, 8), ("  ->row descriptors", 8, 9), ("  ->W rows, frag offsets", 9, 10), ("  ->first k-tile issued", 10, 11), ("  ->second issued", 11, 1)):
+        d = (s[:, b] - s[:, a]).astype(np.float64)
+        print(f"{n:24s} mean {d.mean():8.0f} cyc  p50 {np.median(d):8.0f}  p90 {np.percentile(d, 90):8.0f}")
+tot = (s[:, LAST] - s[:, 0]) * tick_us
 print(f"{'block total':24s} mean {tot.mean():8.0f} cyc")
 # gaps between consecutive blocks on the same CU
 cu = (s[:, 7] << 16) | (s[:, 6] & 0xFF00) | ((s[:, 6] >> 13) & 7) << 4   # xcc, cu_id/sh, se
@@ -55,6 +64,6 @@ gaps = []
 for c in np.unique(cu):
     r = s[cu == c]
     r = r[np.argsort(r[:, 0])]
-    gaps += list((r[1:, 0] - r[:-1, 5]) * tick_us)
+    gaps += list((r[1:, 0] - r[:-1, LAST]) * tick_us)
 gaps = np.array(gaps) if len(gaps) else np.zeros(1)
 print(f"CUs seen {len(np.unique(cu))}; gap end(prev)->start(next) on a CU: mean {gaps.mean():.0f} cyc  p50 {np.median(gaps):.0f}  p90 {np.percentile(gaps,90):.0f}")
