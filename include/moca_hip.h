@@ -450,7 +450,8 @@ int moca_event_destroy(void* ev);
 #define MOCA_TUNE_GEMM_MF32  6   /* MFMA shape of the persistent kernel: 0 v_mfma_f32_16x16x32_f16, 1 v_mfma_f32_32x32x16_f16                          */
 #define MOCA_TUNE_GEMM_SQP   7   /* persistent 256 x 256 kernel (register epilogue): 0 never, 1 GEGLU linears, 2 every linear it can run               */
 #define MOCA_TUNE_SQP_WALK   8   /* tile walk of the persistent 256 x 256 kernel: 0 strided over the XCD's blocks, 1 a contiguous range per block           */
-#define MOCA_TUNE_COUNT      9
+#define MOCA_TUNE_SLAB_F16   9   /* split-K partial slabs of the 256-row kernel: 0 fp32, 1 fp16 (A/B of VERDICT r4 #5's candidate; changes results within the fp16 tolerance) */
+#define MOCA_TUNE_COUNT      10
 int moca_set_tuning(int32_t knob, int32_t value);
 
 /* device query: returns 0 and fills name[len] / cu count, or MOCA_E_NODEVICE */

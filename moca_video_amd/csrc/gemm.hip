@@ -386,11 +386,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const moca_gemm_para
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = p.bias ? p.bias[col + j] : 0.f;
-            for (int s = 0; s < p.splits; ++s) {
-                const float* w = p.splitk_ws + ((int64_t)s * p.M + m) * p.N + col;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(w), a1 = *reinterpret_cast<const f32x4*>(w + 4);
+            if (p.reserved4_ & 4) {                               // fp16 slabs (MOCA_TUNE_SLAB_F16)
+                for (int s = 0; s < p.splits; ++s) {
+                    const half8v a = *reinterpret_cast<const half8v*>(reinterpret_cast<const half_t*>(p.splitk_ws) + ((int64_t)s * p.M + m) * p.N + col);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] += a0[j]; v[4 + j] += a1[j]; }
+                    for (int j = 0; j < 8; ++j) v[j] += (float)a[j];
+                }
+            } else {
+                for (int s = 0; s < p.splits; ++s) {
+                    const float* w = p.splitk_ws + ((int64_t)s * p.M + m) * p.N + col;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(w), a1 = *reinterpret_cast<const f32x4*>(w + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] += a0[j]; v[4 + j] += a1[j]; }
+                }
             }
         }
         if (rowadd) {
@@ -452,11 +460,19 @@ __global__ __launch_bounds__(1024) void splitk_gn_kernel(const moca_gemm_params 
             float a[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = p.bias ? p.bias[col + j] : 0.f;
-            for (int sp = 0; sp < p.splits; ++sp) {
-                const float* w = p.splitk_ws + ((int64_t)sp * p.M + m) * N + col;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(w), a1 = *reinterpret_cast<const f32x4*>(w + 4);
+            if (p.reserved4_ & 4) {                               // fp16 slabs (MOCA_TUNE_SLAB_F16)
+                for (int sp = 0; sp < p.splits; ++sp) {
+                    const half8v h = *reinterpret_cast<const half8v*>(reinterpret_cast<const half_t*>(p.splitk_ws) + ((int64_t)sp * p.M + m) * N + col);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { a[j] += a0[j]; a[4 + j] += a1[j]; }
+                    for (int j = 0; j < 8; ++j) a[j] += (float)h[j];
+                }
+            } else {
+                for (int sp = 0; sp < p.splits; ++sp) {
+                    const float* w = p.splitk_ws + ((int64_t)sp * p.M + m) * N + col;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(w), a1 = *reinterpret_cast<const f32x4*>(w + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { a[j] += a0[j]; a[4 + j] += a1[j]; }
+                }
             }
             if (rowadd) {
                 const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
@@ -1411,6 +1427,28 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
     // of tile (mt, nt) is row m = wave_m*64 + mt*16 + fr, column n = wave_n*BN/2 + nt*16 + 4*fg + r:
     // each lane owns 4 CONSECUTIVE output columns of one row -> 8-byte fp16 / 16-byte fp32 accesses.
     if (p.splits > 1) {
+        if (p.reserved4_ & 4) {
+            // fp16 slabs (MOCA_TUNE_SLAB_F16, A/B only): the partial tile is rounded to fp16, staged like the fp16 epilogue and leaves as whole rows
+            constexpr int pitch16 = BN * 2 + 16;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = wave_n * (BN / 2) + nt * 16 + 4 * fg;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int row = wave_m * 64 + mt * 16 + fr;
+                    *reinterpret_cast<half4v*>(smem + row * pitch16 + col * 2) = __builtin_convertvector(acc[mt][nt], half4v);
+                }
+            }
+            __syncthreads();
+            half_t* ws16 = reinterpret_cast<half_t*>(p.splitk_ws) + (int64_t)split * p.M * p.N;
+            constexpr int cpr = BN / 8;
+            for (int idx = tid; idx < TM * cpr; idx += 512) {
+                const int row = idx / cpr, ch = idx - row * cpr;
+                const int m = m0 + row;
+                if (m < p.M) *reinterpret_cast<half8v*>(ws16 + (int64_t)m * p.N + n0 + ch * 8) = *reinterpret_cast<const half8v*>(smem + row * pitch16 + ch * 16);
+            }
+            return;
+        }
         float* ws = p.splitk_ws + (int64_t)split * p.M * p.N;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -3639,6 +3677,10 @@ extern "C" int moca_gemm_ln_ok(const moca_gemm_params* pp) {
     return takes_w80t_ln(p) ? 1 : 0;
 }
 
+// fp16 split-K slabs (MOCA_TUNE_SLAB_F16): a split-K call of the 256-row kernel with an fp16 output and no GEGLU
+static bool slab_f16(const moca_gemm_params& p) {
+    return moca_tuning_get(MOCA_TUNE_SLAB_F16) && p.splits > 1 && !(p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32)) && takes_glds_bn(p) != 0;
+}
 // can moca_gemm_splitk_groupnorm_f16 finish this (validated, split-normalised) MOCA_EP_SLABS call?  fp16 plain epilogue, one block per
 // (statistics group, channel group) slab with the slab in registers
 static bool splitk_gn_ok(const moca_gemm_params& p, int HW, int fps) {
@@ -3662,6 +3704,7 @@ extern "C" int moca_gemm_splitk_groupnorm_f16(const moca_gemm_params* pp, void* 
     if (p.ldo % 8 || (p.residual && p.ldr % 8) || (p.rowadd && (p.ld_rowadd % 8 || p.rowadd_div <= 0))) return MOCA_E_BADARG;
     normalise_splits(p);
     if (!splitk_gn_ok(p, HW, frames_per_stat)) return MOCA_E_BADARG;
+    p.reserved4_ = slab_f16(p) ? 4 : 0;
     const int cpg = p.N / 32, R = HW * frames_per_stat;
     const int nchunks = R * (cpg / 8);
     const int cpt = (nchunks + 1023) / 1024;
@@ -3752,6 +3795,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     p.reserved4_ = 0;                                 // (bits 8.. carry the XCD partition chosen by the launcher)
     // bit 0: output rows leave with non-temporal stores when the output is at least half the 256 MiB Infinity Cache (see out_streams)
     if ((int64_t)p.M * (geglu ? p.N / 2 : p.N) * 2 >= (128ll << 20)) p.reserved4_ |= 1;
+    if (slab_f16(p)) p.reserved4_ |= 4;               // bit 2: fp16 split-K slabs (MOCA_TUNE_SLAB_F16; the 256-row kernel only)
     if (p.flags & MOCA_EP_TATTN) {                    // ask moca_gemm_tattn_ok() first
         if (!tattn_ok(p) || ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1))) return MOCA_E_BADARG;
         return launch_gemm_w80s<MOCA_A_LINEAR, 3>(p, st);
