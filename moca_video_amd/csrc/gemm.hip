@@ -1450,16 +1450,25 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
             return;
         }
         float* ws = p.splitk_ws + (int64_t)split * p.M * p.N;
+        // the fp32 partial tile is staged in LDS and leaves as whole 4 BN-byte rows (round 5: straight from registers it left as 64-byte
+        // segments, 16 rows x 4 lanes per instruction -- 1.2-1.4 us slower per launch at the 5 x 8-latent level, profiles/r05_ab_slab_store.txt)
+        float* sC = reinterpret_cast<float*>(smem);
+        constexpr int PF = BN == 128 ? BN + 4 : BN;           // floats per staged row (+16 B where the 160 KiB allow it: BN = 160 fills them)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int row = m0 + wave_m * 64 + mt * 16 + fr;
-            if (row < p.M) {
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = wave_n * (BN / 2) + nt * 16 + 4 * fg;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int col = n0 + wave_n * (BN / 2) + nt * 16 + 4 * fg;
-                    *reinterpret_cast<f32x4*>(ws + (int64_t)row * p.N + col) = acc[mt][nt];
-                }
+            for (int mt = 0; mt < 4; ++mt) {
+                const int row = wave_m * 64 + mt * 16 + fr;
+                *reinterpret_cast<f32x4*>(sC + row * PF + col) = acc[mt][nt];
             }
+        }
+        __syncthreads();
+        constexpr int cpr4 = BN / 4;
+        for (int idx = tid; idx < TM * cpr4; idx += 512) {
+            const int row = idx / cpr4, ch = idx - row * cpr4;
+            const int m = m0 + row;
+            if (m < p.M) *reinterpret_cast<f32x4*>(ws + (int64_t)m * p.N + n0 + ch * 4) = *reinterpret_cast<const f32x4*>(sC + row * PF + ch * 4);
         }
         return;
     }
