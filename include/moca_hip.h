@@ -156,9 +156,6 @@ int moca_gemm_f16(const moca_gemm_params* p, void* stream);
  * direct-to-LDS kernel), or 0 when this call cannot produce column sums (split-K, GEGLU, fp32 output, small tiles ...).
  * The GroupNorm that consumes the sums (moca_groupnorm_colsum_f16) needs (frames_per_stat * H*W) % rows == 0.        */
 int moca_gemm_colsum_rows(const moca_gemm_params* p);
-/* MOCA_EP_GSTAT on a SPLIT-K call: the reduce launch finishes the statistics (8 rows x 320 columns per block); returns 8 when this call
- * can (plain fp16 epilogue, N % 320 == 0, N / 32 a multiple of 8 dividing 320, M % 8 == 0; gstat_rows % 8 == 0 is then required), else 0 */
-int moca_gemm_gstat_reduce_rows(const moca_gemm_params* p);
 /* 1 when this call can also produce the LayerNorm of its output rows (MOCA_EP_LN): a plain linear with N == 320 (a block of
  * the 160 x 320 tiling owns complete rows), fast gather, no split-K, enough rows to fill the chip; else 0.               */
 int moca_gemm_ln_ok(const moca_gemm_params* p);

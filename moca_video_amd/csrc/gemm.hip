@@ -424,62 +424,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const moca_gemm_para
     }
 }
 
-// ---- split-K reduce that also FINISHES the GroupNorm statistics of its output (MOCA_EP_GSTAT on a split-K call; round 5): the 16-frame
-// GroupNorms of the temporal convs at the 5 x 8-latent level then take the one-launch `gstat` apply instead of the 64-block slab kernel.
-// Block = 8 rows x 320 columns (thread = one 16-byte output chunk: row t / 40, chunk t % 40), epilogue as splitk_reduce_kernel; the
-// block adds its sums / sums of squares (of the fp32 values, as the store-loop epilogues do) per GroupNorm channel group through LDS and
-// issues one fixed-point atomic per (group, component): N % 320 == 0, (N / 32) % 8 == 0, gstat_rows % 8 == 0 (host-checked).
-__global__ __launch_bounds__(320) void splitk_reduce_gstat_kernel(const moca_gemm_params p) {
-    __shared__ float s_red[320][2];
-    const int t = threadIdx.x;
-    const int m = blockIdx.y * 8 + t / 40, col = blockIdx.x * 320 + (t % 40) * 8;
-    const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
-    const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = p.bias ? p.bias[col + j] : 0.f;
-    if (p.reserved4_ & 4) {
-        for (int sp = 0; sp < p.splits; ++sp) {
-            const half8v a = *reinterpret_cast<const half8v*>(reinterpret_cast<const half_t*>(p.splitk_ws) + ((int64_t)sp * p.M + m) * p.N + col);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += (float)a[j];
-        }
-    } else {
-        for (int sp = 0; sp < p.splits; ++sp) {
-            const float* w = p.splitk_ws + ((int64_t)sp * p.M + m) * p.N + col;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(w), a1 = *reinterpret_cast<const f32x4*>(w + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] += a0[j]; v[4 + j] += a1[j]; }
-        }
-    }
-    if (rowadd) {
-        const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-    }
-    if (resid) {
-        const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-    }
-    half8v h;
-    float sm = 0.f, sq = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { h[j] = (half_t)v[j]; sm += v[j]; sq += v[j] * v[j]; }
-    *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
-    s_red[t][0] = sm; s_red[t][1] = sq;
-    __syncthreads();
-    const int cpg = p.N / 32, gpb = 320 / cpg, cpc = cpg / 8;     // groups per block, chunks per group
-    if (t < 2 * gpb) {
-        const int g = t >> 1, comp = t & 1;
-        float a = 0.f;
-        for (int r = 0; r < 8; ++r)
-            for (int c = 0; c < cpc; ++c) a += s_red[r * 40 + g * cpc + c][comp];
-        const int sg = (blockIdx.y * 8) / p.gstat_rows;
-        moca_gstat_add(p.gstat + ((int64_t)sg * 32 + blockIdx.x * gpb + g) * 2 + comp, comp, a);
-    }
-}
-
 // ---- split-K reduce + the GroupNorm(+SiLU) that consumes the result, in ONE launch (moca_gemm_splitk_groupnorm_f16): at the
 // 5 x 8-latent level (M = 1280 at B = 2: 50 tiles per launch, every conv / temporal conv runs split-K) a ResBlock is a chain of
 // GEMM -> reduce -> GroupNorm launches of 5-9 us each on tensors of 3 MB.  One block per (statistics group, channel group) slab, as
@@ -3645,20 +3589,6 @@ static int takes_glds_bn(const moca_gemm_params& p) {
     if (big_bn == 128 && use_g4) return 0;
     return big_bn;
 }
-// MOCA_EP_GSTAT on a split-K call: the reduce launch finishes the statistics (splitk_reduce_gstat_kernel: 8 rows x 320 columns per block);
-// 0 = this call cannot (plain fp16 epilogue only, default grouping)
-static int gstat_reduce_rows(const moca_gemm_params& p) {
-    if (p.splits < 2 || (p.flags & ~MOCA_EP_GSTAT) || p.N % 320 || p.N % 32 || (p.N / 32) % 8 || 320 % (p.N / 32) || p.M % 8 || p.up_phase || p.gstat_cpg || p.gstat_coff) return 0;
-    return 8;
-}
-extern "C" int moca_gemm_gstat_reduce_rows(const moca_gemm_params* pp) {
-    if (!pp) return 0;
-    moca_gemm_params p = *pp;
-    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
-    normalise_splits(p);
-    p.flags |= MOCA_EP_GSTAT;
-    return gstat_reduce_rows(p);
-}
 // rows per tile of the column sums a MOCA_EP_COLSUM launch leaves behind (0: this call cannot): 320 / 160 on the staggered kernel,
 // 256 on the 256-row kernel (fp16 output, no GEGLU, no split-k)
 static int colsum_rows(const moca_gemm_params& p) {
@@ -3866,7 +3796,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     if ((p.flags & MOCA_EP_COLSUM) && !(p.colsum && colsum_rows(p) != 0)) return MOCA_E_BADARG;   // ask moca_gemm_colsum_rows() first
     if ((p.flags & MOCA_EP_LN) && !(p.ln_gamma && p.ln_beta && p.ln_out && p.ld_ln % 8 == 0 && takes_w80t_ln(p))) return MOCA_E_BADARG;   // ask moca_gemm_ln_ok() first
     if (p.flags & MOCA_EP_GSTAT) {                    // same kernels as MOCA_EP_COLSUM; a row tile must lie inside one statistics group
-        const int rows = p.splits > 1 ? gstat_reduce_rows(p) : colsum_rows(p);      // (split-K: the reduce launch accumulates them, 8 rows per block)
+        const int rows = colsum_rows(p);
         if (!(p.gstat && rows != 0 && !(p.flags & MOCA_EP_COLSUM) && p.gstat_rows > 0 && p.gstat_rows % rows == 0 && p.M % p.gstat_rows == 0 &&
               (p.gstat_cpg > 0 ? (p.gstat_coff + p.N - 1) / p.gstat_cpg < 32 : (p.N % 32 == 0 && p.gstat_coff == 0)))) return MOCA_E_BADARG;
     }
@@ -3917,8 +3847,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
         const int64_t total = (int64_t)p.M * (out_n / 8);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        if (p.flags & MOCA_EP_GSTAT) hipLaunchKernelGGL(splitk_reduce_gstat_kernel, dim3(p.N / 320, p.M / 8), dim3(320), 0, st, p);
-        else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
         MOCA_CHECK_LAUNCH();
     }
     return MOCA_OK;

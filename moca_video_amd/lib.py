@@ -79,7 +79,6 @@ SIGNATURES = {
     "moca_gemm_f16": (C.c_int, [C.POINTER(GemmParams), _vp]),
     "moca_gemm_splitk_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "moca_gemm_colsum_rows": (C.c_int, [C.POINTER(GemmParams)]),
-    "moca_gemm_gstat_reduce_rows": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_ln_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_rowsum_cols": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_lnfold_ok": (C.c_int, [C.POINTER(GemmParams)]),

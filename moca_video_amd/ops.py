@@ -275,13 +275,6 @@ def gemm_splitk_groupnorm(a, pw: PackedWeight, out, y, gamma, beta, *, HW, frame
     return y
 
 
-def gemm_gstat_reduce_rows(a, pw: PackedWeight, **kw):
-    """rows per block of the statistics a SPLIT-K call's reduce launch can finish (MOCA_EP_GSTAT with splits > 1), 0 if it cannot"""
-    kw = {k: v for k, v in kw.items() if k not in ("gstat", "colsum", "prefetch", "slabs")}
-    p = _gemm_params(a, pw, None, **kw)
-    return int(_l.load().moca_gemm_gstat_reduce_rows(C.byref(p)))
-
-
 def gemm_cat_ok(a, pw: PackedWeight, **kw):
     """can this linear read its A operand from two sources (a2 = (second source, columns of the first): the virtual torch.cat)?"""
     p = _gemm_params(a, pw, None, **kw)

@@ -64,7 +64,6 @@ VIRTUAL_CAT = os.environ.get("MOCA_VCAT", "1") != "0"
 # split-K reduce inside the GroupNorm that consumes it (the 5 x 8-latent level of the B = 2 forward; A/B switch MOCA_SKGN=0)
 SPLITK_GN = os.environ.get("MOCA_SKGN", "1") != "0"
 SPLITK_GN_ALL = os.environ.get("MOCA_SKGN", "1") == "2"     # (A/B: also the 16-frame GroupNorms of the temporal convs)
-REDUCE_GSTAT = os.environ.get("MOCA_RGSTAT", "1") != "0"    # (A/B: the split-K reduce finishes the statistics of the 16-frame GroupNorms)
 
 
 class _LNRef:
@@ -251,17 +250,6 @@ class _PlanBase:
                 self.pool.put(wsk)
                 return y
             self.pool.put(wsk)
-            # statistics over several frames (the temporal convs' GroupNorms): the producer's REDUCE launch finishes them and this
-            # GroupNorm is the one-launch apply (the 64-block slab kernel otherwise; profiles/r05_ab_reduce_gstat.txt)
-            rows = ops.gemm_gstat_reduce_rows(prod.args[0], prod.args[1], **kw) if (SPLITK_GN and REDUCE_GSTAT) else 0
-            if rows > 0 and (fps * fm.H * fm.W) % rows == 0 and fm.C % 32 == 0:
-                slot = self._gstat_slot((fm.F // fps) * 64)
-                kw["gstat"] = (slot, fps * fm.H * fm.W)
-                self.steps[src] = functools.partial(prod.func, *prod.args, **kw)
-                y = self.pool.get(fm.M, fm.C)
-                self._emit(ops.groupnorm_gstat, fm.buf, y, gb[0], gb[1], slot, F=fm.F, HW=fm.H * fm.W, Cn=fm.C, frames_per_stat=fps,
-                           eps=eps, silu=silu)
-                return y
         y = self.pool.get(fm.M, fm.C)
         HW = fm.H * fm.W
         ws = self.pool.get(1, ops.groupnorm_ws_floats(fm.F, HW, fm.C), torch.float32)

@@ -780,39 +780,6 @@ def test_gemm_splitk_groupnorm(Fr, HW, fps, mode, splits, res, radd):
         ops.gemm(a, pw, x0, slabs=True, **kw1)
 
 
-@pytest.mark.parametrize("Fr,HW,fps,mode,splits,res", [(32, 40, 16, "tconv", 4, False), (32, 40, 16, "conv", 5, True), (32, 40, 1, "tconv", 4, True)])
-def test_gemm_splitk_reduce_gstat(Fr, HW, fps, mode, splits, res):
-    """MOCA_EP_GSTAT on a split-K call: the reduce launch finishes the consumer GroupNorm's statistics -- same output as the plain
-    split-K call, statistics = those of the stored values, and the one-launch GroupNorm on them against torch"""
-    C, N, M = 1280, 1280, Fr * HW
-    if mode == "tconv":
-        a, K, kw = rnd(M, C), 3 * C, dict(mode=L.MOCA_A_TCONV3, tconv=(C, 16, HW))
-        pw = ops.pack_tconv3(rnd(N, C, 3, 1, 1, scale=K ** -0.5), rnd(N, dtype=torch.float32))
-    else:
-        a, K, kw = rnd(M, C), 9 * C, dict(mode=L.MOCA_A_CONV3X3, conv=(C, 5, 8, 5, 8, 1, 0))
-        pw = ops.pack_conv3x3(rnd(N, C, 3, 3, scale=K ** -0.5), rnd(N, dtype=torch.float32))
-    r = rnd(M, N) if res else None
-    kw.update(M=M, splits=splits, residual=r)
-    ws = torch.empty(splits * M * N, dtype=torch.float32, device=DEV)
-    x0 = torch.empty(M, N, dtype=torch.float16, device=DEV)
-    ops.gemm(a, pw, x0, splitk_ws=ws, **kw)
-    assert ops.gemm_gstat_reduce_rows(a, pw, splitk_ws=ws, **kw) == 8
-    gst = torch.zeros((Fr // fps) * 64, dtype=torch.int64, device=DEV)
-    x1 = torch.empty_like(x0)
-    ops.gemm(a, pw, x1, splitk_ws=ws, gstat=(gst, fps * HW), **kw)
-    assert torch.equal(x1, x0)
-    acc = torch.zeros_like(gst)
-    ops.gstat_accum(x0, acc, F=Fr, HW=HW, Cn=N, frames_per_stat=fps, cpg=N // 32, coff=0)
-    sc = torch.tensor([2.0 ** -30, 2.0 ** -16], dtype=torch.float64, device=DEV)
-    assert relerr(gst.view(-1, 32, 2).double() * sc, acc.view(-1, 32, 2).double() * sc) < 2e-3
-    g, be = rnd(N, dtype=torch.float32) * 0.2 + 1.0, rnd(N, dtype=torch.float32) * 0.2
-    y = torch.empty_like(x0)
-    ops.groupnorm_gstat(x1, y, g, be, gst, F=Fr, HW=HW, Cn=N, frames_per_stat=fps, eps=1e-5, silu=True)
-    xr = x0.float().view(Fr // fps, fps * HW, N).permute(0, 2, 1)
-    ref = F.silu(F.group_norm(xr, 32, g, be, 1e-5)).permute(0, 2, 1).reshape(M, N)
-    check(y, ref, TOL16, "GroupNorm on the statistics of the split-K reduce")
-
-
 # ---------------------------------------------------------------- the virtual torch.cat of the output blocks (openaimodel3d.py:571)
 @pytest.mark.parametrize("M,C1,C2,N,res", [(81920, 640, 320, 320, False), (81920, 320, 320, 320, True), (20480, 1280, 640, 640, False),
                                            (20480, 640, 320, 640, True), (20000, 640, 640, 640, False), (40960, 512, 256, 320, False)])
