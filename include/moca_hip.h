@@ -143,11 +143,6 @@ typedef struct moca_gemm_params {
     int32_t     gstat_cpg; /* MOCA_EP_GSTAT: columns per GroupNorm channel group (0 = N / 32) and the channel index of column 0 inside the   */
     int32_t     gstat_coff;/* consumer's tensor (0): a producer whose output is ONE SOURCE of a virtual concat accumulates the statistics of  */
                            /* the concat's groups, group (gstat_coff + n) / gstat_cpg (< 32), straight into the concat's accumulators        */
-    int32_t*    sk_counters;/* optional, split-K only: 4096 int32, ZERO before first use (they reset themselves): lets the split blocks of a  */
-                           /* tile meet inside the launch and finish the reduce themselves, each one its share of the tile's rows -- no reduce */
-                           /* launch, same results bit for bit.  Used where it applies (the 256-row kernel, plain fp16 epilogue, <= 248 blocks: */
-                           /* every block must be resident at once); ignored elsewhere.  One buffer per stream of launches.  [4095] is set to 1 */
-                           /* if a block ever gave up waiting for its siblings (results of that launch are then wrong).                       */
 } moca_gemm_params;
 
 /* Replaces F.conv2d 3x3 (openaimodel3d.py:152,177,66-70,96-106,376,531),
@@ -456,8 +451,7 @@ int moca_event_destroy(void* ev);
 #define MOCA_TUNE_GEMM_SQP   7   /* persistent 256 x 256 kernel (register epilogue): 0 never, 1 GEGLU linears, 2 every linear it can run               */
 #define MOCA_TUNE_SQP_WALK   8   /* tile walk of the persistent 256 x 256 kernel: 0 strided over the XCD's blocks, 1 a contiguous range per block           */
 #define MOCA_TUNE_SLAB_F16   9   /* split-K partial slabs of the 256-row kernel: 0 fp32, 1 fp16 (A/B of VERDICT r4 #5's candidate; changes results within the fp16 tolerance) */
-#define MOCA_TUNE_SK_INKERNEL 10 /* split-K reduce inside the launch where moca_gemm_params.sk_counters is given: 0 never, 1 where it applies */
-#define MOCA_TUNE_COUNT      11
+#define MOCA_TUNE_COUNT      10
 int moca_set_tuning(int32_t knob, int32_t value);
 
 /* device query: returns 0 and fills name[len] / cu count, or MOCA_E_NODEVICE */

@@ -1465,78 +1465,6 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(const moca_gemm_param
         }
         __syncthreads();
         constexpr int cpr4 = BN / 4;
-        if (p.reserved4_ & 8) {
-            // ---- the reduce INSIDE the launch (round 5; moca_gemm_params.sk_counters): the `splits` blocks of a tile publish their partial
-            //      tiles, meet at a counter, and each finishes ITS share of the tile's rows (own partial from LDS, the siblings' from their
-            //      slabs, summed in split order: bit-identical to splitk_reduce_kernel).  Every block of the launch is resident (host:
-            //      <= 248 blocks, one per CU), so the wait cannot starve; it is bounded all the same. ----
-            const int rq = (TM + p.splits - 1) / p.splits;
-            const int r_lo = split * rq, r_hi = min(r_lo + rq, TM);
-            for (int idx = tid; idx < TM * cpr4; idx += 512) {
-                const int row = idx / cpr4, ch = idx - row * cpr4;
-                const int m = m0 + row;
-                if (m < p.M && (row < r_lo || row >= r_hi))
-                    *reinterpret_cast<f32x4*>(ws + (int64_t)m * p.N + n0 + ch * 4) = *reinterpret_cast<const f32x4*>(sC + row * PF + ch * 4);
-            }
-            __threadfence();                                  // (agent scope: the partial rows are visible to every XCD before the arrival below)
-            __syncthreads();
-            int* cnt = p.sk_counters + tile;
-            if (tid == 0) {
-                __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                int spins = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < p.splits) {
-                    if (++spins > 400000) { p.sk_counters[4095] = 1; break; }      // (~0.1 s: never in a healthy launch; results are then wrong, not hung)
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
-            __syncthreads();
-            __threadfence();
-            const half_t* __restrict__ rowadd = reinterpret_cast<const half_t*>(p.rowadd);
-            const half_t* __restrict__ resid = reinterpret_cast<const half_t*>(p.residual);
-            constexpr int cpr8 = BN / 8;
-            const int64_t sstr = (int64_t)p.M * p.N;
-            for (int idx = tid; idx < (r_hi - r_lo) * cpr8; idx += 512) {
-                const int row = r_lo + idx / cpr8, ch = idx % cpr8;
-                const int m = m0 + row, col = n0 + ch * 8;
-                if (m >= p.M) continue;
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = p.bias ? p.bias[col + j] : 0.f;
-                for (int sp = 0; sp < p.splits; ++sp) {
-                    f32x4 a0, a1;
-                    if (sp == split) {
-                        a0 = *reinterpret_cast<const f32x4*>(sC + row * PF + ch * 8);
-                        a1 = *reinterpret_cast<const f32x4*>(sC + row * PF + ch * 8 + 4);
-                    } else {
-                        const float* w = p.splitk_ws + sp * sstr + (int64_t)m * p.N + col;
-                        a0 = *reinterpret_cast<const f32x4*>(w);
-                        a1 = *reinterpret_cast<const f32x4*>(w + 4);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] += a0[j]; v[4 + j] += a1[j]; }
-                }
-                if (rowadd) {
-                    const half8v e = *reinterpret_cast<const half8v*>(rowadd + (int64_t)(m / p.rowadd_div) * p.ld_rowadd + col);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-                }
-                if (resid) {
-                    const half8v e = *reinterpret_cast<const half8v*>(resid + (int64_t)m * p.ldr + col);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-                }
-                half8v h;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
-                *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(p.out) + (int64_t)m * p.ldo + col) = h;
-            }
-            __syncthreads();
-            if (tid == 0) {                                   // the last block to leave re-arms the counter for the next launch
-                const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == 2 * p.splits - 1) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        }
         for (int idx = tid; idx < TM * cpr4; idx += 512) {
             const int row = idx / cpr4, ch = idx - row * cpr4;
             const int m = m0 + row;
@@ -3762,15 +3690,6 @@ extern "C" int moca_gemm_ln_ok(const moca_gemm_params* pp) {
 static bool slab_f16(const moca_gemm_params& p) {
     return moca_tuning_get(MOCA_TUNE_SLAB_F16) && p.splits > 1 && !(p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32)) && takes_glds_bn(p) != 0;
 }
-// the reduce inside the launch (moca_gemm_params.sk_counters): a split-K call of the 256-row kernel with the plain fp16 epilogue whose
-// blocks are all resident at once (one block per CU: a waiting block must never keep a sibling from being scheduled)
-static bool sk_inkernel_ok(const moca_gemm_params& p) {
-    if (!moca_tuning_get(MOCA_TUNE_SK_INKERNEL) || !p.sk_counters || p.splits < 2 || p.flags != 0 || slab_f16(p)) return false;
-    const int bn = takes_glds_bn(p);
-    if (bn == 0) return false;
-    const int tiles = ((p.M + 255) / 256) * (p.N / bn);
-    return tiles < 4095 && tiles * p.splits <= 248;
-}
 // can moca_gemm_splitk_groupnorm_f16 finish this (validated, split-normalised) MOCA_EP_SLABS call?  fp16 plain epilogue, one block per
 // (statistics group, channel group) slab with the slab in registers
 static bool splitk_gn_ok(const moca_gemm_params& p, int HW, int fps) {
@@ -3886,8 +3805,6 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
     // bit 0: output rows leave with non-temporal stores when the output is at least half the 256 MiB Infinity Cache (see out_streams)
     if ((int64_t)p.M * (geglu ? p.N / 2 : p.N) * 2 >= (128ll << 20)) p.reserved4_ |= 1;
     if (slab_f16(p)) p.reserved4_ |= 4;               // bit 2: fp16 split-K slabs (MOCA_TUNE_SLAB_F16; the 256-row kernel only)
-    const bool sk_inkernel = sk_inkernel_ok(p);
-    if (sk_inkernel) p.reserved4_ |= 8;               // bit 3: the split blocks of a tile finish the reduce inside the launch (sk_counters)
     if (p.flags & MOCA_EP_TATTN) {                    // ask moca_gemm_tattn_ok() first
         if (!tattn_ok(p) || ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1))) return MOCA_E_BADARG;
         return launch_gemm_w80s<MOCA_A_LINEAR, 3>(p, st);
@@ -3925,7 +3842,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
         else rc = launch_gemm<64, MOCA_A_TCONV3>(p, st);
     }
     if (rc != MOCA_OK) return rc;
-    if (p.splits > 1 && !(p.flags & MOCA_EP_SLABS) && !sk_inkernel) {
+    if (p.splits > 1 && !(p.flags & MOCA_EP_SLABS)) {
         const int out_n = geglu ? p.N / 2 : p.N;
         const int64_t total = (int64_t)p.M * (out_n / 8);
         int blocks = (int)((total + 255) / 256);

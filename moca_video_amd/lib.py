@@ -23,7 +23,7 @@ MOCA_A_LINEAR, MOCA_A_CONV3X3, MOCA_A_TCONV3 = 0, 1, 2
 MOCA_EP_GEGLU, MOCA_EP_OUT_F32, MOCA_FORCE_SMALL_TILE, MOCA_EP_GELU, MOCA_EP_COLSUM, MOCA_EP_LN = 1, 2, 4, 8, 16, 32
 MOCA_EP_ROWSUM, MOCA_EP_LNFOLD, MOCA_EP_GSTAT, MOCA_EP_TATTN, MOCA_EP_SLABS = 64, 128, 256, 512, 1024
 MOCA_TUNE_GEMM_W80, MOCA_TUNE_GEMM_G4, MOCA_TUNE_GEMM_SQ256, MOCA_TUNE_GEMM_WIDE, MOCA_TUNE_GN_SLAB, MOCA_TUNE_GEMM_G4P, MOCA_TUNE_GEMM_MF32, MOCA_TUNE_GEMM_SQP, MOCA_TUNE_SQP_WALK = 0, 1, 2, 3, 4, 5, 6, 7, 8
-MOCA_TUNE_SLAB_F16, MOCA_TUNE_SK_INKERNEL = 9, 10
+MOCA_TUNE_SLAB_F16 = 9
 
 _ERR = {0: "ok", -1: "bad argument (shape/alignment contract)", -2: "HIP launch/runtime error",
         -3: "no gfx950 device", -4: "graph capture/replay failed"}
@@ -51,7 +51,6 @@ class GemmParams(C.Structure):
         ("gstat", C.c_void_p), ("gstat_rows", C.c_int32), ("tattn_scale", C.c_float),
         ("prefetch", C.c_void_p), ("up_phase", C.c_int32), ("reserved4_", C.c_int32),
         ("a2", C.c_void_p), ("lda2", C.c_int32), ("k1", C.c_int32), ("gstat_cpg", C.c_int32), ("gstat_coff", C.c_int32),
-        ("sk_counters", C.c_void_p),
     ]
 
 

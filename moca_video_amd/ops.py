@@ -155,11 +155,8 @@ def finish_lnfold(pw: PackedWeight) -> PackedWeight:
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
                  residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None,
-                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, up_phase=0, prefetch=None, a2=None, slabs=False,
-                 sk_counters=None):
+                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, up_phase=0, prefetch=None, a2=None, slabs=False):
     p = _l.GemmParams()
-    if sk_counters is not None:              # int32 [4096], zero before first use: split-K launches may finish their reduce inside the launch
-        p.sk_counters = sk_counters.data_ptr()
     p.up_phase = up_phase
     if a2 is not None:                       # (second A source fp16 [M][lda2], columns of `a`): A = the virtual cat([a, a2], channels)
         p.a2, p.lda2, p.k1 = a2[0].data_ptr(), a2[0].stride(-2), a2[1]
@@ -271,7 +268,7 @@ def gemm_splitk_groupnorm_ok(a, pw: PackedWeight, *, HW, frames_per_stat, **kw):
 def gemm_splitk_groupnorm(a, pw: PackedWeight, out, y, gamma, beta, *, HW, frames_per_stat, eps, silu, write_x, **kw):
     """finish a `gemm(..., slabs=True)` call: x = its output (written to `out` only with write_x), y = GroupNorm(+SiLU)(x); `kw` = the
     keywords of that gemm call"""
-    kw = {k: v for k, v in kw.items() if k not in ("slabs", "colsum", "prefetch", "sk_counters")}
+    kw = {k: v for k, v in kw.items() if k not in ("slabs", "colsum", "prefetch")}
     p = _gemm_params(a, pw, out, slabs=True, **kw)
     _l.check(_l.load().moca_gemm_splitk_groupnorm_f16(C.byref(p), _l.ptr(y), _l.ptr(gamma), _l.ptr(beta), HW, frames_per_stat, eps,
                                                       1 if silu else 0, 1 if write_x else 0, _st()), "moca_gemm_splitk_groupnorm_f16")

@@ -64,7 +64,6 @@ VIRTUAL_CAT = os.environ.get("MOCA_VCAT", "1") != "0"
 # split-K reduce inside the GroupNorm that consumes it (the 5 x 8-latent level of the B = 2 forward; A/B switch MOCA_SKGN=0)
 SPLITK_GN = os.environ.get("MOCA_SKGN", "1") != "0"
 SPLITK_GN_ALL = os.environ.get("MOCA_SKGN", "1") == "2"     # (A/B: also the 16-frame GroupNorms of the temporal convs)
-SK_INKERNEL = os.environ.get("MOCA_SK_INKERNEL", "1") != "0"   # (A/B: split-K reduce inside the launch, moca_gemm_params.sk_counters)
 
 
 class _LNRef:
@@ -93,7 +92,6 @@ class _PlanBase:
         self.n_runs = 0
         self._gstat_buf, self._gstat_used, self._last_gemm_step = None, 0, None
         self._last_slabs = None
-        self._sk_counters = None
         self._gstat_full = []
         self.reps = 1            # > 1: the batch is `reps` context variants of the same Bx latents (_Plan: shared prefix)
         self._prefetch_at = {}   # during the build: index of a recorded GEMM step -> weights of later launches to prefetch in front of it
@@ -167,10 +165,6 @@ class _PlanBase:
             if rows > 0:
                 cs = (self.pool.get((M + rows - 1) // rows, 2 * pw.N, torch.float32), rows)
         self._note_gemm(pw)
-        if ws is not None and getattr(self, "_sk_inkernel", False):   # split-K: the blocks of a tile may meet inside the launch (moca_gemm_params.sk_counters)
-            if self._sk_counters is None:
-                self._sk_counters = torch.zeros(4096, dtype=torch.int32, device=self.device)
-            kw = dict(kw, sk_counters=self._sk_counters)
         self._emit(ops.gemm, a, pw, out, M=M, splits=splits, splitk_ws=ws, colsum=None if cs is None else cs[0], **kw)
         self._last_slabs = None
         if ws is not None:
@@ -361,13 +355,12 @@ class _PlanBase:
 class _Plan(_PlanBase):
     _defer_slabs = True
 
-    def __init__(self, model, B, T, H, W, L, in_dtype, device, shared_x=False, concurrent=False):
+    def __init__(self, model, B, T, H, W, L, in_dtype, device, shared_x=False):
         """shared_x: the B videos are `len(L)` context variants of the SAME B / len(L) latents (the two `apply_model` calls of
         classifier-free guidance, ddim.py:298-299,366-369, on one x): `x_in` holds the distinct latents only, everything up to the
         first cross-attention (conv_in, init_attn, the first ResBlock, the first SpatialTransformer's self-attention and to_q:
         8 % of the forward) is computed once and repeated where the contexts first enter (`_expand`)."""
         super().__init__(model, device)
-        self._sk_inkernel = SK_INKERNEL and not concurrent    # (the in-launch split-K reduce needs every block of a launch resident: never for plans that overlap)
         self.B, self.T, self.H, self.W, self.L = B, T, H, W, L
         self.BT = B * T
         # context segments (videos, tokens) in batch order: one segment normally; the batched FIFO call carries the conditional

@@ -509,7 +509,7 @@ class UNetModel(nn.Module):
             raise RuntimeError("this rank received the packed operand set of the plans built before dist.broadcast_packed and holds no "
                                "parameters to pack a new plan from")
         if plan is None:
-            plan = _Plan(self, B, T, H, W, L, x.dtype, x.device, shared_x=shared_x, concurrent=replica != 0)
+            plan = _Plan(self, B, T, H, W, L, x.dtype, x.device, shared_x=shared_x)
             self._plans[key] = plan
         return plan
 
@@ -562,8 +562,7 @@ class UNetModel(nn.Module):
         prepared = []
         for i, c in enumerate(calls):
             t_rows, fps_rows = self._prepare(c["x"], c["timesteps"], c["context"], None, c.get("fps", 16))
-            # (replica >= 1: plans that run next to each other never use the in-launch split-K reduce, whose blocks wait for their siblings)
-            prepared.append((self._plan_for(c["x"], c["context"].shape[1], replica=i + 1), c["x"], t_rows, fps_rows, c["context"]))
+            prepared.append((self._plan_for(c["x"], c["context"].shape[1], replica=i), c["x"], t_rows, fps_rows, c["context"]))
         cur = torch.cuda.current_stream(prepared[0][1].device)
         outs = [pl.launch_async(x, t, f, ctx, cur) for pl, x, t, f, ctx in prepared]
         for (pl, *_), o in zip(prepared, outs):

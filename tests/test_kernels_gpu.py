@@ -780,39 +780,6 @@ def test_gemm_splitk_groupnorm(Fr, HW, fps, mode, splits, res, radd):
         ops.gemm(a, pw, x0, slabs=True, **kw1)
 
 
-@pytest.mark.parametrize("mode,M,splits,res,radd", [("tconv", 1280, 4, False, False), ("conv", 1280, 5, True, False), ("conv", 1280, 5, False, True),
-                                                   ("lin", 1280, 4, True, False), ("lin", 1000, 3, False, False), ("lin", 5120, 1, False, False)])
-def test_gemm_splitk_inside_the_launch(mode, M, splits, res, radd):
-    """moca_gemm_params.sk_counters: the split blocks of a tile finish the reduce inside the launch -- bit-identical to split-K + reduce launch,
-    counters back at zero afterwards, no block ever gave up waiting; 50 launches in a row on one counter buffer"""
-    C, N = 1280, 1280
-    HW = 40
-    if mode == "tconv":
-        a, K, kw = rnd(M, C), 3 * C, dict(mode=L.MOCA_A_TCONV3, tconv=(C, 16, HW))
-        pw = ops.pack_tconv3(rnd(N, C, 3, 1, 1, scale=K ** -0.5), rnd(N, dtype=torch.float32))
-    elif mode == "conv":
-        a, K, kw = rnd(M, C), 9 * C, dict(mode=L.MOCA_A_CONV3X3, conv=(C, 5, 8, 5, 8, 1, 0))
-        pw = ops.pack_conv3x3(rnd(N, C, 3, 3, scale=K ** -0.5), rnd(N, dtype=torch.float32))
-    else:
-        a, K, kw = rnd(M, 4 * C), 4 * C, dict()
-        pw = ops.pack_linear(rnd(N, K, scale=K ** -0.5), rnd(N, dtype=torch.float32))
-    r = rnd(M, N) if res else None
-    ra = rnd((M + HW - 1) // HW, N) if radd else None
-    kw.update(M=M, splits=splits, residual=r, rowadd=ra, rowadd_div=HW if radd else 1)
-    ws = torch.empty(max(splits, 1) * M * N, dtype=torch.float32, device=DEV) if splits > 1 else None
-    x0 = torch.empty(M, N, dtype=torch.float16, device=DEV)
-    ops.gemm(a, pw, x0, splitk_ws=ws, **kw)
-    cnt = torch.zeros(4096, dtype=torch.int32, device=DEV)
-    for it in range(50):
-        x1 = torch.full_like(x0, float("nan"))
-        if ws is not None:
-            ws.fill_(float("nan"))
-        ops.gemm(a, pw, x1, splitk_ws=ws, sk_counters=cnt, **kw)
-        if it in (0, 1, 49):
-            assert torch.equal(x1, x0), f"launch {it}"
-    assert int(cnt.abs().sum()) == 0, "counters must re-arm themselves; [4095] != 0 means a block gave up waiting"
-
-
 # ---------------------------------------------------------------- the virtual torch.cat of the output blocks (openaimodel3d.py:571)
 @pytest.mark.parametrize("M,C1,C2,N,res", [(81920, 640, 320, 320, False), (81920, 320, 320, 320, True), (20480, 1280, 640, 640, False),
                                            (20480, 640, 320, 640, True), (20000, 640, 640, 640, False), (40960, 512, 256, 320, False)])
