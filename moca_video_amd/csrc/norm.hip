@@ -761,6 +761,7 @@ extern "C" int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gam
                                         int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
                                         float eps, int32_t silu, void* stream) {
     if (!x || !y || !gamma || !beta || !gstat) return MOCA_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) return MOCA_E_BADARG;     // (fetched as 16-byte vectors)
     if (F <= 0 || HW <= 0 || C <= 0 || C % 8 || C % GN_GROUPS || frames_per_stat <= 0 || F % frames_per_stat) return MOCA_E_BADARG;
     const int nch8 = C / 8;
     if (nch8 > 1024) return MOCA_E_BADARG;
@@ -803,6 +804,7 @@ extern "C" int moca_groupnorm_gstat_cat_f16(const void* a, const void* b, void* 
                                             const int64_t* gstat_cat, const int64_t* gstat_b, int32_t Fb, int32_t F, int32_t HW, int32_t C1,
                                             int32_t C2, int32_t frames_per_stat, float eps, int32_t silu, void* stream) {
     if (!a || !b || !y || !gamma || !beta || !gstat_cat) return MOCA_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) return MOCA_E_BADARG;     // (fetched as 16-byte vectors)
     if (Fb <= 0) Fb = F;
     if (Fb > F || F % Fb || Fb % frames_per_stat) return MOCA_E_BADARG;
     if (F <= 0 || HW <= 0 || C1 <= 0 || C2 <= 0 || C1 % 8 || C2 % 8 || frames_per_stat <= 0 || F % frames_per_stat) return MOCA_E_BADARG;

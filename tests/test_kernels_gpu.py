@@ -780,6 +780,19 @@ def test_gemm_splitk_groupnorm(Fr, HW, fps, mode, splits, res, radd):
         ops.gemm(a, pw, x0, slabs=True, **kw1)
 
 
+def test_groupnorm_gstat_rejects_misaligned_affine_parameters():
+    """gamma / beta are fetched as 16-byte vectors by the statistics-fed apply kernels: a parameter pointer that is not 16-byte aligned is refused"""
+    Fr, HW, C = 2, 64, 320
+    x = rnd(Fr * HW, C)
+    y = torch.empty_like(x)
+    gst = torch.zeros(Fr * 64, dtype=torch.int64, device=DEV)
+    ops.gstat_accum(x, gst, F=Fr, HW=HW, Cn=C, frames_per_stat=1, cpg=C // 32, coff=0)
+    buf = rnd(2 * C + 8, dtype=torch.float32)
+    ops.groupnorm_gstat(x, y, buf[:C], buf[C:2 * C], gst, F=Fr, HW=HW, Cn=C, frames_per_stat=1, eps=1e-5, silu=False)
+    with pytest.raises(L.MocaHipError):
+        ops.groupnorm_gstat(x, y, buf[1:C + 1], buf[C:2 * C], gst, F=Fr, HW=HW, Cn=C, frames_per_stat=1, eps=1e-5, silu=False)
+
+
 # ---------------------------------------------------------------- the virtual torch.cat of the output blocks (openaimodel3d.py:571)
 @pytest.mark.parametrize("M,C1,C2,N,res", [(81920, 640, 320, 320, False), (81920, 320, 320, 320, True), (20480, 1280, 640, 640, False),
                                            (20480, 640, 320, 640, True), (20000, 640, 640, 640, False), (40960, 512, 256, 320, False)])
