@@ -120,11 +120,12 @@ __device__ __forceinline__ f32x4g moca_geglu4(f32x4g v, f32x4g g) {
 // < 1e-8, far below the eps (1e-6 / 1e-5) added to the variance.
 // A NON-FINITE partial (NaN / Inf activations) must not turn into finite statistics: it sets bit 62 of the group's sum-of-squares
 // accumulator (acc layout [group][2] = {sum, sum of squares}) and adds nothing; OR is idempotent, so the bit survives however many
-// partials are poisoned.  A finite partial is clamped to +-2^53 units (8.4e6 as a sum, 1.4e11 as a sum of squares: an rms of 3.3e3 over
-// a 320 x 40 tile) before it is added.  moca_gstat_get returns NaN when the sum-of-squares accumulator is >= 2^61 -- the poison bit, or
-// finite adds that came within a factor 2 of it (256 partials at the clamp; a group of the UNet receives <= 2^10: rows of a statistics
-// group / 160-row tiles x 2 column tiles, so accepted adds stay below 2^63 and cannot wrap): overflowing statistics read back as NaN
-// like poisoned ones, never as a wrong finite number, and finite adds can not alias the poison bit unnoticed.
+// partials are poisoned.  A finite partial beyond +-2^53 units (8.4e6 as a sum, 1.4e11 as a sum of squares: an rms of 3.3e3 over
+// a 320 x 40 tile -- fp16 activations within a factor 20 of their overflow) POISONS the group the same way (it used to be
+// clamped, which gave finite but wrong statistics).  moca_gstat_get returns NaN when the sum-of-squares accumulator is >= 2^61 -- the
+// poison bit, or accepted adds that came within a factor 2 of it (a group of the UNet receives <= 2^10 partials: rows of a statistics
+// group / 160-row tiles x 2 column tiles, so accepted adds stay below 2^63 and cannot wrap): statistics outside the fixed-point
+// range read back as NaN, never as a wrong finite number, and finite adds can not alias the poison bit unnoticed.
 #define MOCA_GSTAT_SUM_SCALE 1073741824.0
 #define MOCA_GSTAT_SQ_SCALE 65536.0
 #define MOCA_GSTAT_POISON (1ull << 62)
@@ -135,7 +136,10 @@ __device__ __forceinline__ void moca_gstat_add(int64_t* acc, int comp, float par
         return;
     }
     double v = (double)partial * (comp ? MOCA_GSTAT_SQ_SCALE : MOCA_GSTAT_SUM_SCALE);
-    v = fmin(fmax(v, -MOCA_GSTAT_MAX_UNITS), MOCA_GSTAT_MAX_UNITS);
+    if (!(fabs(v) <= MOCA_GSTAT_MAX_UNITS)) {      // out of the fixed-point range: poison, never clamp (a clamped partial would read
+        atomicOr(reinterpret_cast<unsigned long long*>(acc + (1 - comp)), MOCA_GSTAT_POISON);      // back as finite, WRONG statistics)
+        return;
+    }
     atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)__double2ll_rn(v));
 }
 __device__ __forceinline__ double moca_gstat_get(const int64_t* acc, int comp) {

@@ -3717,7 +3717,8 @@ extern "C" int moca_gemm_splitk_groupnorm_f16(const moca_gemm_params* pp, void* 
     const int cpg = p.N / 32, R = HW * frames_per_stat;
     const int nchunks = R * (cpg / 8);
     const int cpt = (nchunks + 1023) / 1024;
-    const int thr = ((nchunks + cpt - 1) / cpt + 63) / 64 * 64;
+    int thr = ((nchunks + cpt - 1) / cpt + 63) / 64 * 64;
+    if (thr < (cpg + 63) / 64 * 64) thr = (cpg + 63) / 64 * 64;      // threads tid < cpg fill s_sc / s_sh (cpg = 128 with 64 chunks: ADVICE r5)
     const int n_slabs = (p.M / R) * 32;
     const double inv_count = 1.0 / ((double)R * cpg);
     hipStream_t st = moca_stream(stream);

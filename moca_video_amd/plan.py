@@ -92,6 +92,7 @@ class _PlanBase:
         self.n_runs = 0
         self._gstat_buf, self._gstat_used, self._last_gemm_step = None, 0, None
         self._last_slabs = None
+        self._held = {}          # data_ptr -> [pending deferred reduces that read it, buffer released meanwhile]
         self._gstat_full = []
         self.reps = 1            # > 1: the batch is `reps` context variants of the same Bx latents (_Plan: shared prefix)
         self._prefetch_at = {}   # during the build: index of a recorded GEMM step -> weights of later launches to prefetch in front of it
@@ -145,7 +146,24 @@ class _PlanBase:
                 continue
             if b.data_ptr() in self._pinned:
                 continue
+            held = self._held.get(b.data_ptr())
+            if held is not None:               # an operand a deferred split-K reduce still has to read (see _gemm): back to the pool
+                held[1] = b                    # only once the consumer that performs the reduce has been recorded (_unhold)
+                continue
             self.pool.put(b)
+
+    def _unhold(self, slabs):
+        """the deferred reduce of `slabs` has been recorded (or dropped): operands released meanwhile go back to the pool NOW, i.e.
+        after the fused GroupNorm took its output buffer -- it can never be handed one of the operands it re-reads"""
+        for ptr in slabs[2]:
+            held = self._held.get(ptr)
+            if held is None:
+                continue
+            held[0] -= 1
+            if held[0] == 0:
+                del self._held[ptr]
+                if held[1] is not None:
+                    self.pool.put(held[1])
 
     def _splits(self, M, pw):
         return gemm_splits(M, pw)
@@ -168,8 +186,13 @@ class _PlanBase:
         self._emit(ops.gemm, a, pw, out, M=M, splits=splits, splitk_ws=ws, colsum=None if cs is None else cs[0], **kw)
         self._last_slabs = None
         if ws is not None:
-            if want_colsum and SPLITK_GN and self._defer_slabs:   # conv / tconv: the workspace stays reserved until the consumer is known
-                self._last_slabs = (ws, self._last_gemm_step)   # (_FMap.slabs; released by gn() / _drop_colsum())
+            if want_colsum and SPLITK_GN and self._defer_slabs:   # the workspace stays reserved until the consumer is known
+                ptrs = []                                       # ... and so do the operands a fused reduce re-reads there
+                for t in (kw.get("residual"), kw.get("rowadd")):
+                    if t is not None and t.data_ptr() not in self._pinned:
+                        self._held.setdefault(t.data_ptr(), [0, None])[0] += 1
+                        ptrs.append(t.data_ptr())
+                self._last_slabs = (ws, self._last_gemm_step, tuple(ptrs))   # (_FMap.slabs; released by gn() / _drop_colsum())
             else:
                 self.pool.put(ws)
         return (out, cs) if want_colsum else out
@@ -234,7 +257,8 @@ class _PlanBase:
             return y
         if getattr(fm, "slabs", None) is not None:
             # the producer ran split-K: its reduce launch moves into this GroupNorm (x_dead: nobody else reads fm.buf -- it is not written)
-            wsk, src = fm.slabs
+            slabs = fm.slabs
+            wsk, src = slabs[0], slabs[1]
             prod = self.steps[src]
             kw = dict(prod.keywords)
             fm.slabs = None
@@ -248,8 +272,10 @@ class _PlanBase:
                 self._emit(ops.gemm_splitk_groupnorm, prod.args[0], prod.args[1], prod.args[2], y, gb[0], gb[1], HW=fm.H * fm.W,
                            frames_per_stat=fps, eps=eps, silu=silu, write_x=not x_dead, **kw)
                 self.pool.put(wsk)
+                self._unhold(slabs)
                 return y
             self.pool.put(wsk)
+            self._unhold(slabs)
         y = self.pool.get(fm.M, fm.C)
         HW = fm.H * fm.W
         ws = self.pool.get(1, ops.groupnorm_ws_floats(fm.F, HW, fm.C), torch.float32)
@@ -297,6 +323,7 @@ class _PlanBase:
         """the statistics buffer of a feature map goes back to the pool once its GroupNorm consumer has been recorded"""
         if getattr(fm, "slabs", None) is not None:             # a split-K producer whose consumer was no GroupNorm: its own reduce stays
             self.pool.put(fm.slabs[0])
+            self._unhold(fm.slabs)
             fm.slabs = None
         if fm.colsum is not None:
             if not fm.cs_used and fm.src is not None:          # nobody read the column sums (the consumer was a conv / a concat /
@@ -635,7 +662,9 @@ class _Plan(_PlanBase):
         self._release(h)
         if xres is not x.buf:
             self._release(xres)
-        return _FMap(out, Fr, x.H, x.W, x.C, cs, src=self._last_gemm_step if cs is not None else None)
+        o = _FMap(out, Fr, x.H, x.W, x.C, cs, src=self._last_gemm_step if cs is not None else None)
+        o.slabs = self._last_slabs          # (split-K proj_out, e.g. M = 640 at B = 1: released by gn() / _drop_colsum())
+        return o
 
     def run_seq(self, seq, h):
         """TimestepEmbedSequential.forward, openaimodel3d.py:36-48"""
@@ -653,6 +682,8 @@ class _Plan(_PlanBase):
             else:
                 raise TypeError(type(layer))
             if isinstance(h, _CatMap):
+                self._drop_colsum(h.h)          # (whatever _virtual_cat did not re-target: column sums nobody read, a deferred workspace)
+                self._drop_colsum(h.skip)
                 self._release(h.h.buf, h.skip.buf)
             else:
                 self._release(h.buf)

@@ -378,6 +378,13 @@ def test_timestep_embedding_and_silu_rows():
     args = t[:, None].float() * freqs[None]
     ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
     assert (out.float() - ref).abs().max().item() < 2e-3
+    # the REAL reference's `timestep_embedding` (utils_diffusion.py:8-28) on its own timesteps: tests/golden/timestep_embedding.npz
+    from helpers import golden
+    g = golden("timestep_embedding")
+    tg = torch.from_numpy(g["t"]).to(DEV)
+    og = torch.empty(tg.shape[0], 320, dtype=torch.float16, device=DEV)
+    ops.timestep_embedding(tg, og, n=tg.shape[0], dim=320)
+    assert (og.float().cpu() - torch.from_numpy(g["y"])).abs().max().item() < 2e-3       # fp16 output of values in [-1, 1] (4.9e-4) + the fp32 argument error at t = 999
     a, b = rnd(6, 128), rnd(2, 128)
     o = torch.empty(6, 128, dtype=torch.float16, device=DEV)
     ops.silu_add_rows(a, 1, b, 3, o, rows=6, Cn=128, silu=True)
@@ -730,6 +737,22 @@ def test_concat_with_groupnorm_statistics(Fr, HW, C1, C2):
         keep[1, gi] = False
         assert torch.equal(yv.permute(0, 2, 1, 3)[keep], gref.view(Fr, HW, 32, cpg).permute(0, 2, 1, 3)[keep].to(y.dtype)) or \
             relerr(yv.permute(0, 2, 1, 3)[keep], gref.view(Fr, HW, 32, cpg).permute(0, 2, 1, 3)[keep]) < TOL16
+    # LARGE finite activations: a group at rms 1e3 lies inside the fixed-point range and must be right; at rms 2e4 a
+    # partial can leave the range -- that group then reads back NaN (poisoned), never finite-but-wrong (it used to be clamped)
+    for scale, must_match in ((1.0e3, True), (2.0e4, False)):
+        a2 = a.clone()
+        a2[HW:2 * HW, :cpg] = (torch.randn(HW, cpg, device=DEV) * scale).clamp(-6.0e4, 6.0e4).half()
+        gst.zero_()
+        ops.concat_channels_gstat(a2, b, out, gst, F=Fr, HW=HW, C1=C1, C2=C2, frames_per_stat=1)
+        ops.groupnorm_gstat(out, y, g, be, gst, F=Fr, HW=HW, Cn=C, frames_per_stat=1, eps=1e-5, silu=True)
+        r2 = torch.cat([a2, b], dim=1).float()
+        gref2 = F.silu(F.group_norm(r2.view(Fr, HW, C).permute(0, 2, 1), 32, g, be, 1e-5)).permute(0, 2, 1).reshape(Fr * HW, C)
+        got, want = y.view(Fr, HW, 32, cpg)[1, :, 0], gref2.view(Fr, HW, 32, cpg)[1, :, 0]
+        if must_match or not torch.isnan(got).all():
+            assert relerr(got, want) < TOL16, f"rms {scale:g}: finite GroupNorm output that is not the fp32 reference's"
+        keep = torch.ones(Fr, 32, dtype=torch.bool, device=DEV)
+        keep[1, 0] = False
+        assert relerr(y.view(Fr, HW, 32, cpg).permute(0, 2, 1, 3)[keep], gref2.view(Fr, HW, 32, cpg).permute(0, 2, 1, 3)[keep]) < TOL16
 
 
 # ---------------------------------------------------------------- split-K reduce inside the consuming GroupNorm (the 5 x 8-latent level)
@@ -739,7 +762,17 @@ def test_concat_with_groupnorm_statistics(Fr, HW, C1, C2):
 def test_gemm_splitk_groupnorm(Fr, HW, fps, mode, splits, res, radd):
     """MOCA_EP_SLABS + moca_gemm_splitk_groupnorm_f16 against the three-launch path (GEMM, reduce, GroupNorm): x bit-identical when it is
     written, y to the fp16 tolerance (same fp16 x, statistics summed in another order)"""
-    C, N, M = 1280, 1280, Fr * HW
+    _splitk_groupnorm_case(Fr, HW, fps, mode, splits, res, radd)
+
+
+def test_gemm_splitk_groupnorm_fewer_chunks_than_group_channels():
+    """a statistics group of 128 channels over 4 rows is 64 eight-channel chunks: the block must still have >= 128 threads, which
+    fill the per-channel scale / shift table (64 were launched and half the table was uninitialised LDS)"""
+    _splitk_groupnorm_case(320, 4, 1, "lin", 4, True, False, C=1280, N=4096)
+
+
+def _splitk_groupnorm_case(Fr, HW, fps, mode, splits, res, radd, C=1280, N=1280):
+    M = Fr * HW
     H, W = (5, 8) if HW == 40 else (HW // 8, 8)
     if mode == "tconv":
         a, K, kw = rnd(M, C), 3 * C, dict(mode=L.MOCA_A_TCONV3, tconv=(C, 16, HW))

@@ -299,18 +299,24 @@ def test_forward_concurrent_equals_forward(reduced_model):
     check(o1.cpu(), torch.from_numpy(g["uniform"]), TOL_UNET, "concurrent")
 
 
-def test_unet_full_width_vs_reference_golden():
+@pytest.fixture(scope="module")
+def full_dm():
+    """The full 1.41 B-parameter UNet of inference_t2v_512_v2.0.yaml inside the drop-in DenoiseModel, weights = weightgen seed 11
+    (what tools/make_golden.py loaded into the REAL reference; regenerated here, ~1-2 min of host time, shared by the
+    full-width tests of this module)."""
+    from helpers import FULL
+    from moca_video_amd import DenoiseModel
+    dm = DenoiseModel({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": FULL})
+    m = dm.model.diffusion_model
+    m.load_state_dict(state_dict_for(m, 11), strict=True)
+    return dm.cuda()
+
+
+def test_unet_full_width_vs_reference_golden(full_dm):
     """The full 1.41 B-parameter UNet (inference_t2v_512_v2.0.yaml) against outputs of the REAL reference UNet captured by
     `tools/make_golden.py --only full`: config[0] shape (uniform t, 77 tokens; FIFO per-frame t, 154 tokens) and the headline
-    16x40x64 shape as a FIFO window call.  Weights = weightgen seed 11 (regenerated here, ~1-2 min of host time)."""
-    import os
-    from helpers import FULL, GOLD
-    if not (os.path.exists(os.path.join(GOLD, "unet_full.npz")) and os.path.exists(os.path.join(GOLD, "unet_full_cfgN.npz"))):
-        pytest.skip("full-width goldens not generated (tools/make_golden.py --only full)")
-    from moca_video_amd import UNetModel
-    m = UNetModel(**FULL)
-    m.load_state_dict(state_dict_for(m, 11), strict=True)
-    m = m.cuda()
+    16x40x64 shape as a FIFO window call."""
+    m = full_dm.model.diffusion_model
     for tag, shape in (("full", (4, 8, 32, 32)), ("full_cfgN", (4, 16, 40, 64))):
         g = golden("unet_" + tag)
         for name in sorted(k for k in g.files if "__" not in k):
@@ -338,6 +344,142 @@ def test_unet_full_width_vs_reference_golden():
     a = m(xs[0], t16, context=cs[0], fps=fps[:1])
     b = m(xs[0], torch.tensor([500]).cuda(), context=cs[0], fps=fps[:1])
     assert relerr(a.cpu(), b.cpu()) < 1e-6
+
+
+def _b16_inputs():
+    """the 8 window rows of one FIFO iteration, tiled from the two windows of tests/golden/unet_full_b16.npz (own latents, 16
+    consecutive timesteps of the 50-step schedule each), + the 154-token and the 77-token context"""
+    g = golden("unet_full_b16")
+    wins = ["w0", "w1", "w1", "w0", "w0", "w0", "w1", "w1"]                 # not periodic in 2 or 4: a row permutation shows
+    xw = {w: inp(f"full_b16.{w}.x", (1, 4, 16, 40, 64)) for w in ("w0", "w1")}
+    x = torch.cat([xw[w] for w in wins]).cuda()
+    t = torch.cat([torch.from_numpy(g[f"{w}__t"]) for w in wins]).cuda()
+    c154 = inp("full_b16.ctx154", (1, 154, 1024)).cuda()
+    c77 = inp("full_b16.ctx77", (1, 77, 1024)).cuda()
+    return g, wins, x, t, c154, c77
+
+
+def test_unet_full_width_b16_vs_reference_golden(full_dm):
+    """The operating point of configs[2-4]: ONE B = 16 forward laid out as `FifoEngine` lays it out -- 8 window rows
+    with the two-prompt 154-token context followed by the SAME 8 windows with the 77-token unconditional context, per-(b, t)
+    timesteps (funcs.py:305-355 -> ddim.py:362-374 -> openaimodel3d.py:535-549).  M = 655 360 rows at the 320-channel level selects
+    other kernels than B <= 2 (GEGLU / `+res` kernels switch at M >= 2^17, NT stores on output size), so EVERY row is held to the
+    output the REAL reference UNet gave for that (window, context) at B = 1 (`tools/make_golden.py --only fullB16`), through
+    (a) the shared-prefix plan the engine uses and (b) the plain two-segment batch it falls back to for unequal fps."""
+    m = full_dm.model.diffusion_model
+    g, wins, x, t, c154, c77 = _b16_inputs()
+    fps = torch.tensor([10]).cuda()
+    ctxs = [c154.expand(8, -1, -1).contiguous(), c77.expand(8, -1, -1).contiguous()]
+    for it in range(3):                                                      # eager, hipGraph capture, replay
+        y = m.forward_segments(x, t, ctxs, fps=fps, shared_x=True)
+        assert y.shape == (16, 4, 16, 40, 64)
+        if it == 0:
+            y0 = y.clone()
+    assert torch.equal(y, y0), "replays must be bit-identical"
+    worst = 0.0
+    for r in range(16):
+        name = f"{wins[r % 8]}_{154 if r < 8 else 77}"
+        e, _ = check(y[r:r + 1].cpu(), torch.from_numpy(g[name]), TOL_UNET, f"b16 shared-prefix row {r} ({name})")
+        worst = max(worst, e)
+    print(f"b16 shared prefix: worst row {worst:.2e}")
+    # (b) the plain batch: 16 latent rows, two context segments, nothing shared
+    y2 = m.forward_segments(torch.cat([x, x]), torch.cat([t, t]), ctxs, fps=fps, shared_x=False)
+    for r in range(16):
+        name = f"{wins[r % 8]}_{154 if r < 8 else 77}"
+        check(y2[r:r + 1].cpu(), torch.from_numpy(g[name]), TOL_UNET, f"b16 plain row {r} ({name})")
+    # batch consistency: row i of the B = 16 launch == the B = 1 launch of the same window (other tilings / split-K: tolerance),
+    # and rows that hold the same window agree with each other to the bit where the tile walk is per video
+    for r, L, ctx in ((0, 154, c154), (1, 154, c154), (9, 77, c77)):
+        s = m(x[r % 8:r % 8 + 1], t[(r % 8) * 16:(r % 8) * 16 + 16], context=ctx, fps=fps)
+        assert relerr(y[r:r + 1].cpu(), s.cpu()) < TOL_UNET, f"batch consistency row {r}"
+    assert relerr(y[1].cpu(), y[2].cpu()) < 1e-3 and relerr(y[8].cpu(), y[11].cpu()) < 1e-3      # same window in other rows
+
+
+def test_fifo_engine_full_size_iteration_vs_oracle_step(full_dm):
+    """One FULL-SIZE `FifoEngine` iteration (72-frame queue of 40x64 latents, 8 windows x {154, 77} tokens = the B = 16 graph the
+    `fifo` / `video` bench legs time) checked beyond `isfinite`:
+      * its UNet output rows against the B = 1 launches of the same windows (which the goldens above pin to the reference);
+      * guidance + MoCA `ddim_step` (ddim.py:366-372,405-430,556-609) of all 8 windows, in the reference's call order with the momentum
+        state carried from call to call, against `oracle.sampler_oracle.ddim_step` fed the HIP eps -- fp32, <= 2e-5;
+      * write-back, emitted frame, FreeInit mix and shift (funcs.py:336-371,86-99) against the oracle's queue ops;
+      * iterations 2 and 3 (capture, replay) against the host-driven HIP loop on the same draws."""
+    import types
+    from moca_video_amd.fifo import fifo_ddim_sampling, prepare_latents
+    from moca_video_amd.fifo_graph import FifoEngine, fifo_windows
+    from moca_video_amd.sampler import DDIMSampler
+    from oracle import freeinit_oracle as FO
+    from oracle import sampler_oracle as SO
+    dm = full_dm
+    m = dm.model.diffusion_model
+    T, H, W, S = 16, 40, 64, 64
+    args = types.SimpleNamespace(num_inference_steps=S, video_length=T, lookahead_denoising=True, num_partitions=4, new_video_length=100)
+    s = DDIMSampler(dm)
+    s.make_schedule(S, ddim_eta=1.0, verbose=False)
+    Q = S + T // 2
+    fps = torch.tensor([10]).cuda()
+    c1, c2, ucx = (inp(f"full_it.{n}", (1, 77, 1024)).cuda() for n in ("c1", "c2", "uc"))
+    cond = {"c_crossattn": [c1, c2], "fps": fps}
+    uc = {"c_crossattn": [ucx], "fps": fps}
+    prep = [inp(f"full_it.prep{j}", (1, 4, 1, H, W)).cuda() for j in range(Q)]
+    lat0 = prepare_latents(args, None, s, initial_latents=inp("full_it.z", (1, 4, T, H, W)).cuda(), noises=prep)
+    mask = torch.zeros(1, 1, Q, H, W)
+    mask[..., H // 4: 3 * H // 4, W // 4: 3 * W // 4] = 1.0
+    mask[:, :, 5] = 0.0
+    cimg = (inp("full_it.cimg", (1, 4, 1, H, W)) * 0.25 + 0.5).clamp(0, 1)
+    n_it = 3
+    noises = [[inp(f"full_it.n{i}.{w}", (1, 4, T, H, W)) for w in range(8)] for i in range(n_it)]
+    shifts = [inp(f"full_it.sh{i}", (1, 4, H, W)) for i in range(n_it)]
+    eng = FifoEngine(args, dm, s, cond, uc, 12.0, lat0.clone(), conditioned_image=cimg.cuda(), masks=mask.cuda(), n_slots=n_it)
+    assert eng.plan.B == 16 and eng.nW == 8
+    eng.step(noise=[n.cuda() for n in noises[0]], shift_noise=shifts[0].cuda())
+    eng.sync_to()
+    torch.cuda.synchronize()
+    eps = eng.plan.out.reshape(16, 4, T, H, W).float().clone()              # [cond windows | uncond windows], reference call order
+    xp, p0 = [[v.clone() for v in vs] for vs in eng.window_outputs()]
+    q1, em0 = eng.latents().clone(), eng.emitted_frames(0, 1).clone()
+    # ---- (1) the engine's eps rows == B = 1 launches of the same window
+    wins = list(fifo_windows(args))
+    ts_all = np.concatenate([np.full((T // 2,), s.ddim_timesteps[0]), s.ddim_timesteps])
+    idx_all = np.concatenate([np.full((T // 2,), 0), np.arange(S)])
+    cc = torch.cat([c1, c2], 1)
+    for w in (0, 3, 7):
+        s0, _, e0 = wins[w]
+        xw = lat0[:, :, s0:e0].contiguous()
+        tw = torch.as_tensor(ts_all[s0:e0].copy()).long().cuda()
+        e_c = m(xw, tw, context=cc, fps=fps)
+        e_u = m(xw, tw, context=ucx, fps=fps)
+        assert relerr(eps[w:w + 1].cpu(), e_c.cpu()) < TOL_UNET, f"window {w} cond eps"
+        assert relerr(eps[8 + w:9 + w].cpu(), e_u.cpu()) < TOL_UNET, f"window {w} uncond eps"
+    # ---- (2) guidance + ddim_step of the 8 windows + write-back + shift on the oracle, from the HIP eps
+    sch = SO.make_schedule(SO.ddpm_buffers(), S, 1.0)
+    lat, msk = lat0.cpu().clone(), mask.clone()
+    mom = torch.zeros(1, 4, T, H, W)
+    eps_c = eps.cpu()
+    for w, (s0, mid, e0) in enumerate(wins):
+        x = lat[:, :, s0:e0].clone()
+        e = eps_c[8 + w:9 + w] + 12.0 * (eps_c[w:w + 1] - eps_c[8 + w:9 + w])                      # ddim.py:372
+        t = torch.as_tensor(ts_all[s0:e0].copy()).long()
+        out, px0 = SO.ddim_step(sch, x, e, idx_all[s0:e0], cimg[:, :, 0], t, [noises[0][w][:, :, [k]] for k in range(T)], mom,
+                                davis_masks=msk[:, :, s0:e0].clone())
+        assert relerr(xp[w].cpu(), out) < 2e-5, f"window {w} x_prev"
+        assert relerr(p0[w].cpu(), px0) < 2e-5, f"window {w} pred_x0"
+        lat[:, :, mid:e0] = out[:, :, -(T // 2):]
+    assert relerr(em0.cpu(), lat[:, :, [T // 2]]) < 2e-5, "emitted frame"
+    lat = FO.shift_latents(lat, shifts[0])
+    assert relerr(q1.cpu(), lat) < 2e-5, "queue after write-back, FreeInit mix and shift"
+    # ---- (3) capture + replay vs the host-driven HIP loop
+    for i in (1, 2):
+        eng.step(noise=[n.cuda() for n in noises[i]], shift_noise=shifts[i].cuda())
+    assert eng.plan.graph is not None, "the iteration was not captured into a hipGraph"
+    q3, em = eng.latents().clone(), eng.emitted_frames(0, n_it).clone()
+    eng.close()
+    lat_h, m_h = lat0.clone(), mask.cuda().clone()
+    fr_h = fifo_ddim_sampling(args, dm, cond, (1, 4, T, H, W), s, cfg_scale=12.0, uc_emb=ucx, latents=lat_h, conditioned_image=cimg.cuda(),
+                              masks=m_h, n_iterations=n_it, noises=[[n.cuda() for n in row] for row in noises],
+                              shift_noises=[x.cuda() for x in shifts], use_graph=False)
+    assert relerr(q3, lat_h) < 3e-2          # CFG 12 x the fp16 UNet noise, 3 iterations fed back (tests/test_loops_gpu.py: TOL_FIFO)
+    for i in range(n_it):
+        assert relerr(em[:, :, [i]], fr_h[i]) < 3e-2, f"emitted frame {i}"
 
 
 def test_reloading_weights_releases_the_old_graphs(reduced_model):

@@ -166,6 +166,37 @@ def unet_full(om, only_cfgN=False):
     ])
 
 
+def unet_full_b16(om):
+    """The FIFO-iteration operating point (funcs.py:305-355): the windows of one outer iteration, each run through the REAL
+    reference UNet twice as `DDIMSampler.unet` does (ddim.py:362-374) -- 154-token two-prompt context and 77-token
+    unconditional context on the SAME latents / per-frame timesteps.  Two distinct windows (their own latents and 16
+    consecutive timesteps of the 50-step schedule); the B = 16 test tiles them over the 8 window rows of the batched plan."""
+    import yaml
+    with open(os.path.join(REF, "configs/inference_t2v_512_v2.0.yaml")) as f:
+        params = dict(yaml.safe_load(f)["model"]["params"]["unet_config"]["params"])
+    params["use_checkpoint"] = False
+    t0 = time.time()
+    model = om.UNetModel(**params).eval()
+    fill(model, 11)
+    print(f"[full_b16] reference UNet built+filled in {time.time() - t0:.1f}s")
+    sched = np.linspace(0, 999, 50).round().astype(np.int64)[::-1]          # descending, as the queue holds them
+    out = {}
+    ctxs = {154: inp("full_b16.ctx154", (1, 154, 1024)), 77: inp("full_b16.ctx77", (1, 77, 1024))}
+    with torch.no_grad():
+        for w, lo in (("w0", 4), ("w1", 30)):
+            x = inp(f"full_b16.{w}.x", (1, 4, 16, 40, 64))
+            t = torch.from_numpy(np.ascontiguousarray(sched[lo:lo + 16]))
+            out[f"{w}__t"] = t
+            for L, ctx in ctxs.items():
+                t1 = time.time()
+                y = model(x, t, context=ctx, fps=torch.tensor([10]), clean_cond=True, gamma=0.5)
+                print(f"[full_b16] {w} L={L}: forward {time.time() - t1:.1f}s, out std {y.std():.4f}")
+                out[f"{w}_{L}"] = y
+    out["fps"] = np.asarray([10])
+    save("unet_full_b16", **out)
+    del model
+
+
 # --------------------------------------------------------------------------------------
 class FakeModel:
     """What DDIMSampler reads from LatentDiffusion; apply_model returns queued eps tensors."""
@@ -726,6 +757,7 @@ def main():
     if "loop" in todo: loop_cases()
     if "full" in todo: unet_full(om)
     if "fullN" in todo: unet_full(om, only_cfgN=True)
+    if "fullB16" in todo: unet_full_b16(om)
 
 
 if __name__ == "__main__":
