@@ -96,7 +96,7 @@ def test_fifo_two_iterations_vs_oracle(models):
             t = torch.as_tensor(ts_all[s0:e0].copy()).long()
             e_c, e_u = _oracle_eps(sd, x, t, ctx2, uctx, fps, cfg)
             eps = e_u + cfg * (e_c - e_u)
-            out, _ = SO.ddim_step(sch, x, eps, idx_all[s0:e0], cimg[:, :, 0], t, [noises[i][wi][:, :, [k]] for k in range(f)], mom,
+            out, _ = SO.ddim_step(sch, x, eps, idx_all[s0:e0], cimg, t, [noises[i][wi][:, :, [k]] for k in range(f)], mom,
                                   davis_masks=msk[:, :, s0:e0].clone())
             lat[:, :, mid:e0] = out[:, :, -(f // 2):]
         frames_ref.append(lat[:, :, [f // 2]].clone())

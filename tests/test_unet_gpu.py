@@ -459,7 +459,7 @@ def test_fifo_engine_full_size_iteration_vs_oracle_step(full_dm):
         x = lat[:, :, s0:e0].clone()
         e = eps_c[8 + w:9 + w] + 12.0 * (eps_c[w:w + 1] - eps_c[8 + w:9 + w])                      # ddim.py:372
         t = torch.as_tensor(ts_all[s0:e0].copy()).long()
-        out, px0 = SO.ddim_step(sch, x, e, idx_all[s0:e0], cimg[:, :, 0], t, [noises[0][w][:, :, [k]] for k in range(T)], mom,
+        out, px0 = SO.ddim_step(sch, x, e, idx_all[s0:e0], cimg, t, [noises[0][w][:, :, [k]] for k in range(T)], mom,
                                 davis_masks=msk[:, :, s0:e0].clone())
         assert relerr(xp[w].cpu(), out) < 2e-5, f"window {w} x_prev"
         assert relerr(p0[w].cpu(), px0) < 2e-5, f"window {w} pred_x0"
