@@ -117,8 +117,8 @@ typedef struct moca_gemm_params {
     const float* lnf_wsum; /* MOCA_EP_LNFOLD: f32 [N], sum over k of the packed fp16 W'[n][k]                           */
     int32_t     lnf_nparts;
     int32_t     reserved2_;
-    int64_t*    gstat;     /* MOCA_EP_GSTAT: i64 [M / gstat_rows][32][2] fixed-point accumulators (sum in 2^-30 units, sum of squares
-                              in 2^-16 units: integer atomics, so the result does not depend on the arrival order of the blocks) per
+    int64_t*    gstat;     /* MOCA_EP_GSTAT: i64 [M / gstat_rows][32][2] fixed-point accumulators (sum in 2^-20 units, sum of squares
+                              in 2^-12 units: integer atomics, so the result does not depend on the arrival order of the blocks) per
                               (statistics group, GroupNorm channel group of N / 32 columns)                             */
     int32_t     gstat_rows;/* rows per statistics group (frames_per_stat * H*W of the consumer's GroupNorm)             */
     float       tattn_scale;/* MOCA_EP_TATTN: softmax scale (dim_head ** -0.5); frames / pixels per frame in T / HW     */
@@ -451,7 +451,8 @@ int moca_event_destroy(void* ev);
 #define MOCA_TUNE_GEMM_SQP   7   /* persistent 256 x 256 kernel (register epilogue): 0 never, 1 GEGLU linears, 2 every linear it can run               */
 #define MOCA_TUNE_SQP_WALK   8   /* tile walk of the persistent 256 x 256 kernel: 0 strided over the XCD's blocks, 1 a contiguous range per block           */
 #define MOCA_TUNE_SLAB_F16   9   /* split-K partial slabs of the 256-row kernel: 0 fp32, 1 fp16 (A/B of VERDICT r4 #5's candidate; changes results within the fp16 tolerance) */
-#define MOCA_TUNE_COUNT      10
+#define MOCA_TUNE_GEMM_WS    10  /* weight-stationary streaming kernel of the 320 -> 320 linears (gemm_ws.hip): 0 never, 1 where it applies                */
+#define MOCA_TUNE_COUNT      11
 int moca_set_tuning(int32_t knob, int32_t value);
 
 /* device query: returns 0 and fills name[len] / cu count, or MOCA_E_NODEVICE */

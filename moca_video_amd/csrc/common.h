@@ -24,6 +24,10 @@ static inline hipStream_t moca_stream(void* s) { return reinterpret_cast<hipStre
 // current value of a MOCA_TUNE_* knob (runtime.hip; set through moca_set_tuning)
 int moca_tuning_get(int knob);
 
+// gemm_ws.hip: the weight-stationary streaming kernel of the 320 -> 320 linears (dispatched by moca_gemm_f16)
+bool moca_gemm_ws_ok(const moca_gemm_params& p);
+int moca_gemm_ws_launch(const moca_gemm_params& p, hipStream_t st);
+
 // x * sigmoid(x) with v_exp + v_rcp (1 ulp each, far below the fp16 output resolution) instead of an IEEE division: the
 // GroupNorm apply pass runs it on every activation and the division's ~10 instructions were a third of its VALU work
 __device__ __forceinline__ float moca_silu(float x) {
@@ -114,20 +118,24 @@ __device__ __forceinline__ f32x4g moca_geglu4(f32x4g v, f32x4g g) {
 
 // GroupNorm statistics accumulated across blocks (MOCA_EP_GSTAT, concat with statistics): 64-bit FIXED-POINT atomics -- integer
 // addition is associative, so the finished statistics do not depend on the order in which the producer's blocks arrive and a
-// replayed graph reproduces its output bit for bit by construction (f64 atomicAdd did so only "in practice").  Sum: 2^-30 units
-// (|sum| < 8.6e9), sum of squares: 2^-16 units (< 1.4e14, i.e. an rms of 1.8e4 over a 4e5-element group: beyond what fp16
-// activations can hold); the rounding of a partial to those units changes a group's mean of squares by < 2^-17 * partials / elements
-// < 1e-8, far below the eps (1e-6 / 1e-5) added to the variance.
-// A NON-FINITE partial (NaN / Inf activations) must not turn into finite statistics: it sets bit 62 of the group's sum-of-squares
-// accumulator (acc layout [group][2] = {sum, sum of squares}) and adds nothing; OR is idempotent, so the bit survives however many
-// partials are poisoned.  A finite partial beyond +-2^53 units (8.4e6 as a sum, 1.4e11 as a sum of squares: an rms of 3.3e3 over
-// a 320 x 40 tile -- fp16 activations within a factor 20 of their overflow) POISONS the group the same way (it used to be
-// clamped, which gave finite but wrong statistics).  moca_gstat_get returns NaN when the sum-of-squares accumulator is >= 2^61 -- the
+// replayed graph reproduces its output bit for bit by construction (f64 atomicAdd did so only "in practice").
+// Units (round 6; 2^-30 / 2^-16 before): sum 2^-20, sum of squares 2^-12.  What they must hold: one PARTIAL (a row tile x a
+// channel group, <= 320 x 40 = 12 800 values) is accepted up to 2^53 units, a group's TOTAL up to 2^61 units:
+//     sum:            |partial| < 8.6e9 (a mean of 6.7e5 over 12 800 values), |total| < 2.2e12      -- beyond fp16 (max 65 504)
+//     sum of squares:  partial  < 2.2e12 (rms 1.3e4 over 12 800 values),      total  < 5.6e14 (rms 3.7e4 over the largest group,
+//                      409 600 values): a tensor at that rms already holds fp16 infinities.
+//   The old units stopped at a partial rms of 3.3e3 -- reached by the latents of bench.py's synthetic video (~4e3), whose statistics
+//   were then CLAMPED, i.e. silently wrong.  Precision: rounding a partial to the units changes a group's mean by
+//   < 2^-21 * partials / values and its mean of squares by < 2^-13 * partials / values <= 2^-13 / 400 = 3e-7 at worst (a 5 x 8 x
+//   10-value partial), below the 1e-6 / 1e-5 eps added to the variance.
+// A NON-FINITE partial (NaN / Inf activations) or one beyond +-2^53 units must not turn into finite statistics: it sets bit 62 of
+// the group's sum-of-squares accumulator (acc layout [group][2] = {sum, sum of squares}) and adds nothing; OR is idempotent, so the
+// bit survives however many partials are poisoned.  moca_gstat_get returns NaN when the sum-of-squares accumulator is >= 2^61 -- the
 // poison bit, or accepted adds that came within a factor 2 of it (a group of the UNet receives <= 2^10 partials: rows of a statistics
 // group / 160-row tiles x 2 column tiles, so accepted adds stay below 2^63 and cannot wrap): statistics outside the fixed-point
 // range read back as NaN, never as a wrong finite number, and finite adds can not alias the poison bit unnoticed.
-#define MOCA_GSTAT_SUM_SCALE 1073741824.0
-#define MOCA_GSTAT_SQ_SCALE 65536.0
+#define MOCA_GSTAT_SUM_SCALE 1048576.0        /* 2^20 */
+#define MOCA_GSTAT_SQ_SCALE 4096.0            /* 2^12 */
 #define MOCA_GSTAT_POISON (1ull << 62)
 #define MOCA_GSTAT_MAX_UNITS 9007199254740992.0      /* 2^53 */
 __device__ __forceinline__ void moca_gstat_add(int64_t* acc, int comp, float partial) {

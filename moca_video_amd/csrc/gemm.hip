@@ -3415,8 +3415,15 @@ static inline bool takes_sq256(const moca_gemm_params& p, bool use_g4) {
 static inline bool fast_gather(const moca_gemm_params& p) {
     return (p.a_mode == MOCA_A_LINEAR) ? (p.K % BK == 0 && p.K <= 8192) : (p.C % BK == 0 && p.C <= 8192);
 }
+// the weight-stationary streaming kernel of the 320 -> 320 linears (gemm_ws.hip; MOCA_TUNE_GEMM_WS = 0: never).  Asked FIRST by every
+// predicate below: a call it takes runs on none of the tiled kernels.  (The queries -- moca_gemm_colsum_rows / _rowsum_cols / _lnfold_ok /
+// _ln_ok -- add the flag they ask about before they come here: the kernel has no column sums, no LayerNorm fold, no LayerNorm store.)
+static inline bool takes_ws(const moca_gemm_params& p) {
+    return moca_tuning_get(MOCA_TUNE_GEMM_WS) && moca_gemm_ws_ok(p);
+}
 // does this (validated, split-normalised) call run on the 320 x 160 kernels / on their staggered buffer-addressed form?
 static inline bool takes_w80(const moca_gemm_params& p) {
+    if (takes_ws(p)) return false;
     const int w80_mode = moca_tuning_get(MOCA_TUNE_GEMM_W80);
     const int tiles320 = ((p.M + 319) / 320) * (p.N / 160);
     return w80_mode && p.N % 160 == 0 && !(p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32 | MOCA_FORCE_SMALL_TILE)) && p.M > 160 &&
@@ -3436,7 +3443,9 @@ static inline bool w80s_wide(const moca_gemm_params& p) {
     if (mode == 0 || p.N % 320) return false;
     return p.a_mode == MOCA_A_LINEAR || mode == 2;
 }
-static inline bool takes_w80t_ln(const moca_gemm_params& p) {     // the 160 x 320 tiling with the LayerNorm store loop
+static inline bool takes_w80t_ln(const moca_gemm_params& pp) {     // the 160 x 320 tiling with the LayerNorm store loop
+    moca_gemm_params p = pp;
+    p.flags |= MOCA_EP_LN;
     return p.a_mode == MOCA_A_LINEAR && p.N == 320 && p.splits == 1 && takes_w80s(p) && !(p.flags & (MOCA_EP_COLSUM | MOCA_EP_GSTAT));
 }
 
@@ -3581,7 +3590,7 @@ static void normalise_splits(moca_gemm_params& p) {
 // does this (validated, split-normalised) call run on the 256-row direct-to-LDS kernel (gemm_glds_kernel), and with which BN?
 // (mirrors the dispatch order of moca_gemm_f16: w80 family first, then sq256, then g4, then glds)
 static int takes_glds_bn(const moca_gemm_params& p) {
-    if (takes_w80(p)) return 0;
+    if (takes_ws(p) || takes_w80(p)) return 0;
     const int big_bn = (p.N % 128 == 0) ? 128 : (p.N % 160 == 0 ? 160 : 0);
     if (!(big_bn != 0 && p.M > 128 && !(p.flags & MOCA_FORCE_SMALL_TILE))) return 0;
     const bool use_g4 = !(p.flags & MOCA_EP_OUT_F32) && wants_g4(p);
@@ -3591,7 +3600,9 @@ static int takes_glds_bn(const moca_gemm_params& p) {
 }
 // rows per tile of the column sums a MOCA_EP_COLSUM launch leaves behind (0: this call cannot): 320 / 160 on the staggered kernel,
 // 256 on the 256-row kernel (fp16 output, no GEGLU, no split-k)
-static int colsum_rows(const moca_gemm_params& p) {
+static int colsum_rows(const moca_gemm_params& pp) {
+    moca_gemm_params p = pp;
+    if (!(p.flags & (MOCA_EP_COLSUM | MOCA_EP_GSTAT))) p.flags |= MOCA_EP_COLSUM;      // (the question is about the call WITH column sums)
     if (p.splits != 1) return 0;
     if (takes_w80s(p)) return w80s_wide(p) ? 160 : 320;
     if (!(p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32)) && takes_glds_bn(p) != 0) return 256;
@@ -3599,13 +3610,18 @@ static int colsum_rows(const moca_gemm_params& p) {
 }
 
 // columns per column tile of the row sums a MOCA_EP_ROWSUM launch leaves behind (0: this call cannot)
-static int rowsum_cols(const moca_gemm_params& p) {
+static int rowsum_cols(const moca_gemm_params& pp) {
+    moca_gemm_params p = pp;
+    p.flags |= MOCA_EP_ROWSUM;
+    if (takes_ws(p)) return 80;                       // one partial per wave of the weight-stationary kernel
     if (p.splits != 1 || (p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_GSTAT | MOCA_EP_LN | MOCA_EP_GELU | MOCA_FORCE_SMALL_TILE))) return 0;
     if (takes_w80s(p)) return w80s_wide(p) ? 320 : 160;
     return takes_glds_bn(p);
 }
 // does the kernel this call runs on have the MOCA_EP_LNFOLD epilogue?
-static bool lnfold_ok(const moca_gemm_params& p) {
+static bool lnfold_ok(const moca_gemm_params& pp) {
+    moca_gemm_params p = pp;
+    p.flags |= MOCA_EP_LNFOLD;
     if (p.a_mode != MOCA_A_LINEAR || p.splits != 1) return false;
     if (p.flags & (MOCA_EP_OUT_F32 | MOCA_EP_COLSUM | MOCA_EP_GSTAT | MOCA_EP_LN | MOCA_EP_ROWSUM | MOCA_EP_GELU | MOCA_FORCE_SMALL_TILE)) return false;
     if (takes_sqp(p) || takes_g4p(p)) return true;
@@ -3811,7 +3827,9 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
         return launch_gemm_w80s<MOCA_A_LINEAR, 3>(p, st);
     }
     if ((p.flags & MOCA_EP_LNFOLD) && !(p.lnf_part && p.lnf_wsum && p.lnf_nparts >= 1 && lnfold_ok(p))) return MOCA_E_BADARG;   // ask moca_gemm_lnfold_ok() first
-    if (p.a2) {                                       // (cat_ok: a staggered-kernel call)
+    if (takes_ws(p)) {
+        rc = moca_gemm_ws_launch(p, st);
+    } else if (p.a2) {                                // (cat_ok: a staggered-kernel call)
         rc = launch_gemm_w80_mode(p, st);
     } else if (takes_sqp(p)) {
         rc = (p.flags & MOCA_EP_GEGLU) ? launch_gemm_sqp<true>(p, st) : launch_gemm_sqp<false>(p, st);

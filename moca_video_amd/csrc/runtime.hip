@@ -105,7 +105,7 @@ extern "C" int moca_memset_zero(void* ptr, int64_t bytes, void* stream) {
 }
 
 // ---- kernel-choice knobs for tests / A-B runs (never results): one table instead of getenv() calls in the launchers
-static int g_tuning[MOCA_TUNE_COUNT] = {1, 1, 1, 1, 1, 1, 0, 1, 0, 0};
+static int g_tuning[MOCA_TUNE_COUNT] = {1, 1, 1, 1, 1, 1, 0, 1, 0, 0, 1};
 int moca_tuning_get(int knob) { return (knob >= 0 && knob < MOCA_TUNE_COUNT) ? g_tuning[knob] : 0; }
 extern "C" int moca_set_tuning(int32_t knob, int32_t value) {
     if (knob < 0 || knob >= MOCA_TUNE_COUNT || value < 0 || value > 2) return MOCA_E_BADARG;

@@ -24,6 +24,7 @@ MOCA_EP_GEGLU, MOCA_EP_OUT_F32, MOCA_FORCE_SMALL_TILE, MOCA_EP_GELU, MOCA_EP_COL
 MOCA_EP_ROWSUM, MOCA_EP_LNFOLD, MOCA_EP_GSTAT, MOCA_EP_TATTN, MOCA_EP_SLABS = 64, 128, 256, 512, 1024
 MOCA_TUNE_GEMM_W80, MOCA_TUNE_GEMM_G4, MOCA_TUNE_GEMM_SQ256, MOCA_TUNE_GEMM_WIDE, MOCA_TUNE_GN_SLAB, MOCA_TUNE_GEMM_G4P, MOCA_TUNE_GEMM_MF32, MOCA_TUNE_GEMM_SQP, MOCA_TUNE_SQP_WALK = 0, 1, 2, 3, 4, 5, 6, 7, 8
 MOCA_TUNE_SLAB_F16 = 9
+MOCA_TUNE_GEMM_WS = 10
 
 _ERR = {0: "ok", -1: "bad argument (shape/alignment contract)", -2: "HIP launch/runtime error",
         -3: "no gfx950 device", -4: "graph capture/replay failed"}

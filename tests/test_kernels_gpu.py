@@ -72,6 +72,56 @@ def test_gemm_rowadd_f32out():
     check(out, ref, 1e-3, "gemm rowadd f32")
 
 
+@pytest.mark.parametrize("M,res,rows,bias,pad", [(8192, True, True, True, 0), (8192, False, False, False, 0), (10016, True, False, True, 64),
+                                               (81920, True, True, True, 0), (81920, False, True, True, 32), (40960, "inplace", True, True, 0)])
+def test_gemm_weight_stationary_320(M, res, rows, bias, pad):
+    """gemm_ws.hip: the weight-stationary streaming kernel of the 320 -> 320 linears (W as MFMA fragments in registers, A and the residual
+    through an LDS-DMA ring, register epilogue) against fp32 torch AND against the tiled kernel it replaces (knob off): one strip per
+    block, uneven strips per block (313 strips on 256 blocks), 10 strips per block; bias / residual / row sums; padded row strides;
+    `out` aliasing `residual` (attention.py:217-219: x = attn(norm(x)) + x in place)."""
+    K = N = 320
+    a_full, w = rnd(M, K + pad), rnd(N, K, scale=K ** -0.5)
+    a = a_full[:, :K]
+    b = rnd(N, dtype=torch.float32) if bias else None
+    pw = ops.pack_linear(w, b)
+    r_full = rnd(M, N + pad) if res else None
+    r = r_full[:, :N] if res else None
+    ref = a.float() @ w.float().t() + (b if bias else 0.0) + (r.float() if res else 0.0)
+    assert ops.gemm_rowsum_cols(a, pw, M=M, residual=r, rowsum=True) == 80, "the weight-stationary kernel leaves one row partial per wave"
+    outs = []
+    for knob in (1, 0):
+        old = L.set_tuning(L.MOCA_TUNE_GEMM_WS, knob)
+        try:
+            cols = ops.gemm_rowsum_cols(a, pw, M=M, residual=r, rowsum=True)
+            o_full = torch.full((M, N + pad), float("nan"), dtype=torch.float16, device=DEV)
+            out = o_full[:, :N]
+            rr = r
+            if res == "inplace":
+                out = r.clone()
+                rr = out
+            part = torch.full((N // cols * M, 2), float("nan"), dtype=torch.float32, device=DEV) if rows else None
+            ops.gemm(a, pw, out, M=M, residual=rr, rowsum=part)
+            check(out, ref, TOL16, f"ws={knob} linear {M}x320x320 res={res} rows={rows}")
+            if pad:
+                assert torch.isnan(o_full[:, N:]).all(), "wrote outside the output columns"
+            if rows:
+                ps = part.view(N // cols, M, 2).sum(0)
+                of = out.float()
+                assert relerr(ps[:, 0], of.sum(1)) < 1e-4 and relerr(ps[:, 1], (of * of).sum(1)) < 1e-4, "row sums of the stored values"
+            outs.append(out.clone())
+        finally:
+            L.set_tuning(L.MOCA_TUNE_GEMM_WS, old)
+    assert relerr(outs[0], outs[1]) < 1e-3, "weight-stationary vs tiled kernel"
+    # refused shapes fall through to the tiled kernels: M not a multiple of 32, a row add
+    assert ops.gemm_rowsum_cols(a[:M - 8], pw, M=M - 8, rowsum=True) != 80
+    # repeatable to the bit (no atomics, fixed strip -> block map)
+    o2 = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(a, pw, o2, M=M, residual=None if res == "inplace" else r)
+    o3 = torch.empty_like(o2)
+    ops.gemm(a, pw, o3, M=M, residual=None if res == "inplace" else r)
+    assert torch.equal(o2, o3)
+
+
 @pytest.mark.parametrize("splits", [1, 2])
 def test_gemm_geglu(splits):
     M, K, inner = 520, 320, 1280
@@ -223,7 +273,7 @@ def test_gemm_colsum_feeds_groupnorm(mode, Fr, HW, C, N, fps, with_res):
     ops.gemm(a, pw, out2, M=M, residual=res, gstat=(gst, fps * HW), **kw)
     assert torch.equal(out2, out)
     xg = out.float().view(n_sg, fps * HW, 32, N // 32)
-    gs = gst.view(n_sg, 32, 2).double() * torch.tensor([2.0 ** -30, 2.0 ** -16], dtype=torch.float64, device=DEV)   # fixed point
+    gs = gst.view(n_sg, 32, 2).double() * torch.tensor([2.0 ** -20, 2.0 ** -12], dtype=torch.float64, device=DEV)   # fixed point
     assert relerr(gs[..., 0], xg.sum(dim=(1, 3))) < 1e-3 and relerr(gs[..., 1], (xg * xg).sum(dim=(1, 3))) < 1e-3
     gst2 = torch.zeros_like(gst)
     ops.gemm(a, pw, out2, M=M, residual=res, gstat=(gst2, fps * HW), **kw)
@@ -486,7 +536,7 @@ def test_gemm_upconv_phases(Fr, H, W, C, N):
         assert torch.equal(out2, out)
         acc = torch.zeros_like(gst)
         ops.gstat_accum(out, acc, F=Fr, HW=4 * H * W, Cn=N, frames_per_stat=1, cpg=gw, coff=coff)
-        sc = torch.tensor([2.0 ** -30, 2.0 ** -16], dtype=torch.float64, device=DEV)
+        sc = torch.tensor([2.0 ** -20, 2.0 ** -12], dtype=torch.float64, device=DEV)
         assert relerr(gst.view(Fr, 32, 2).double() * sc, acc.view(Fr, 32, 2).double() * sc) < 2e-3
     else:
         assert (Fr, H, W) != (32, 20, 32), "the 640-channel Upsample of the B = 2 forward is expected to take the statistics epilogue"
@@ -713,7 +763,7 @@ def test_concat_with_groupnorm_statistics(Fr, HW, C1, C2):
     ref = torch.cat([a, b], dim=1)
     assert torch.equal(out, ref)
     xg = ref.float().view(Fr, HW, 32, C // 32)
-    gs = gst.view(Fr, 32, 2).double() * torch.tensor([2.0 ** -30, 2.0 ** -16], dtype=torch.float64, device=DEV)   # fixed point
+    gs = gst.view(Fr, 32, 2).double() * torch.tensor([2.0 ** -20, 2.0 ** -12], dtype=torch.float64, device=DEV)   # fixed point
     assert relerr(gs[..., 0], xg.sum(dim=(1, 3))) < 1e-3 and relerr(gs[..., 1], (xg * xg).sum(dim=(1, 3))) < 1e-3
     g, be = rnd(C, dtype=torch.float32) * 0.2 + 1.0, rnd(C, dtype=torch.float32) * 0.2
     y = torch.empty_like(out)
@@ -737,9 +787,10 @@ def test_concat_with_groupnorm_statistics(Fr, HW, C1, C2):
         keep[1, gi] = False
         assert torch.equal(yv.permute(0, 2, 1, 3)[keep], gref.view(Fr, HW, 32, cpg).permute(0, 2, 1, 3)[keep].to(y.dtype)) or \
             relerr(yv.permute(0, 2, 1, 3)[keep], gref.view(Fr, HW, 32, cpg).permute(0, 2, 1, 3)[keep]) < TOL16
-    # LARGE finite activations: a group at rms 1e3 lies inside the fixed-point range and must be right; at rms 2e4 a
-    # partial can leave the range -- that group then reads back NaN (poisoned), never finite-but-wrong (it used to be clamped)
-    for scale, must_match in ((1.0e3, True), (2.0e4, False)):
+    # LARGE finite activations: a group at rms 1e3 or 4e3 (the latents of bench.py's synthetic video) lies inside the
+    # fixed-point range and must be right; at rms 3e4 a partial can leave the range -- that group then reads back NaN (poisoned),
+    # never finite-but-wrong (out-of-range partials used to be clamped)
+    for scale, must_match in ((1.0e3, True), (4.0e3, True), (3.0e4, False)):
         a2 = a.clone()
         a2[HW:2 * HW, :cpg] = (torch.randn(HW, cpg, device=DEV) * scale).clamp(-6.0e4, 6.0e4).half()
         gst.zero_()
@@ -902,7 +953,7 @@ def test_groupnorm_virtual_cat(Fr, HW, C1, C2, own):
     gacc = torch.zeros(Fr * 64, dtype=torch.int64, device=DEV)
     ops.gstat_accum(h, gacc, F=Fr, HW=HW, Cn=C1, frames_per_stat=1, cpg=gw, coff=0)
     ops.gstat_accum(sk, gacc, F=Fr, HW=HW, Cn=C2, frames_per_stat=1, cpg=gw, coff=C1)
-    sc = torch.tensor([2.0 ** -30, 2.0 ** -16], dtype=torch.float64, device=DEV)
+    sc = torch.tensor([2.0 ** -20, 2.0 ** -12], dtype=torch.float64, device=DEV)
     assert relerr(gacc.view(Fr, 32, 2).double() * sc, gst.view(Fr, 32, 2).double() * sc) < 1e-6
     y1 = torch.empty_like(y)
     ops.groupnorm_gstat_cat(h, sk, y1, g, be, gacc, None, F=Fr, HW=HW, C1=C1, C2=C2, frames_per_stat=1, eps=1e-5, silu=True)
