@@ -3419,7 +3419,11 @@ static inline bool fast_gather(const moca_gemm_params& p) {
 // predicate below: a call it takes runs on none of the tiled kernels.  (The queries -- moca_gemm_colsum_rows / _rowsum_cols / _lnfold_ok /
 // _ln_ok -- add the flag they ask about before they come here: the kernel has no column sums, no LayerNorm fold, no LayerNorm store.)
 static inline bool takes_ws(const moca_gemm_params& p) {
-    return moca_tuning_get(MOCA_TUNE_GEMM_WS) && moca_gemm_ws_ok(p);
+    const int mode = moca_tuning_get(MOCA_TUNE_GEMM_WS);
+    if (!mode || !moca_gemm_ws_ok(p)) return false;
+    // 1: where it was measured ahead of the tiled kernel (profiles/r06_ab_gemm_ws.txt): with a residual at every size, without one from
+    // M = 2^17 up (B = 16 forwards; at M = 81920 a block's 10 strips do not amortise its start-up: W fetch + first strip).  2: wherever it applies
+    return mode == 2 || p.residual || p.M >= (1 << 17);
 }
 // does this (validated, split-normalised) call run on the 320 x 160 kernels / on their staggered buffer-addressed form?
 static inline bool takes_w80(const moca_gemm_params& p) {

@@ -7,31 +7,41 @@
 // Why another kernel.  These launches move 3 x M x 640 B (A in, residual in, out) for 2 x M x 320 x 320 FLOP: 0.10 of the matrix pipe at
 // the HBM rate.  On the staggered 160 x 320 tiling (gemm_w80s_kernel<0, 1>) a CU runs prologue -> main loop -> store loop once per
 // 160-row tile and nothing streams during two of the three phases (profiles/r05_g4_phase_stamps.txt: store loop 45 %, main loop
-// 31 %, prologue 17 % of a tile), and the 200 KB weight matrix is re-streamed L2 -> LDS for every 100 KB of A: 3.5-4.0 TB/s isolated,
-// ~2.9 TB/s inside the graph (cold residual).  Here
-//   * W never moves again: each of a block's 4 waves keeps its 80 output columns x 320 k of W as MFMA fragments in 200 registers
-//     (one wave per SIMD, 512 registers each; loaded once per block);
-//   * A AND the residual rows stream through one LDS ring by LDS-DMA, 3 strips of 32 rows (40 KB each) ahead of the strip being
-//     computed -- every byte a block needs is requested ~100 KB ahead and no wave ever waits for a register load (vmcnt is in-order:
-//     one register load consumed per strip would pull the whole DMA queue in with it);
+// 31 %, prologue 17 % of a tile), and the 200 KB weight matrix is re-streamed L2 -> LDS for every 100 KB of A: 3.7-4.0 TB/s.  Here
+//   * W never moves again: wave (c, h) of a block's 8 -- column group c = wave & 3 (on SIMD c), K half h = wave >> 2 -- keeps its 80
+//     output columns x 160 k of W as MFMA fragments in 100 registers, loaded once per block;
+//   * A AND the residual rows stream through one LDS ring by LDS-DMA, 32-row strips, 2 (with a residual: 40 KB each) or 5 strips ahead
+//     of the one being computed, and no wave ever waits for a register load: vmcnt retires loads, LDS-DMA and stores together IN
+//     ISSUE ORDER, one register load consumed per strip would pull the whole DMA queue in with it.  For the same reason the wait for
+//     the next strip is counted exactly -- younger DMA pieces AND the store groups issued since -- and the output leaves with plain
+//     stores (a non-temporal store is acknowledged late and holds the counter: 252 -> 222 us / 337 -> 251 us at M = 655360);
 //   * a DMA instruction fetches ONE MFMA fragment (16 rows x 64 B of A: lane l takes row l % 16, chunk l / 16) or one accumulator-
 //     shaped piece of the residual, so its 1 KB lands contiguously and is read back with ds_read_b128 at base + 16 lane: no swizzle,
 //     no bank conflict, addresses are immediates;
-//   * the epilogue runs from registers: W rows are assigned to MFMA rows in a permuted order so that a lane's accumulators in two
-//     neighbouring tiles are 8 consecutive output columns (16-byte stores, 16 rows x 64 B per instruction);
-//   * one s_barrier per strip; the waits are counted (`vmcnt(20)`: the two younger strips stay in flight).
+//   * a wave multiplies BOTH row tiles of a strip by its K half (50 MFMAs), hands the partial sums of row tile 1 - h to its partner
+//     through LDS (5 KB per wave, plain stores: hipcc pads the MFMA -> LDS-write hazard, an inline-asm ds_write does not and read
+//     stale accumulators) and finishes row tile h from registers: W rows are assigned to MFMA rows in a permuted order so that a
+//     lane's accumulators in two neighbouring tiles are 8 consecutive output columns (16-byte stores, 16 rows x 64 B per instruction);
+//   * strips are dealt round-robin (block b: b, b + G, ...): the G blocks stream one contiguous window; a contiguous range per block
+//     put all of them M / G rows apart -- the same HBM channels -- and ran 1.2-1.3 x slower;
+//   * two s_barriers per strip (strip landed / partials exchanged).
+// The first form had 4 waves (one per SIMD, all of K: 200 registers of W, 512-register budget): what a strip cost was the SUM of what
+// its one wave issued -- DMA pieces, fragment reads, 100 MFMAs, epilogue -- 3-8 % behind this form at M = 655360, 5-10 % at M = 81920.
+// Measured (profiles/r06_ab_gemm_ws.txt, same box, alternating, cold operands): M = 655360 +res 318 -> 247 us (5.1 TB/s of algorithmic
+// bytes), +res +rowsum 321 -> 265, plain 228 -> 188; M = 81920 +res 46.5 -> 42.1, +res +rowsum 47.0 -> 43.2, plain 33.4 -> 37.2 (a block's
+// 10 strips do not amortise its start-up: the dispatch takes it only with a residual or from M = 2^17 up).
 // Algorithmic bytes per launch: M x 640 B x (2 + residual) + 200 KB x blocks of W (from L2).
 #include "common.h"
 
 namespace {
 
 typedef __attribute__((address_space(3))) char* lds_ptr;
-constexpr unsigned WS_OOB = 0x80000000u;
-constexpr int WS_C = 320;                       // N == K
-constexpr int WS_ROWS = 32;                     // rows per strip (two MFMA row tiles)
-constexpr int WS_KSTEPS = WS_C / 32;            // 10 k-steps of v_mfma_f32_16x16x32_f16
-constexpr int WS_A_BYTES = WS_ROWS * WS_C * 2;  // 20 KiB: 20 fragments of 1 KiB, [row tile][k-step]
-constexpr int WS_R_BYTES = WS_ROWS * WS_C * 2;  // 20 KiB: per wave 5 pieces of 1 KiB, [wave][piece]
+[[maybe_unused]] constexpr unsigned WS_OOB = 0x80000000u;
+[[maybe_unused]] constexpr int WS_C = 320;                       // N == K
+[[maybe_unused]] constexpr int WS_ROWS = 32;                     // rows per strip (two MFMA row tiles)
+[[maybe_unused]] constexpr int WS_KSTEPS = WS_C / 32;            // 10 k-steps of v_mfma_f32_16x16x32_f16
+[[maybe_unused]] constexpr int WS_A_BYTES = WS_ROWS * WS_C * 2;  // 20 KiB: 20 fragments of 1 KiB, [row tile][k-step]
+[[maybe_unused]] constexpr int WS_R_BYTES = WS_ROWS * WS_C * 2;  // 20 KiB: per wave 5 pieces of 1 KiB, [wave][piece]
 // ring: 160 KiB either way -- 4 slots of (A + residual) = 40 KiB with a residual, 8 slots of 20 KiB without; SLOTS - 1 strips in flight
 // ahead of the one being computed
 
@@ -41,8 +51,6 @@ __device__ __forceinline__ int ws_col(int j, int i) {
     if (j == 4) return 64 + i;
     return 32 * (j >> 1) + 8 * (i >> 2) + 4 * (j & 1) + (i & 3);
 }
-
-template <int V> struct int_c { static constexpr int value = V; };
 
 // s_waitcnt vmcnt(BASE + min(k, MAXK) * STEP) with immediate operands
 template <int BASE, int STEP, int MAXK, int I = 0>
@@ -58,187 +66,167 @@ __device__ __forceinline__ void ws_wait(int k) {
 }
 
 template <bool RES, bool ROWSUM>
-__global__ __launch_bounds__(256) void gemm_ws_kernel(const moca_gemm_params p, const int nstrips) {
+__global__ __launch_bounds__(512) void gemm_ws_kernel(const moca_gemm_params p, const int nstrips) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // vmcnt retires loads, LDS-DMA and stores together in issue order, so "strip k + 1 has landed" = all but the N youngest operations are
-    // done, N = the DMA pieces AND the stores this wave has issued since: AHEAD - 1 groups of each (N <= 63 bounds AHEAD without a residual)
-    constexpr int DMA_PER_STRIP = RES ? 10 : 5;  // per wave: 5 fragments of A (+ its 5 residual pieces)
-    constexpr int ST_PER_STRIP = ROWSUM ? 8 : 6; // per wave: 2 row tiles x (16 B, 16 B, 8 B per lane) (+ the row partial)
-    constexpr int WS_SLOT = WS_A_BYTES + (RES ? WS_R_BYTES : 0), WS_SLOTS = RES ? 4 : 8, WS_AHEAD = RES ? 3 : (ROWSUM ? 5 : 6);
-    constexpr int WAIT_N = (WS_AHEAD - 1) * (DMA_PER_STRIP + ST_PER_STRIP);
-    static_assert(WAIT_N <= 63 && WS_AHEAD <= WS_SLOTS - 1, "vmcnt is a 6-bit counter; a slot is refilled one barrier after its last read");
+    constexpr int SLOT = WS_A_BYTES + (RES ? WS_R_BYTES : 0), SLOTS = RES ? 3 : 6, AHEAD = SLOTS - 1;
+    constexpr int XCH = SLOTS * SLOT;                // 40 KiB exchange area behind the ring: [wave][column tile][lane] f32x4
+    constexpr int ST_PER_STRIP = ROWSUM ? 4 : 3;     // per wave: its row tile's (16 B, 16 B, 8 B per lane) (+ the row partial)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave & 3, h = wave >> 2;
     const int fr = lane & 15, fq = lane >> 4;
-
-    // ---- this block's strips: b, b + G, b + 2 G, ... -- at any moment the G blocks stream ONE contiguous window of G x 20 KB, spread over
-    //      every HBM channel (a contiguous range per block puts all blocks on addresses a multiple of M / G rows apart: 1.2-1.3 x slower
-    //      at M = 655360, profiles/r06_ab_gemm_ws.txt) ----
     const int G = gridDim.x;
-    const int n_my = (nstrips - (int)blockIdx.x + G - 1) / G;
+    const int n_my = (nstrips - (int)blockIdx.x + G - 1) / G;        // strips b, b + G, ... (see the 4-wave kernel)
     if (n_my <= 0) return;
 
-    // ---- DMA stream.  A: fragment f = 5 wave + g (g < 5) of a strip's 20, f = 10 t + s: lane takes row 16 t + fr, bytes 64 s + 16 fq.
-    //      Residual: this wave's own 5 pieces: (t, pair) = 16 rows x 64 B at byte column 160 wave + 64 pair + 16 fq, and the tile-4 piece:
-    //      lanes 0..31 row tile 0, 32..63 row tile 1, 16 B at byte column 160 wave + 128 + 16 (fq & 1). ----
+    // ---- DMA stream: the pieces of a strip = 20 fragments of A (f = 10 t + s) then, with a residual, its 20 pieces (r = 5 c + g, as in the
+    //      4-wave kernel); wave v issues pieces v, v + 8, v + 16 (, v + 24, v + 32): 5 each with a residual, else 3 (v < 4) or 2 ----
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, WS_OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(RES ? p.residual : p.a), 0, WS_OOB, 0x00020000);
-    unsigned a_rel[5], r_rel[5];                 // byte offsets inside a strip (row 0 of the strip = 0)
+    constexpr int NP = RES ? 5 : 3;
+    unsigned rel[NP];
 #pragma unroll
-    for (int g = 0; g < 5; ++g) {
-        const int f = 5 * wave + g, t = f / WS_KSTEPS, s = f - t * WS_KSTEPS;
-        a_rel[g] = (unsigned)(((16 * t + fr) * p.lda) * 2 + 64 * s + 16 * fq);
+    for (int i = 0; i < NP; ++i) {
+        const int q = wave + 8 * i;
+        if (q < 20) {
+            const int t = q / WS_KSTEPS, sk = q - t * WS_KSTEPS;
+            rel[i] = (unsigned)(((16 * t + fr) * p.lda) * 2 + 64 * sk + 16 * fq);
+        } else {
+            const int r = q - 20, c = r / 5, g = r - 5 * c;
+            rel[i] = g < 4 ? (unsigned)(((16 * (g >> 1) + fr) * p.ldr) * 2 + 160 * c + 64 * (g & 1) + 16 * fq)
+                           : (unsigned)(((16 * (fq >> 1) + fr) * p.ldr) * 2 + 160 * c + 128 + 16 * (fq & 1));
+        }
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int t = g >> 1, pr = g & 1;
-        r_rel[g] = (unsigned)(((16 * t + fr) * p.ldr) * 2 + 160 * wave + 64 * pr + 16 * fq);
-    }
-    r_rel[4] = (unsigned)(((16 * (fq >> 1) + fr) * p.ldr) * 2 + 160 * wave + 128 + 16 * (fq & 1));
-    auto issue = [&](int k) {                    // k-th strip of this block -> ring slot k % 4 (k >= n_my: zero fill, no traffic)
+    auto issue = [&](int k, int slot_i) {            // k-th strip of this block -> ring slot slot_i (k >= n_my: zero fill, no traffic)
         const bool live = k < n_my;
         const int64_t row0 = ((int64_t)blockIdx.x + (int64_t)k * G) * WS_ROWS;
         const unsigned a0 = (unsigned)(row0 * p.lda * 2), r0 = (unsigned)(row0 * p.ldr * 2);
-        const lds_ptr slot = (lds_ptr)smem + (k & (WS_SLOTS - 1)) * WS_SLOT;
+        const lds_ptr slot = (lds_ptr)smem + slot_i * SLOT;
 #pragma unroll
-        for (int g = 0; g < 5; ++g)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, slot + (5 * wave + g) * 1024, 16, live ? a_rel[g] + a0 : WS_OOB, 0, 0, 0);
-        if constexpr (RES) {
-#pragma unroll
-            for (int g = 0; g < 5; ++g)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_r, slot + WS_A_BYTES + (5 * wave + g) * 1024, 16, live ? r_rel[g] + r0 : WS_OOB, 0, 0, 0);
+        for (int i = 0; i < NP; ++i) {
+            const int q = wave + 8 * i;                                  // (wave-uniform)
+            if (RES || q < 20) {
+                if (q < 20) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, slot + q * 1024, 16, live ? rel[i] + a0 : WS_OOB, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_r, slot + q * 1024, 16, live ? rel[i] + r0 : WS_OOB, 0, 0, 0);
+            }
         }
     };
-    // ---- W: this wave's 80 columns x 320 k as 5 x 10 MFMA fragments (A operand of the swapped product: lane = W row fr of the tile,
-    //      k chunk fq), once per block; bias of the lane's 20 output columns ----
-    half8v wf[5][WS_KSTEPS];
+
+    // ---- W: 80 columns x the K half h as 5 x 5 MFMA fragments, once per block; bias of the lane's 20 output columns ----
+    half8v wf[5][5];
     {
         const half_t* w = reinterpret_cast<const half_t*>(p.w);
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const half_t* wr = w + (int64_t)(80 * wave + ws_col(j, fr)) * p.ldw + 8 * fq;
+            const half_t* wr = w + (int64_t)(80 * wc + ws_col(j, fr)) * p.ldw + 160 * h + 8 * fq;
 #pragma unroll
-            for (int s = 0; s < WS_KSTEPS; ++s) wf[j][s] = *reinterpret_cast<const half8v*>(wr + 32 * s);
+            for (int sk = 0; sk < 5; ++sk) wf[j][sk] = *reinterpret_cast<const half8v*>(wr + 32 * sk);
         }
     }
-    float bias[20];                                  // columns 80 wave + {8 fq .. +7, 32 + 8 fq .. +7, 64 + 4 fq .. +3}
+    float bias[20];                                  // columns 80 wc + {8 fq .. +7, 32 + 8 fq .. +7, 64 + 4 fq .. +3}
 #pragma unroll
     for (int c = 0; c < 20; ++c) bias[c] = 0.f;
     if (p.bias) {
-        const float* bp = p.bias + 80 * wave;
+        const float* bp = p.bias + 80 * wc;
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp + 8 * fq), b1 = *reinterpret_cast<const f32x4*>(bp + 8 * fq + 4);
         const f32x4 b2 = *reinterpret_cast<const f32x4*>(bp + 32 + 8 * fq), b3 = *reinterpret_cast<const f32x4*>(bp + 32 + 8 * fq + 4);
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 64 + 4 * fq);
 #pragma unroll
         for (int c = 0; c < 4; ++c) { bias[c] = b0[c]; bias[4 + c] = b1[c]; bias[8 + c] = b2[c]; bias[12 + c] = b3[c]; bias[16 + c] = b4[c]; }
     }
-    // (W and the bias are requested BEFORE the stream starts: vmcnt retires in order, behind the first strips' DMAs they would arrive
-    //  only after those -- an HBM round trip later than needed)
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);               // (W and the bias are requested before the stream starts: vmcnt retires in order)
 #pragma unroll
-    for (int k0 = 0; k0 < WS_AHEAD; ++k0) issue(k0);
+    for (int k0 = 0; k0 < AHEAD; ++k0) issue(k0, k0);
+
     half_t* const out = reinterpret_cast<half_t*>(p.out);
-#ifdef MOCA_WS_ABLATE                            // timing-only diagnostic builds (wrong results): 1 one k-step of MFMAs, 2 no stores, 4 no epilogue reads
-    constexpr int abl = MOCA_WS_ABLATE;
-#else
-    constexpr int abl = 0;
-#endif
-    const unsigned a_rd = (unsigned)lane * 16;                                      // fragment read: base + 16 lane
-    const unsigned r_rd = (unsigned)(WS_A_BYTES + 5 * wave * 1024) + (unsigned)lane * 16;
-    const unsigned r4_rd = (unsigned)(WS_A_BYTES + (5 * wave + 4) * 1024) + (unsigned)(((fq >> 1) * 16 + fr) * 16 + (fq & 1) * 8);
+    const unsigned ax_rd = (unsigned)(((1 - h) * WS_KSTEPS + 5 * h) * 1024) + (unsigned)lane * 16;   // fragments of k-steps 5 h .. 5 h + 4 of row tile 1 - h
+    const unsigned am_rd = (unsigned)((h * WS_KSTEPS + 5 * h) * 1024) + (unsigned)lane * 16;         // ... of row tile h
+    const unsigned r_rd = (unsigned)(WS_A_BYTES + (5 * wc + 2 * h) * 1024) + (unsigned)lane * 16;
+    const unsigned r4_rd = (unsigned)(WS_A_BYTES + (5 * wc + 4) * 1024) + (unsigned)((h * 32 + (fq >> 1) * 16 + fr) * 16 + (fq & 1) * 8);
+    char* const x_wr = smem + XCH + wave * 5120 + lane * 16;
+    const char* const x_rd = smem + XCH + (wc + 4 * (1 - h)) * 5120 + lane * 16;
 
     // strip 0 has landed (this wave's share; the younger strips may stay in flight)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WS_AHEAD - 1) * DMA_PER_STRIP) : "memory");      // (no stores yet)
+    if (RES || h == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * 2) : "memory");
+    int cur = 0, nxt = AHEAD;                        // ring slots of strip k and of strip k + AHEAD (= the slot of strip k - 1)
     for (int k = 0; k < n_my; ++k) {
-        // strip k has landed everywhere (each wave waited for its share at the end of the previous iteration) and every wave is done
-        // with strip k - 1, whose slot the stream refills now
-        __builtin_amdgcn_s_barrier();
-        issue(k + WS_AHEAD);
-        const char* slot = smem + (k & (WS_SLOTS - 1)) * WS_SLOT;
-        const int64_t row0 = ((int64_t)blockIdx.x + (int64_t)k * G) * WS_ROWS;
-        half8v o0[2], o1[2];
-        half4v o2[2];
-        float sum[2], sq[2];
-        // every fragment read of the strip is issued before the first MFMA (80 registers; the compiler's own schedule kept two reads in
-        // flight and the matrix pipe idled for an LDS round trip in each of the 10 k-steps: 2.0 us of arithmetic per strip)
-        half8v af[2][WS_KSTEPS];
+        __builtin_amdgcn_s_barrier();                // B1: strip k has landed everywhere; everybody is done with strip k - 1 and its exchange
+        issue(k + AHEAD, nxt);
+        const char* slot = smem + cur * SLOT;
+        const int64_t m = ((int64_t)blockIdx.x + (int64_t)k * G) * WS_ROWS + 16 * h + fr;
+        // afx / accx: the row tile the PARTNER finishes (1 - h), afm / accm: this wave's (h) -- selected by address, not by branches
+        half8v afx[5], afm[5];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int sk = 0; sk < 5; ++sk) afx[sk] = *reinterpret_cast<const half8v*>(slot + ax_rd + sk * 1024);
 #pragma unroll
-            for (int s = 0; s < WS_KSTEPS; ++s) af[t][s] = *reinterpret_cast<const half8v*>(slot + (t * WS_KSTEPS + s) * 1024 + a_rd);
-        half8v r0v[2], r1v[2];
-        half4v r2v[2];
+        for (int sk = 0; sk < 5; ++sk) afm[sk] = *reinterpret_cast<const half8v*>(slot + am_rd + sk * 1024);
+        half8v r0v, r1v;
+        half4v r2v;
         if constexpr (RES) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                r0v[t] = *reinterpret_cast<const half8v*>(slot + r_rd + (2 * t) * 1024);
-                r1v[t] = *reinterpret_cast<const half8v*>(slot + r_rd + (2 * t + 1) * 1024);
-                r2v[t] = *reinterpret_cast<const half4v*>(slot + r4_rd + t * 512);
-            }
+            r0v = *reinterpret_cast<const half8v*>(slot + r_rd);
+            r1v = *reinterpret_cast<const half8v*>(slot + r_rd + 1024);
+            r2v = *reinterpret_cast<const half4v*>(slot + r4_rd);
         }
-        __builtin_amdgcn_sched_barrier(0);           // (keeps the reads above: the machine scheduler sinks them back next to their MFMAs)
-        f32x4 acc[2][5];
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 accx[5], accm[5];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int j = 0; j < 5; ++j) { accx[j] = f32x4{0.f, 0.f, 0.f, 0.f}; accm[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // the partner's row tile first: its partial sums leave as early as possible
 #pragma unroll
-            for (int j = 0; j < 5; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // epilogue arithmetic of one row tile: lane = row fr, columns 80 wave + {8 fq .. +7, 32 + 8 fq .. +7, 64 + 4 fq .. +3}
-        auto finish = [&](auto t_tag) {
-            constexpr int t = decltype(t_tag)::value;
-            sum[t] = 0.f; sq[t] = 0.f;
+        for (int sk = 0; sk < 5; ++sk)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float v0 = acc[t][c >> 2][c & 3] + bias[c], v1 = acc[t][2 + (c >> 2)][c & 3] + bias[8 + c];
-                if constexpr (RES) { v0 += (float)r0v[t][c]; v1 += (float)r1v[t][c]; }
-                o0[t][c] = (half_t)v0; o1[t][c] = (half_t)v1;
-                if constexpr (ROWSUM) {
-                    const float h0 = (float)o0[t][c], h1 = (float)o1[t][c];
-                    sum[t] += h0 + h1; sq[t] += h0 * h0 + h1 * h1;
-                }
-            }
+            for (int j = 0; j < 5; ++j) accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][sk], afx[sk], accx[j], 0, 0, 0);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float v = acc[t][4][c] + bias[16 + c];
-                if constexpr (RES) v += (float)r2v[t][c];
-                o2[t][c] = (half_t)v;
-                if constexpr (ROWSUM) { const float h = (float)o2[t][c]; sum[t] += h; sq[t] += h * h; }
-            }
-            if constexpr (ROWSUM) {                  // partial `wave` of 4: (sum, sum of squares) over this wave's 80 stored columns of a row
-                sum[t] += __shfl_xor(sum[t], 16, 64); sq[t] += __shfl_xor(sq[t], 16, 64);
-                sum[t] += __shfl_xor(sum[t], 32, 64); sq[t] += __shfl_xor(sq[t], 32, 64);
-            }
-        };
-        // (tile 0's epilogue arithmetic placed in the MFMA gaps of tile 1 with sched_group_barrier: no difference, 253 vs 253 us / 279 vs 270 us
-        //  at M = 655360 -- what a strip costs is the sum of what its ONE wave per SIMD issues: DMA pieces, fragment reads, MFMAs, epilogue)
+        for (int j = 0; j < 5; ++j) *reinterpret_cast<f32x4*>(x_wr + j * 1024) = accx[j];      // (plain stores: hipcc pads the MFMA -> LDS-write hazard)
 #pragma unroll
-        for (int s = 0; s < ((abl & 1) ? 1 : WS_KSTEPS); ++s)
+        for (int sk = 0; sk < 5; ++sk)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int j = 0; j < 5; ++j) accm[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][sk], afm[sk], accm[j], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          // (the exchange writes have left)
+        __builtin_amdgcn_s_barrier();                // B2: every partial is in the exchange area
+        f32x4 mine[5];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][s], af[t][s], acc[t][j], 0, 0, 0);
-        finish(int_c<0>{});
-        finish(int_c<1>{});
-        // strip k + 1 has landed (this wave's share), counted exactly: the younger DMA groups and the store groups issued since stay in
-        // flight.  (First form: the wait counted the DMA pieces only and sat behind the strip's fresh stores -- it then also waited for
-        // AHEAD - 1 younger strips' worth of operations, and with `nt` stores, acknowledged late, the kernel was 1.1-1.4 x slower than the
-        // tiled one.)  Strip k has min(k, AHEAD - 1) store groups behind DMA(k + 1): counting more than exist would let the wait pass early.
-        __builtin_amdgcn_sched_barrier(0);           // (the wait is not hoisted into the MFMA sequence)
-        ws_wait<(WS_AHEAD - 1) * DMA_PER_STRIP, ST_PER_STRIP, WS_AHEAD - 1>(k);
-        if (!(abl & 2) || p.M < 0)               // (ablation: a never-taken branch keeps the arithmetic alive)
+        for (int j = 0; j < 5; ++j) mine[j] = accm[j] + *reinterpret_cast<const f32x4*>(x_rd + j * 1024);
+        // ---- epilogue of this wave's 16 rows: lane = row fr, columns 80 wc + {8 fq .. +7, 32 + 8 fq .. +7, 64 + 4 fq .. +3} ----
+        half8v o0, o1;
+        half4v o2;
+        float sum = 0.f, sq = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int64_t m = row0 + 16 * t + fr;
-            half_t* orow = out + m * p.ldo + 80 * wave;
-            // (plain stores also where the tiled kernels stream their output with `nt`: a non-temporal store is acknowledged late, and
-            //  vmcnt counts it -- the next strip's wait then pulls the younger loads in with it: 252 -> 222 us / 337 -> 251 us at M = 655360)
-            *reinterpret_cast<half8v*>(orow + 8 * fq) = o0[t];
-            *reinterpret_cast<half8v*>(orow + 32 + 8 * fq) = o1[t];
-            *reinterpret_cast<half4v*>(orow + 64 + 4 * fq) = o2[t];
+        for (int c = 0; c < 8; ++c) {
+            float v0 = mine[c >> 2][c & 3] + bias[c], v1 = mine[2 + (c >> 2)][c & 3] + bias[8 + c];
+            if constexpr (RES) { v0 += (float)r0v[c]; v1 += (float)r1v[c]; }
+            o0[c] = (half_t)v0; o1[c] = (half_t)v1;
             if constexpr (ROWSUM) {
-                if (fq == 0) *reinterpret_cast<f32x2*>(p.rowsum + ((int64_t)wave * p.M + m) * 2) = f32x2{sum[t], sq[t]};
+                const float h0 = (float)o0[c], h1 = (float)o1[c];
+                sum += h0 + h1; sq += h0 * h0 + h1 * h1;
             }
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = mine[4][c] + bias[16 + c];
+            if constexpr (RES) v += (float)r2v[c];
+            o2[c] = (half_t)v;
+            if constexpr (ROWSUM) { const float hh = (float)o2[c]; sum += hh; sq += hh * hh; }
+        }
+        if constexpr (ROWSUM) {                      // partial `wc` of 4: (sum, sum of squares) over the 80 stored columns of row m
+            sum += __shfl_xor(sum, 16, 64); sq += __shfl_xor(sq, 16, 64);
+            sum += __shfl_xor(sum, 32, 64); sq += __shfl_xor(sq, 32, 64);
+        }
+        // strip k + 1 has landed (this wave's share), counted exactly: AHEAD - 1 younger DMA groups and the store groups issued since
+        __builtin_amdgcn_sched_barrier(0);
+        if (RES || h == 0) ws_wait<(AHEAD - 1) * NP, ST_PER_STRIP, AHEAD - 1>(k);
+        else ws_wait<(AHEAD - 1) * 2, ST_PER_STRIP, AHEAD - 1>(k);
+        half_t* orow = out + m * p.ldo + 80 * wc;
+        *reinterpret_cast<half8v*>(orow + 8 * fq) = o0;
+        *reinterpret_cast<half8v*>(orow + 32 + 8 * fq) = o1;
+        *reinterpret_cast<half4v*>(orow + 64 + 4 * fq) = o2;
+        if constexpr (ROWSUM) {
+            if (fq == 0) *reinterpret_cast<f32x2*>(p.rowsum + ((int64_t)wc * p.M + m) * 2) = f32x2{sum, sq};
+        }
+        cur = cur + 1 == SLOTS ? 0 : cur + 1;
+        nxt = nxt + 1 == SLOTS ? 0 : nxt + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                // (the zero-fill tail of the stream)
 #endif
@@ -265,7 +253,7 @@ int ws_launch2(const moca_gemm_params& p, hipStream_t st) {
             return MOCA_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_ws_kernel<RES, ROWSUM>), dim3(grid), dim3(256), lds, st, p, nstrips);
+    hipLaunchKernelGGL((gemm_ws_kernel<RES, ROWSUM>), dim3(grid), dim3(512), lds, st, p, nstrips);
     MOCA_CHECK_LAUNCH();
     return MOCA_OK;
 }

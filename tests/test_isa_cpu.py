@@ -43,10 +43,11 @@ MAIN_LOOPS = {
     "gemm_g4p_kernel<false>": (64, 12, 24, 2),
     **{f"gemm_glds_kernel<128, {m}, {f}>": (32, 6, 16, 1) for m in range(3) for f in ("true", "false")},
     **{f"gemm_glds_kernel<160, {m}, {f}>": (40, 7, 18, 1) for m in range(3) for f in ("true", "false")},
-    # weight-stationary 320 -> 320 kernel: a 32-row strip per body = 2 row tiles x 10 k-steps x 5 column tiles of MFMAs with W in registers,
-    # 5 LDS-DMA fragments of A (+ 5 residual pieces), 20 fragment reads (+ 5 / 6 residual reads), ONE barrier
-    "gemm_ws_kernel<false, false>": (100, 5, 20, 1), "gemm_ws_kernel<false, true>": (100, 5, 20, 1),
-    "gemm_ws_kernel<true, false>": (100, 10, 25, 1), "gemm_ws_kernel<true, true>": (100, 10, 25, 1),
+    # weight-stationary 320 -> 320 kernel (8 waves, K halves): per 32-row strip a wave issues 2 row tiles x 5 k-steps x 5 column tiles of MFMAs
+    # with W in registers, its share of the strip's LDS-DMA pieces (5 with a residual, 2-3 without: the conditional third is outside the
+    # loop body the report isolates), 10 fragment reads + 5 exchange reads (+ 3 residual reads)
+    "gemm_ws_kernel<false, false>": (50, 2, 15, None), "gemm_ws_kernel<false, true>": (50, 2, 15, None),
+    "gemm_ws_kernel<true, false>": (50, 5, 18, 2), "gemm_ws_kernel<true, true>": (50, 5, 18, 2),
 }
 
 
@@ -55,11 +56,13 @@ def test_main_loops_have_the_designed_instruction_counts_and_no_dma_drain(isa):
         assert name in isa, f"{name} is not in the library"
         lp = isa[name]["loop"]
         assert lp is not None, f"{name}: no MFMA loop found"
-        got = (lp["mfma"], lp["lds_dma"], lp["ds_read"], lp["barrier"])
+        got = (lp["mfma"], lp["lds_dma"], lp["ds_read"], lp["barrier"] if barr is not None else None)
         assert got == (mfma, dma, dsrd, barr), f"{name}: main loop (MFMA, LDS-DMA, ds_read, barriers) = {got}, designed {(mfma, dma, dsrd, barr)}"
         assert lp["vmcnt0"] == 0, f"{name}: {lp['vmcnt0']} `s_waitcnt vmcnt(0)` in the main loop ({lp['vmcnt0_inside']} between its MFMAs): " \
                                   "the DMA stream is drained every iteration (DESIGN 4.1)"
-        assert lp["ds_write"] == 0 and lp["global_load"] == 0, f"{name}: register-staged traffic in the main loop: {lp}"
+        if not name.startswith("gemm_ws_"):           # (its partial-sum exchange is 5 ds_write_b128 per strip by design)
+            assert lp["ds_write"] == 0, f"{name}: LDS writes in the main loop: {lp}"
+        assert lp["global_load"] == 0, f"{name}: register-staged traffic in the main loop: {lp}"
 
 
 # the plain / `+res` flavour of the persistent kernel is NOT in the default dispatch (MOCA_TUNE_GEMM_SQP=2 only): hipcc
@@ -79,13 +82,11 @@ def test_no_kernel_spills_vector_registers_or_uses_scratch(isa):
 
 def test_register_counts_keep_the_designed_occupancy(isa):
     """8-wave blocks (w80s, sqp, glds) and the 4-wave kernels that run two blocks per CU hold two waves per SIMD: <= 256 registers
-    (VGPR + AGPR, unified file of 512 per SIMD lane; the weight-stationary kernel is one wave per SIMD by design); attention_v4 runs four waves per SIMD: <= 128; no AGPR use in the GEMMs (an
+    (VGPR + AGPR, unified file of 512 per SIMD lane); attention_v4 runs four waves per SIMD: <= 128; no AGPR use in the GEMMs (an
     accumulator that moves to AGPRs costs v_accvgpr moves in every epilogue)."""
     for name, d in isa.items():
         regs = d.get("vgpr_count", 0) + d.get("agpr_count", 0)
-        if name.startswith("gemm_ws_"):           # one wave per SIMD by design: W lives in 200 registers of the 512
-            assert d.get("vgpr_count", 0) <= 512, f"{name}: {d.get('vgpr_count')} registers"
-        elif name.startswith("gemm_"):
+        if name.startswith("gemm_"):
             assert regs <= 256, f"{name}: {regs} registers: fewer than two waves per SIMD"
             assert d.get("agpr_count", 0) == 0, f"{name}: accumulators moved to AGPRs"
         if "attention_v4" in name:

@@ -87,9 +87,11 @@ def test_gemm_weight_stationary_320(M, res, rows, bias, pad):
     r_full = rnd(M, N + pad) if res else None
     r = r_full[:, :N] if res else None
     ref = a.float() @ w.float().t() + (b if bias else 0.0) + (r.float() if res else 0.0)
-    assert ops.gemm_rowsum_cols(a, pw, M=M, residual=r, rowsum=True) == 80, "the weight-stationary kernel leaves one row partial per wave"
+    old = L.set_tuning(L.MOCA_TUNE_GEMM_WS, 2)
+    assert ops.gemm_rowsum_cols(a, pw, M=M, residual=r, rowsum=True) == 80, "the weight-stationary kernel leaves one row partial per column group"
+    L.set_tuning(L.MOCA_TUNE_GEMM_WS, old)
     outs = []
-    for knob in (1, 0):
+    for knob in (2, 0):                      # weight-stationary kernel wherever it applies; tiled kernel
         old = L.set_tuning(L.MOCA_TUNE_GEMM_WS, knob)
         try:
             cols = ops.gemm_rowsum_cols(a, pw, M=M, residual=r, rowsum=True)
@@ -112,14 +114,18 @@ def test_gemm_weight_stationary_320(M, res, rows, bias, pad):
         finally:
             L.set_tuning(L.MOCA_TUNE_GEMM_WS, old)
     assert relerr(outs[0], outs[1]) < 1e-3, "weight-stationary vs tiled kernel"
-    # refused shapes fall through to the tiled kernels: M not a multiple of 32, a row add
-    assert ops.gemm_rowsum_cols(a[:M - 8], pw, M=M - 8, rowsum=True) != 80
-    # repeatable to the bit (no atomics, fixed strip -> block map)
-    o2 = torch.empty(M, N, dtype=torch.float16, device=DEV)
-    ops.gemm(a, pw, o2, M=M, residual=None if res == "inplace" else r)
-    o3 = torch.empty_like(o2)
-    ops.gemm(a, pw, o3, M=M, residual=None if res == "inplace" else r)
-    assert torch.equal(o2, o3)
+    old = L.set_tuning(L.MOCA_TUNE_GEMM_WS, 2)
+    try:
+        # refused shapes fall through to the tiled kernels: M not a multiple of 32
+        assert ops.gemm_rowsum_cols(a[:M - 8], pw, M=M - 8, rowsum=True) != 80
+        # repeatable to the bit (no atomics, fixed strip -> block map)
+        o2 = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        ops.gemm(a, pw, o2, M=M, residual=None if res == "inplace" else r)
+        o3 = torch.empty_like(o2)
+        ops.gemm(a, pw, o3, M=M, residual=None if res == "inplace" else r)
+        assert torch.equal(o2, o3)
+    finally:
+        L.set_tuning(L.MOCA_TUNE_GEMM_WS, old)
 
 
 @pytest.mark.parametrize("splits", [1, 2])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Same-box alternating A/B of the weight-stationary 320 -> 320 kernel (gemm_ws.hip, MOCA_TUNE_GEMM_WS) against the staggered 160 x 320
+"""Same-box alternating A/B of the weight-stationary 320 -> 320 kernel (gemm_ws.hip, MOCA_TUNE_GEMM_WS = 2: wherever it applies; env MOCA_WS_4WAVE=1: its first, 4-wave form) against the staggered 160 x 320
 tiling it replaces, on the UNet's launches of that shape: plain / +rowsum / +res / +res +rowsum at B = 2 (M = 81920) and B = 16
 (M = 655360).  HOT = the same operands every launch (what an isolated replay sees: at B = 2 they sit in the 256 MB Infinity Cache);
 COLD = the launches rotate through enough operand sets to exceed it (what a launch inside the graph sees: A and the residual were
@@ -46,15 +46,14 @@ def bench(M, res, rows, cold, knob, iters=30):
 if __name__ == "__main__":
     ops.set_stream(None)
     rounds = int(os.environ.get("ROUNDS", "2"))
-    print(f"{'launch':44s} {'tiled us':>9s} {'GB/s':>6s} {'ws us':>9s} {'GB/s':>6s}  ratio")
+    print(f"{'launch':44s} {'tiled us':>9s} {'GB/s':>6s} {'ws us':>9s} {'GB/s':>6s}  ws/tiled")
     for M in (81920, 655360):
         for res, rows in ((False, False), (False, True), (True, False), (True, True)):
             for cold in (False, True):
-                t = [[], []]
+                t = {0: [], 2: []}
                 for _ in range(rounds):
-                    for knob in (0, 1):
+                    for knob in (0, 2):
                         t[knob].append(bench(M, res, rows, cold, knob))
-                a = min(x[0] for x in t[0]), max(x[1] for x in t[0])
-                b = min(x[0] for x in t[1]), max(x[1] for x in t[1])
+                a, b = ((min(x[0] for x in tt), max(x[1] for x in tt)) for tt in (t[0], t[2]))
                 name = f"lin M={M} 320x320{' +res' if res else ''}{' +rowsum' if rows else ''} {'COLD' if cold else 'hot'}"
                 print(f"{name:44s} {a[0]:9.1f} {a[1]:6.0f} {b[0]:9.1f} {b[1]:6.0f}  {b[0] / a[0]:.3f}", flush=True)
