@@ -454,6 +454,11 @@ int moca_event_destroy(void* ev);
 #define MOCA_TUNE_GEMM_WS    10  /* weight-stationary streaming kernel of the 320 -> 320 linears (gemm_ws.hip): 0 never, 1 where it applies                */
 #define MOCA_TUNE_COUNT      11
 int moca_set_tuning(int32_t knob, int32_t value);
+/* Measurement aid, no counterpart in the reference (tools/clock_in_step.py): `blocks` one-wave blocks each record `nsamples` pairs
+ * (shader-cycle counter, 100 MHz real-time counter) ~8 us apart into buf = u64 [blocks][nsamples][2] (device memory, zeroed by the
+ * caller) while other streams' launches run: the shader clock the chip holds under THAT load, per interval.  Stops early when *stop
+ * (device-visible, may be NULL) becomes non-zero.                                                                              */
+int moca_debug_clock_sampler(void* buf, int32_t blocks, int32_t nsamples, const int32_t* stop, void* stream);
 
 /* device query: returns 0 and fills name[len] / cu count, or MOCA_E_NODEVICE */
 int moca_device_info(char* name, int32_t len, int32_t* cu_count);

@@ -104,6 +104,34 @@ extern "C" int moca_memset_zero(void* ptr, int64_t bytes, void* stream) {
     return MOCA_OK;
 }
 
+// ---- measurement aid (tools/clock_in_step.py): what shader clock does the chip hold WHILE another stream's launches run?  `blocks` single-
+// wave blocks (one per XCD with blocks = 8: consecutive workgroups go to consecutive XCDs) each record `nsamples` pairs
+// (s_memtime = shader cycles, s_memrealtime = the constant 100 MHz counter) about 8 us apart; between two samples the clock is
+// d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back (6)).  A block occupies one wave slot, no LDS, 8 registers.
+// Bounded by nsamples (and an optional stop flag); results: u64 [blocks][nsamples][2], zeroed by the caller.
+__global__ __launch_bounds__(64) void clock_sampler_kernel(unsigned long long* __restrict__ buf, int nsamples, const volatile int* stop) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x) return;
+    unsigned long long* b = buf + (size_t)blockIdx.x * nsamples * 2;
+    for (int i = 0; i < nsamples; ++i) {
+        unsigned long long t, r;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r)::"memory");
+        b[2 * i] = t;
+        b[2 * i + 1] = r;
+        if (stop && *stop) break;
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+}
+extern "C" int moca_debug_clock_sampler(void* buf, int32_t blocks, int32_t nsamples, const int32_t* stop, void* stream) {
+    if (!buf || blocks < 1 || blocks > 64 || nsamples < 1 || nsamples > (1 << 20)) return MOCA_E_BADARG;
+    hipLaunchKernelGGL(clock_sampler_kernel, dim3(blocks), dim3(64), 0, moca_stream(stream), reinterpret_cast<unsigned long long*>(buf), nsamples,
+                       reinterpret_cast<const volatile int*>(stop));
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
 // ---- kernel-choice knobs for tests / A-B runs (never results): one table instead of getenv() calls in the launchers
 static int g_tuning[MOCA_TUNE_COUNT] = {1, 1, 1, 1, 1, 1, 0, 1, 0, 0, 1};
 int moca_tuning_get(int knob) { return (knob >= 0 && knob < MOCA_TUNE_COUNT) ? g_tuning[knob] : 0; }

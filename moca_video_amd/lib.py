@@ -137,6 +137,7 @@ SIGNATURES = {
     "moca_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(_f32)]),
     "moca_event_destroy": (C.c_int, [_vp]),
     "moca_set_tuning": (C.c_int, [_i32, _i32]),
+    "moca_debug_clock_sampler": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "moca_device_info": (C.c_int, [C.c_char_p, _i32, C.POINTER(_i32)]),
     "moca_version": (C.c_char_p, []),
 }
