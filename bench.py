@@ -257,7 +257,7 @@ def synthetic_sam_candidates(T, H, W):
     return cands
 
 
-def fifo_leg(dm, device, T, H, W, iters=10, mode="masks"):
+def fifo_leg(dm, device, T, H, W, iters=10, mode="masks", weights="zero-data"):
     """Extra (not the headline value): one outer iteration of the MoCA FIFO loop (configs[2-3]) at full size --
     8 diagonal windows x {cond (2 prompts = 154 tokens), uncond (77)} = 16 UNet-steps as ONE batched forward with two context
     segments, + noise, window gather, guidance, the MoCA ddim_step of the 8 windows with mask injection, write-back, emission,
@@ -326,7 +326,10 @@ def fifo_leg(dm, device, T, H, W, iters=10, mode="masks"):
     return {"iteration_ms": round(dt * 1e3, 2), "iteration_wall_ms": round(wall * 1e3, 2), "unet_steps_per_iteration": 16,
             "unet_steps_per_s": round(16 / dt, 2), "projected_s_per_video_148_iterations": round(148 * dt, 1),
             "one_hipgraph_per_iteration": graph_on, "launches_per_iteration": n_launch, "queue_finite": finite,
-            "note": "synthetic zero-data weights (ZeroDataDenoiser); injection masks handed in (`masks=`: the davis_masks branch of "
+            "note": ("synthetic zero-data weights (ZeroDataDenoiser)" if weights == "zero-data" else
+                     "RANDOM-INIT weights (the headline's): the same iteration graph on the operand statistics the headline runs on -- only a "
+                     "few iterations are bounded on them (see ZeroDataDenoiser), hence 5 timed ones behind 3") +
+                    "; injection masks handed in (`masks=`: the davis_masks branch of "
                     "ddim_step); 8 windows x (154-token cond + 77-token uncond) as ONE B=16 forward with two context segments; noise, "
                     "gather, guidance, MoCA ddim_step x 8, write-back, emission, FreeInit mix, shift in the same hipGraph; VAE decode excluded"}
 
@@ -794,6 +797,9 @@ def main():
         res["emulate_world_8"] = emulate_world_leg(dm, sampler, device, T, H, W)
         note("emulate_world_8 done")
     if world == 1 and not args.no_fifo:
+        # (operand statistics move the clock -- the same iteration on the headline's random-init weights, beside the
+        #  zero-data one the long video leg needs)
+        res["fifo_random_init"] = fifo_leg(dm, device, T, H, W, iters=5, weights="random-init")
         zdd = ZeroDataDenoiser(dm)
         res["fifo"] = fifo_leg(dm, device, T, H, W)
         note("fifo leg done")

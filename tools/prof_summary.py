@@ -16,6 +16,7 @@ for r in rows:
     elif 'gemm_w80s' in n and re.search(r'<\d, 2>|ELi2EEE', n): k = 'gemm_w80s 256x256 (wide GEGLU)'
     elif 'gemm_w80s' in n and re.search(r'<\d, 1>|ELi1EEE', n): k = 'gemm_w80s 160x320'
     elif 'gemm_w80s' in n: k = 'gemm_w80s 320x160'
+    elif 'gemm_ws' in n: k = 'gemm_ws (weight-stationary 320->320 linears with a residual)'
     elif 'gemm_sqp' in n: k = 'gemm_sqp (persistent 256x256, register epilogue: GEGLU)'
     elif 'gemm_g4p' in n or 'gemm_g4q' in n: k = 'gemm_g4p (persistent 256x128)'
     elif 'gemm_w80' in n: k = 'gemm_w80/w80b (320x160)'
