@@ -143,6 +143,12 @@ typedef struct moca_gemm_params {
     int32_t     gstat_cpg; /* MOCA_EP_GSTAT: columns per GroupNorm channel group (0 = N / 32) and the channel index of column 0 inside the   */
     int32_t     gstat_coff;/* consumer's tensor (0): a producer whose output is ONE SOURCE of a virtual concat accumulates the statistics of  */
                            /* the concat's groups, group (gstat_coff + n) / gstat_cpg (< 32), straight into the concat's accumulators        */
+    int32_t     wgroup_rows;   /* MOCA_A_LINEAR only, 0 = off.  > 0: PER-ROW-GROUP weights -- rows [g R, (g + 1) R), R = wgroup_rows, are    */
+    int32_t     wgroup_stride; /* multiplied by the matrix at w + g * wgroup_stride (fp16 elements, >= N * ldw) and take the bias at bias + */
+                           /* g * N: `proj_in(GroupNorm(x))` (attention.py:238-242,262-268 / :297-302,333-341) with the GroupNorm -- whose    */
+                           /* scale and shift are constant over a (frames_per_stat x H x W) row group -- folded into per-group weights by   */
+                           /* moca_groupnorm_fold_weights_f16: the normalised tensor is never written or read.  Only where               */
+                           /* moca_gemm_wgroup_ok() != 0 (the staggered kernels, row tiles inside one group)                            */
 } moca_gemm_params;
 
 /* Replaces F.conv2d 3x3 (openaimodel3d.py:152,177,66-70,96-106,376,531),
@@ -168,6 +174,9 @@ int moca_gemm_lnfold_ok(const moca_gemm_params* p);
 /* 1 when this call can run as MOCA_EP_TATTN (linear, K % 64 == 0, N % 192 == 0, T == 16, HW % 20 == 0, M % (16 HW) == 0,
  * no split-K / residual / row add); else 0 (the caller then runs the projection and moca_temporal_attention_f16).       */
 int moca_gemm_tattn_ok(const moca_gemm_params* p);
+/* 1 when this call (wgroup_rows / wgroup_stride set) can take per-row-group weights (see moca_gemm_params.wgroup_rows); else 0 (the
+ * caller then runs the GroupNorm as a pass of its own).                                                                    */
+int moca_gemm_wgroup_ok(const moca_gemm_params* p);
 /* 1 when this call (a2 / lda2 / k1 set) can read its A operand from two sources (see moca_gemm_params.a2); else 0 (the caller
  * then materialises the concat with moca_concat_channels*_f16).                                                          */
 int moca_gemm_cat_ok(const moca_gemm_params* p);
@@ -200,6 +209,19 @@ int64_t moca_groupnorm_ws_bytes(int32_t F, int32_t HW, int32_t C);
 int moca_groupnorm_colsum_f16(const void* x, void* y, const float* gamma, const float* beta, const float* colsum,
                               int32_t tile_rows, int32_t F, int32_t HW, int32_t C, int32_t frames_per_stat,
                               float eps, int32_t silu, float* ws, void* stream);
+
+/* GroupNorm(32, K, affine, no activation) folded into the Linear(K, N) that consumes it -- `x = self.norm(x); ...; x = self.proj_in(x)`
+ * of SpatialTransformer / TemporalTransformer (attention.py:238-242,262-268 / :297-302,333-341) -- as PER-STATISTICS-GROUP weights:
+ * with mean / rstd of group (sg, k / (K/32)) from the finished statistics gstat i64 [n_sg][32][2] (a MOCA_EP_GSTAT producer; `count` =
+ * values per group = frames_per_stat * H*W * K/32), s[k] = gamma[k] rstd, t[k] = beta[k] - mean rstd gamma[k]:
+ *     wg[sg][n][k] = fp16(w[n][k] * s[k])            (fp16 [n_sg][N][ldw], zero padding copied),
+ *     bg[sg][n]    = bias[n] + sum_k t[k] * w[n][k]    (f32 [n_sg][N]; bias may be NULL),
+ * so that Linear(GroupNorm(x)) = x . wg[sg]^T + bg[sg] for the rows of group sg: moca_gemm_f16 with wgroup_rows = rows per group,
+ * wgroup_stride = N * ldw.  The normalised tensor is never stored (one fp16 rounding less than the reference's layout would need).
+ * A poisoned / out-of-range statistics group yields NaN weights for that group.  K % 32 == 0, K % 8 == 0, ldw % 8 == 0.        */
+int moca_groupnorm_fold_weights_f16(const void* w, const float* bias, const float* gamma, const float* beta, const int64_t* gstat,
+                                    void* wg, float* bg, int32_t n_sg, int32_t N, int32_t K, int32_t ldw, int64_t count, float eps,
+                                    void* stream);
 
 /* The same GroupNorm when the producer of x was a moca_gemm_f16 call with MOCA_EP_GSTAT: gstat i64 [F / frames_per_stat][32][2]
  * holds the finished sums, so this is ONE launch (apply) and x is read once.                                          */

@@ -2503,6 +2503,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
     const int tq_tpv = TQ ? p.HW / 20 : 1;                                   // row tiles per video
     const int tq_b = tile_m / tq_tpv, tq_pb = tile_m - tq_b * tq_tpv;
     auto grow = [&](int tr) -> int { return TQ ? (tq_b * 16 + (tr & 15)) * p.HW + tq_pb * 20 + (tr >> 4) : m0 + tr; };
+    // MOCA per-row-group weights (moca_gemm_params.wgroup_rows: GroupNorm folded into the linear that consumes it): the rows of
+    // a tile lie inside one group (host-checked), whose W / bias start wg x stride further -- an offset, nothing in the main loop
+    const int wg = (AMODE == MOCA_A_LINEAR && p.wgroup_rows > 0) ? m0 / p.wgroup_rows : 0;
+    const unsigned wgo = (unsigned)((int64_t)wg * p.wgroup_stride * 2);
     unsigned w_off[3];
     if constexpr (SQ) {                                  // A pieces w and 8 + w, W pieces w and 8 + w
         ga.init_row(0, m0 + wave * 16 + lrow);
@@ -2523,6 +2527,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
         w_off[1] = (unsigned)(((int64_t)(n0 + (8 + wave) * 16 + lrow) * p.ldw + lch * 8) * 2);       // j = 1
         w_off[2] = (unsigned)(((int64_t)(n0 + (16 + (wave & 3)) * 16 + lrow) * p.ldw + lch * 8) * 2); // j = 2 (waves 0..3)
     }
+    if (wgo) { w_off[0] += wgo; w_off[1] += wgo; w_off[2] += wgo; }
     // (two-source A, MOCA_A_LINEAR2: the A descriptor follows the gather's block-uniform source index -- `sync_src()` behind every
     //  ga.seek() / ga.advance(); one scalar compare per k-tile pair, the other modes compile to the constant descriptors)
     __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, OOB_OFF, 0x00020000);
@@ -2577,7 +2582,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w80s_kernel(const moca_gemm_param
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && p.splits == 1 && !(p.flags & MOCA_EP_LNFOLD)) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + wave_n * WTN + nt * 16 + 4 * fg);
+        if (p.bias && p.splits == 1 && !(p.flags & MOCA_EP_LNFOLD)) bv = *reinterpret_cast<const f32x4*>(p.bias + (int64_t)wg * p.N + n0 + wave_n * WTN + nt * 16 + 4 * fg);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = bv;
     }
@@ -3674,6 +3679,24 @@ extern "C" int moca_gemm_cat_ok(const moca_gemm_params* pp) {
     return cat_ok(p) ? 1 : 0;
 }
 
+// per-row-group weights (wgroup_rows / wgroup_stride): a plain linear on the staggered kernels whose row tiles (160 rows on the
+// 160 x 320 tiling, 320 on 320 x 160) lie inside one group; bias / residual / row sums / LayerNorm store loop / column statistics
+static bool wgroup_ok(const moca_gemm_params& p) {
+    if (p.wgroup_rows <= 0 || p.wgroup_stride < p.N * p.ldw || p.a_mode != MOCA_A_LINEAR || p.a2 || p.splits != 1) return false;
+    if (p.flags & ~(MOCA_EP_COLSUM | MOCA_EP_GSTAT | MOCA_EP_ROWSUM | MOCA_EP_LN)) return false;
+    if (!takes_w80s(p) || p.M % p.wgroup_rows) return false;
+    const int tm = w80s_wide(p) ? 160 : 320;
+    if (p.wgroup_rows % tm) return false;
+    return (int64_t)(p.M / p.wgroup_rows) * p.wgroup_stride * 2 < (1ll << 31);
+}
+extern "C" int moca_gemm_wgroup_ok(const moca_gemm_params* pp) {
+    if (!pp) return 0;
+    moca_gemm_params p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % 64 || p.K % 8) return 0;
+    normalise_splits(p);
+    return wgroup_ok(p) ? 1 : 0;
+}
+
 extern "C" int moca_gemm_rowsum_cols(const moca_gemm_params* pp) {
     if (!pp) return 0;
     moca_gemm_params p = *pp;
@@ -3822,6 +3845,7 @@ extern "C" int moca_gemm_f16(const moca_gemm_params* pp, void* stream) {
               (p.gstat_cpg > 0 ? (p.gstat_coff + p.N - 1) / p.gstat_cpg < 32 : (p.N % 32 == 0 && p.gstat_coff == 0)))) return MOCA_E_BADARG;
     }
     if ((p.flags & MOCA_EP_ROWSUM) && !(p.rowsum && rowsum_cols(p) != 0)) return MOCA_E_BADARG;             // ask moca_gemm_rowsum_cols() first
+    if (p.wgroup_rows < 0 || (p.wgroup_rows > 0 && !wgroup_ok(p))) return MOCA_E_BADARG;                    // ask moca_gemm_wgroup_ok() first
     p.reserved4_ = 0;                                 // (bits 8.. carry the XCD partition chosen by the launcher)
     // bit 0: output rows leave with non-temporal stores when the output is at least half the 256 MiB Infinity Cache (see out_streams)
     if ((int64_t)p.M * (geglu ? p.N / 2 : p.N) * 2 >= (128ll << 20)) p.reserved4_ |= 1;

@@ -263,7 +263,7 @@ int ws_launch2(const moca_gemm_params& p, hipStream_t st) {
 // which calls the kernel can run (validated, split-normalised parameters): a plain linear 320 -> 320 on whole 32-row strips, bias /
 // residual / row sums only, every operand inside the 2 GiB a buffer descriptor's 32-bit offsets reach
 bool moca_gemm_ws_ok(const moca_gemm_params& p) {
-    if (p.a_mode != MOCA_A_LINEAR || p.a2 || p.splits != 1 || p.N != WS_C || p.K != WS_C || p.rowadd || p.up_phase) return false;
+    if (p.a_mode != MOCA_A_LINEAR || p.a2 || p.splits != 1 || p.N != WS_C || p.K != WS_C || p.rowadd || p.up_phase || p.wgroup_rows) return false;
     if (p.flags & ~MOCA_EP_ROWSUM) return false;
     if (p.M % WS_ROWS || p.M < 8192) return false;
     if (p.lda % 8 || p.lda < WS_C || p.ldo % 8 || p.ldo < WS_C || p.ldw % 8 || p.ldw < WS_C || (p.residual && (p.ldr % 8 || p.ldr < WS_C))) return false;

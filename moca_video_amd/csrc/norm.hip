@@ -779,6 +779,77 @@ extern "C" int moca_groupnorm_gstat_f16(const void* x, void* y, const float* gam
     return MOCA_OK;
 }
 
+// ---- GroupNorm folded into the consuming linear as per-statistics-group weights (moca_groupnorm_fold_weights_f16) ----
+// block (sg, row block of 16 W rows): the 2 x K scale / shift values of the group in LDS, then thread = one 8-element chunk of a W row:
+// scaled copy + the dot product with the shift (reduced over the row's chunks through LDS in a fixed order: deterministic)
+__global__ __launch_bounds__(256) void gn_fold_weights_kernel(const half_t* __restrict__ w, const float* __restrict__ bias,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const int64_t* __restrict__ gstat, half_t* __restrict__ wg, float* __restrict__ bg,
+                                                              int N, int K, int ldw, double inv_count, float eps) {
+    extern __shared__ float s_st[];                       // [2][K] scale, shift; then [rows][chunks] partial dots
+    const int sg = blockIdx.x, tid = threadIdx.x;
+    const int cpg = K / GN_GROUPS;
+    __shared__ float s_mr[2 * GN_GROUPS];
+    if (tid < GN_GROUPS) {
+        const double a = moca_gstat_get(gstat + ((int64_t)sg * GN_GROUPS + tid) * 2, 0), b = moca_gstat_get(gstat + ((int64_t)sg * GN_GROUPS + tid) * 2 + 1, 1);
+        const double mean = a * inv_count;
+        double var = b * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mr[2 * tid] = (float)mean;
+        s_mr[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+        const int g = k / cpg;
+        const float sc = s_mr[2 * g + 1] * gamma[k];
+        s_st[k] = sc;
+        s_st[K + k] = beta[k] - s_mr[2 * g] * sc;
+    }
+    __syncthreads();
+    const int cpr = ldw / 8;                              // 16-byte chunks per W row (padding included: copied as zeros x scale 0)
+    float* s_dot = s_st + 2 * K;
+    const int rows_pb = 16;
+    const int n0 = blockIdx.y * rows_pb;
+    for (int idx = tid; idx < rows_pb * cpr; idx += 256) {
+        const int r = idx / cpr, ch = idx - r * cpr, n = n0 + r;
+        float dot = 0.f;
+        if (n < N) {
+            const half8v v = *reinterpret_cast<const half8v*>(w + (int64_t)n * ldw + ch * 8);
+            half8v o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = ch * 8 + j;
+                const float x = (float)v[j];
+                const float sc = k < K ? s_st[k] : 0.f, sh = k < K ? s_st[K + k] : 0.f;
+                o[j] = (half_t)(x * sc);
+                dot += x * sh;
+            }
+            *reinterpret_cast<half8v*>(wg + ((int64_t)sg * N + n) * ldw + ch * 8) = o;
+        }
+        s_dot[idx] = dot;
+    }
+    __syncthreads();
+    if (tid < rows_pb && n0 + tid < N) {
+        float a = bias ? bias[n0 + tid] : 0.f;
+        for (int ch = 0; ch < cpr; ++ch) a += s_dot[tid * cpr + ch];
+        bg[(int64_t)sg * N + n0 + tid] = a;
+    }
+}
+
+extern "C" int moca_groupnorm_fold_weights_f16(const void* w, const float* bias, const float* gamma, const float* beta, const int64_t* gstat,
+                                               void* wg, float* bg, int32_t n_sg, int32_t N, int32_t K, int32_t ldw, int64_t count, float eps,
+                                               void* stream) {
+    if (!w || !gamma || !beta || !gstat || !wg || !bg) return MOCA_E_BADARG;
+    if (n_sg <= 0 || N <= 0 || K <= 0 || K % GN_GROUPS || K % 8 || ldw % 8 || ldw < K || count <= 0) return MOCA_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(wg)) & 15) return MOCA_E_BADARG;
+    const size_t lds = (size_t)(2 * K + 16 * (ldw / 8)) * sizeof(float);
+    if (lds > 60 * 1024) return MOCA_E_BADARG;
+    hipLaunchKernelGGL(gn_fold_weights_kernel, dim3(n_sg, (N + 15) / 16), dim3(256), lds, moca_stream(stream), reinterpret_cast<const half_t*>(w), bias,
+                       gamma, beta, gstat, reinterpret_cast<half_t*>(wg), bg, N, K, ldw, 1.0 / (double)count, eps);
+    MOCA_CHECK_LAUNCH();
+    return MOCA_OK;
+}
+
 extern "C" int moca_concat_channels_gstat_f16(const void* a, const void* b, void* out, int32_t F, int32_t HW, int32_t C1, int32_t C2,
                                               int32_t frames_per_stat, int64_t* gstat, void* stream) {
     if (!a || !b || !out || !gstat || F <= 0 || HW <= 0 || C1 <= 0 || C2 <= 0 || C1 % 8 || C2 % 8) return MOCA_E_BADARG;

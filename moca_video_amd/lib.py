@@ -52,6 +52,7 @@ class GemmParams(C.Structure):
         ("gstat", C.c_void_p), ("gstat_rows", C.c_int32), ("tattn_scale", C.c_float),
         ("prefetch", C.c_void_p), ("up_phase", C.c_int32), ("reserved4_", C.c_int32),
         ("a2", C.c_void_p), ("lda2", C.c_int32), ("k1", C.c_int32), ("gstat_cpg", C.c_int32), ("gstat_coff", C.c_int32),
+        ("wgroup_rows", C.c_int32), ("wgroup_stride", C.c_int32),
     ]
 
 
@@ -85,6 +86,8 @@ SIGNATURES = {
     "moca_gemm_lnfold_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_tattn_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "moca_gemm_cat_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "moca_gemm_wgroup_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "moca_groupnorm_fold_weights_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _f32, _vp]),
     "moca_gemm_splitk_groupnorm_ok": (C.c_int, [C.POINTER(GemmParams), _i32, _i32]),
     "moca_gemm_splitk_groupnorm_f16": (C.c_int, [C.POINTER(GemmParams), _vp, _vp, _vp, _i32, _i32, _f32, _i32, _i32, _vp]),
     "moca_groupnorm_gstat_cat_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),

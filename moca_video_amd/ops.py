@@ -42,11 +42,12 @@ def _round_up(x, m):
 # --------------------------------------------------------------------------------------
 class PackedWeight:
     """fp16 [Npad][Kpad] K-contiguous weight + fp32 bias, as moca_gemm_f16 wants them."""
-    __slots__ = ("w", "bias", "N", "K", "n_out", "geglu", "wsum")
+    __slots__ = ("w", "bias", "N", "K", "n_out", "geglu", "wsum", "derived")
 
     def __init__(self, w, bias, N, K, n_out, geglu=False):
         self.w, self.bias, self.N, self.K, self.n_out, self.geglu = w, bias, N, K, n_out, geglu
         self.wsum = None         # LayerNorm-folded weights only (fold_layernorm): f32 [N], row sums of the packed fp16 W'
+        self.derived = False     # True: written by a launch of the forward itself (groupnorm_fold_weights) -- nothing to prefetch
 
 
 def _finish(w2d: torch.Tensor, bias, device, n_out=None, geglu=False) -> PackedWeight:
@@ -155,8 +156,11 @@ def finish_lnfold(pw: PackedWeight) -> PackedWeight:
 # --------------------------------------------------------------------------------------
 def _gemm_params(a, pw: PackedWeight, out, *, M, lda=None, mode=_l.MOCA_A_LINEAR, rowadd=None, rowadd_div=1,
                  residual=None, conv=None, tconv=None, out_f32=False, splits=1, splitk_ws=None, gelu=False, colsum=None, ln=None,
-                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, up_phase=0, prefetch=None, a2=None, slabs=False):
+                 force_small=False, rowsum=None, lnfold=None, gstat=None, tattn=None, up_phase=0, prefetch=None, a2=None, slabs=False,
+                 wgroup=None):
     p = _l.GemmParams()
+    if wgroup is not None:                   # (rows per group, fp16 elements between two groups' matrices): `pw` = the per-group weights of
+        p.wgroup_rows, p.wgroup_stride = wgroup   # groupnorm_fold_weights (pw.w [n_sg * N][ldw], pw.bias [n_sg * N])
     p.up_phase = up_phase
     if a2 is not None:                       # (second A source fp16 [M][lda2], columns of `a`): A = the virtual cat([a, a2], channels)
         p.a2, p.lda2, p.k1 = a2[0].data_ptr(), a2[0].stride(-2), a2[1]
@@ -239,6 +243,23 @@ def gemm_lnfold_ok(a, pw: PackedWeight, **kw):
     """does the kernel this call runs on have the MOCA_EP_LNFOLD epilogue?"""
     p = _gemm_params(a, pw, None, **kw)
     return bool(_l.load().moca_gemm_lnfold_ok(C.byref(p)))
+
+
+def gemm_wgroup_ok(a, pw: PackedWeight, **kw):
+    """can this call take per-row-group weights (`wgroup`: a GroupNorm folded into the linear that consumes it)?"""
+    p = _gemm_params(a, pw, None, **kw)
+    return bool(_l.load().moca_gemm_wgroup_ok(C.byref(p)))
+
+
+def groupnorm_fold_weights(pw: PackedWeight, gamma, beta, gstat, wg, bg, *, n_sg, count, eps):
+    """wg fp16 [n_sg * N][ldw], bg f32 [n_sg * N] = the weights / bias of `Linear(GroupNorm(x))` per statistics group, from the finished
+    statistics of a MOCA_EP_GSTAT producer (include/moca_hip.h); returns them as a PackedWeight for `gemm(..., wgroup=(rows, N * ldw))`"""
+    _l.check(_l.load().moca_groupnorm_fold_weights_f16(_l.ptr(pw.w), _l.ptr(pw.bias) if pw.bias is not None else None, _l.ptr(gamma), _l.ptr(beta),
+                                                       _l.ptr(gstat), _l.ptr(wg), _l.ptr(bg), n_sg, pw.N, pw.K, pw.w.stride(0), count, eps, _st()),
+             "moca_groupnorm_fold_weights_f16")
+    out = PackedWeight(wg, bg, pw.N, pw.K, pw.n_out)
+    out.derived = True
+    return out
 
 
 def gemm_tattn_ok(a, pw: PackedWeight, **kw):

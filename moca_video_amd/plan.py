@@ -63,6 +63,9 @@ PREFETCH_HOST_FLOP = float(os.environ.get("MOCA_PREFETCH_HOST_GF", "50")) * 1e9
 VIRTUAL_CAT = os.environ.get("MOCA_VCAT", "1") != "0"
 # split-K reduce inside the GroupNorm that consumes it (the 5 x 8-latent level of the B = 2 forward; A/B switch MOCA_SKGN=0)
 SPLITK_GN = os.environ.get("MOCA_SKGN", "1") != "0"
+# GroupNorm of a transformer entry folded into its proj_in as per-statistics-group weights (moca_groupnorm_fold_weights_f16 +
+# moca_gemm_params.wgroup_rows): the normalised tensor is never written.  MOCA_GNFOLD=0: A/B
+GN_FOLD = os.environ.get("MOCA_GNFOLD", "1") != "0"
 SPLITK_GN_ALL = os.environ.get("MOCA_SKGN", "1") == "2"     # (A/B: also the 16-frame GroupNorms of the temporal convs)
 
 
@@ -102,7 +105,7 @@ class _PlanBase:
         """called right before a GEMM step is recorded: weight-heavy -> its weights ride on the PREVIOUS GEMM launch (moca_gemm_params.prefetch:
         spare blocks of that launch's grid stream them into the Infinity Cache while its tiles compute; the small launches in between do
         not matter)"""
-        if self._last_gemm_step is not None and pw.w.numel() * pw.w.element_size() >= PREFETCH_MIN_BYTES:
+        if self._last_gemm_step is not None and not pw.derived and pw.w.numel() * pw.w.element_size() >= PREFETCH_MIN_BYTES:
             self._prefetch_at.setdefault(self._last_gemm_step, []).append(pw.w)
         self._last_gemm_step = len(self.steps)
 
@@ -573,7 +576,7 @@ class _Plan(_PlanBase):
         self._emit(ops.repeat, buf.reshape(-1)[:rows * cols], out, reps=self.reps)
         return out
 
-    def linear_ln(self, a, M, pw, gb, residual=None, consumer=None):
+    def linear_ln(self, a, M, pw, gb, residual=None, consumer=None, wgroup=None):
         """`out = linear(a) (+ residual)` and `l = LayerNorm(out)` (eps 1e-5, attention.py:199-201).
         (1) `consumer` = a callable returning the LayerNorm-folded weights of the ONE linear that reads l: when this launch can
         leave row sums behind (MOCA_EP_ROWSUM) and the consumer's kernel has the fold epilogue (MOCA_EP_LNFOLD), l is an
@@ -582,14 +585,15 @@ class _Plan(_PlanBase):
         followed by the LayerNorm kernel."""
         lda = a.stride(-2)
         splits = self._splits(M, pw)
-        ln_epilogue = ops.gemm_ln_ok(a, pw, M=M, lda=lda, residual=residual, splits=splits, ln=(gb[0], gb[1], None, 1e-5))
+        wk = {} if wgroup is None else {"wgroup": wgroup}      # (`pw` = per-row-group weights: a GroupNorm folded in, see transformer())
+        ln_epilogue = ops.gemm_ln_ok(a, pw, M=M, lda=lda, residual=residual, splits=splits, ln=(gb[0], gb[1], None, 1e-5), **wk)
         # Measured (same device, whole CFG step, tools/ab_run7.sh): fold wherever possible 36.9 ms, fold only where neither the
         # LayerNorm store loop (N = 320) nor more than two row partials apply 37.3, never 37.6.  In isolation the consumers pay
         # 3-12 % for the two FMAs per accumulator and the statistics loads (tools/bench_lnfold.py; worst at K = 320 and with the
         # 10 partials of the 1280-channel level), less than the LayerNorm pass and the second output they replace cost in the
         # graph.  So: fold wherever producer and consumer kernels allow.
         if consumer is not None and splits == 1:
-            cols = ops.gemm_rowsum_cols(a, pw, M=M, lda=lda, residual=residual, splits=1, rowsum=True)
+            cols = ops.gemm_rowsum_cols(a, pw, M=M, lda=lda, residual=residual, splits=1, rowsum=True, **wk)
             nparts = pw.N // cols if cols > 0 else 0
             if cols > 0:
                 pwf = consumer()
@@ -598,14 +602,15 @@ class _Plan(_PlanBase):
                     out = self.pool.get(M, pw.N)
                     part = self.pool.get(nparts * M, 2, torch.float32)
                     self._note_gemm(pw)
-                    self._emit(ops.gemm, a, pw, out, M=M, lda=lda, residual=residual, splits=1, rowsum=part)
+                    self._emit(ops.gemm, a, pw, out, M=M, lda=lda, residual=residual, splits=1, rowsum=part, **wk)
                     return out, _LNRef(out, part, nparts)
         if ln_epilogue:
             out, l = self.pool.get(M, pw.N), self.pool.get(M, pw.N)
             self._note_gemm(pw)
-            self._emit(ops.gemm, a, pw, out, M=M, lda=lda, residual=residual, splits=1, ln=(gb[0], gb[1], l, 1e-5))
+            self._emit(ops.gemm, a, pw, out, M=M, lda=lda, residual=residual, splits=1, ln=(gb[0], gb[1], l, 1e-5), **wk)
             return out, l
-        out = self.linear(a, M, pw, residual=residual)
+        assert wgroup is None or splits == 1
+        out = self._gemm(a, pw, M, lda=lda, residual=residual, **wk)
         return out, self.ln(out, M, pw.N, gb)
 
     def tblock(self, blk, h, l, M, Cn, heads, spatial, F, HW, next_gb=None, next_consumer=None):
@@ -642,14 +647,62 @@ class _Plan(_PlanBase):
         """the folded weights of the projection that reads `norm` in front of attention `att`"""
         return lambda: self._fold_pw("qkv" if att.is_self else "q", att, norm)
 
+    def _gn_fold(self, fm, gb, pw, *, fps, eps):
+        """GroupNorm(32, no activation) -> Linear as ONE GEMM on per-statistics-group weights, where (a) the producer of `fm` can leave the
+        FINISHED statistics behind (the condition of gn()'s single-launch path: a GEMM whose row tiles lie inside one statistics group, or
+        a concat that accumulated them) and (b) the linear runs on a staggered kernel whose row tiles lie inside one group
+        (moca_gemm_wgroup_ok).  Returns (per-group PackedWeight, (rows per group, stride)) or None (the caller runs gn() + the linear)."""
+        if not GN_FOLD or isinstance(fm, _CatMap) or getattr(fm, "slabs", None) is not None or fm.C % 32 or pw.geglu:
+            return None
+        HW, rows = fm.H * fm.W, fps * fm.H * fm.W
+        cs = fm.colsum
+        have = fm.gstat is not None and fm.gstat[1] == fps
+        can = cs is not None and rows % cs[1] == 0 and fm.src is not None and not isinstance(fm.src, tuple)
+        # worth it only while the derived weights (written once, read by the group's row tiles) are small against the tensor the GroupNorm
+        # pass would read and write: rows per group >= 4 N.  (640-channel level, per-frame statistics: 640 rows per group -- 256 frames x
+        # 819 KB of weights at B = 16, as many bytes as the pass itself: measured no gain; that norm stays a launch)
+        if not (have or can) or fm.F % fps or rows < 4 * pw.N:
+            return None
+        stride = pw.N * pw.w.stride(0)
+        if not ops.gemm_wgroup_ok(fm.buf, pw, M=fm.M, lda=fm.buf.stride(-2), splits=self._splits(fm.M, pw), wgroup=(rows, stride)):
+            return None
+        n_sg = fm.F // fps
+        if have:
+            slot = fm.gstat[0]
+        else:                                        # re-target the producer: finished statistics instead of per-tile column sums (as gn())
+            prod = self.steps[fm.src]
+            slot = self._gstat_slot(n_sg * 64)
+            kw = dict(prod.keywords)
+            kw["colsum"] = None
+            kw["gstat"] = (slot, rows)
+            self.steps[fm.src] = functools.partial(prod.func, *prod.args, **kw)
+            self.pool.put(cs[0])
+            fm.colsum = None
+            fm.gstat_own = (slot, fps)
+        wg = self.pool.get(n_sg * pw.N, pw.w.stride(0))
+        bg = self.pool.get(1, n_sg * pw.N, torch.float32)
+        self._emit(ops.groupnorm_fold_weights, pw, gb[0], gb[1], slot, wg, bg, n_sg=n_sg, count=rows * (fm.C // 32), eps=eps)
+        pwg = ops.PackedWeight(wg, bg.reshape(-1), pw.N, pw.K, pw.n_out)
+        pwg.derived = True
+        return pwg, (rows, stride)
+
     def transformer(self, mod, x, spatial):
         """SpatialTransformer.forward attention.py:262-278 / TemporalTransformer.forward :331-373"""
         P = self.P
-        n = self.gn(x, P[id(mod.norm)], fps=1 if spatial else self.T, eps=1e-6, silu=False)
         blocks = list(mod.transformer_blocks)
-        h, l = self.linear_ln(n, x.M, P[id(mod.proj_in)], P[id(blocks[0].norm1)],
-                              consumer=self._ln_consumer(blocks[0].attn1, blocks[0].norm1))
-        self._release(n)
+        fold = self._gn_fold(x, P[id(mod.norm)], P[id(mod.proj_in)], fps=1 if spatial else self.T, eps=1e-6)
+        if fold is not None:
+            # `x = self.norm(x)` (attention.py:262-268 / :333-341) lives in proj_in's per-statistics-group weights: no GroupNorm launch,
+            # the normalised tensor is never written
+            pwg, wgroup = fold
+            h, l = self.linear_ln(x.buf, x.M, pwg, P[id(blocks[0].norm1)], consumer=self._ln_consumer(blocks[0].attn1, blocks[0].norm1),
+                                  wgroup=wgroup)
+            self._release(pwg.w, pwg.bias)
+        else:
+            n = self.gn(x, P[id(mod.norm)], fps=1 if spatial else self.T, eps=1e-6, silu=False)
+            h, l = self.linear_ln(n, x.M, P[id(mod.proj_in)], P[id(blocks[0].norm1)],
+                                  consumer=self._ln_consumer(blocks[0].attn1, blocks[0].norm1))
+            self._release(n)
         M, Fr, xres = x.M, x.F, x.buf
         for i, blk in enumerate(blocks):
             last = i + 1 >= len(blocks)

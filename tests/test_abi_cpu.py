@@ -42,7 +42,7 @@ def test_gemm_params_struct_matches_header():
         decl = re.sub(r"^(const\s+)?(void|float|double|int32_t|uint32_t|int64_t)\s*\*?\s*", "", line)
         names += [n.strip().lstrip("*") for n in decl.split(",") if n.strip()]
     assert names == [f[0] for f in lib.GemmParams._fields_]
-    assert C.sizeof(lib.GemmParams) == 280   # (256 + a2 + lda2 + k1 + gstat_cpg + gstat_coff) 7 pointers + 23 int32 padded to 8, + colsum, ln_gamma, ln_beta, ln_out + ld_ln + ln_eps + rowsum, lnf_part, lnf_wsum + lnf_nparts + pad + gstat + gstat_rows + tattn_scale + sk_sync + sk_big + pad
+    assert C.sizeof(lib.GemmParams) == 288   # (256 + a2 + lda2 + k1 + gstat_cpg + gstat_coff + wgroup_rows + wgroup_stride) 7 pointers + 23 int32 padded to 8, + colsum, ln_gamma, ln_beta, ln_out + ld_ln + ln_eps + rowsum, lnf_part, lnf_wsum + lnf_nparts + pad + gstat + gstat_rows + tattn_scale + sk_sync + sk_big + pad
 
 
 def _header_struct_fields(name):

@@ -128,6 +128,70 @@ def test_gemm_weight_stationary_320(M, res, rows, bias, pad):
         L.set_tuning(L.MOCA_TUNE_GEMM_WS, old)
 
 
+@pytest.mark.parametrize("Fr,HW,C,fps,mode", [(32, 2560, 320, 1, "rowsum"), (32, 2560, 320, 16, "ln"), (32, 640, 640, 1, "rowsum"),
+                                              (32, 640, 640, 16, "plain")])
+def test_gemm_groupnorm_folded_into_per_group_weights(Fr, HW, C, fps, mode):
+    """`proj_in(GroupNorm(x))` of SpatialTransformer / TemporalTransformer (attention.py:238-242,262-268 / :297-302,333-341) as ONE GEMM on
+    per-statistics-group weights (moca_groupnorm_fold_weights_f16 + moca_gemm_params.wgroup_rows): against fp32 torch and against the
+    two-launch path (statistics-fed GroupNorm apply, then the linear); per-frame and per-video statistics; with the row sums / the
+    LayerNorm store loop the consumer of proj_in asks for; poisoned statistics give NaN rows for exactly that group."""
+    M, N, eps = Fr * HW, C, 1e-6
+    x = (rnd(M, C) * 1.7 + 0.6).half()
+    x.view(Fr, HW, C)[1] *= 3.0                                  # (a frame of another scale: the groups must not mix)
+    gm, be = rnd(C, dtype=torch.float32) * 0.3 + 1.0, rnd(C, dtype=torch.float32) * 0.3
+    w, b = rnd(N, C, scale=C ** -0.5), rnd(N, dtype=torch.float32)
+    pw = ops.pack_linear(w, b)
+    n_sg = Fr // fps
+    gst = torch.zeros(n_sg * 64, dtype=torch.int64, device=DEV)
+    ops.gstat_accum(x, gst, F=Fr, HW=HW, Cn=C, frames_per_stat=fps, cpg=C // 32, coff=0)
+    ldw = pw.w.stride(0)
+    wg = torch.empty(n_sg * pw.N, ldw, dtype=torch.float16, device=DEV)
+    bg = torch.empty(n_sg * pw.N, dtype=torch.float32, device=DEV)
+    pwg = ops.groupnorm_fold_weights(pw, gm, be, gst, wg, bg, n_sg=n_sg, count=fps * HW * (C // 32), eps=eps)
+    wgroup = (fps * HW, pw.N * ldw)
+    assert ops.gemm_wgroup_ok(x, pwg, M=M, wgroup=wgroup)
+    xr = x.float().view(n_sg, fps * HW, C).permute(0, 2, 1)
+    y_ref = F.group_norm(xr, 32, gm, be, eps).permute(0, 2, 1).reshape(M, C)
+    ref = y_ref @ w.float().t() + b
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    kw = {}
+    if mode == "rowsum":
+        cols = ops.gemm_rowsum_cols(x, pwg, M=M, rowsum=True, wgroup=wgroup)
+        assert cols > 0
+        part = torch.empty(N // cols * M, 2, dtype=torch.float32, device=DEV)
+        kw["rowsum"] = part
+    elif mode == "ln":
+        lg, lb = rnd(N, dtype=torch.float32) * 0.2 + 1.0, rnd(N, dtype=torch.float32) * 0.2
+        assert ops.gemm_ln_ok(x, pwg, M=M, ln=(lg, lb, None, 1e-5), wgroup=wgroup)
+        lo = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        kw["ln"] = (lg, lb, lo, 1e-5)
+    ops.gemm(x, pwg, out, M=M, wgroup=wgroup, **kw)
+    check(out, ref, TOL16, "Linear(GroupNorm(x)) on per-group weights")
+    if mode == "rowsum":
+        ps, of = part.view(N // cols, M, 2).sum(0), out.float()
+        assert relerr(ps[:, 0], of.sum(1)) < 1e-4 and relerr(ps[:, 1], (of * of).sum(1)) < 1e-4
+    if mode == "ln":
+        check(lo, F.layer_norm(out.float(), (N,), lg, lb, 1e-5), TOL16, "LayerNorm store loop behind the folded GroupNorm")
+    # the two-launch path it replaces
+    y = torch.empty_like(x)
+    ops.groupnorm_gstat(x, y, gm, be, gst, F=Fr, HW=HW, Cn=C, frames_per_stat=fps, eps=eps, silu=False)
+    out2 = torch.empty_like(out)
+    ops.gemm(y, pw, out2, M=M)
+    assert relerr(out, out2) < 2e-3
+    e_fold, e_two = relerr(out, ref), relerr(out2, ref)
+    print(f"[parity] folded {e_fold:.2e} vs two launches {e_two:.2e}")
+    # refusals: a group that does not hold whole row tiles; the weight-stationary kernel never takes such a call
+    assert not ops.gemm_wgroup_ok(x, pwg, M=M, wgroup=(fps * HW - 160 + 32, pw.N * ldw))
+    # poison: group 1's statistics out of range -> its rows NaN, the others untouched
+    gst2 = gst.clone()
+    gst2.view(n_sg, 32, 2)[1, 3, 1] = 1 << 62
+    ops.groupnorm_fold_weights(pw, gm, be, gst2, wg, bg, n_sg=n_sg, count=fps * HW * (C // 32), eps=eps)
+    out3 = torch.empty_like(out)
+    ops.gemm(x, pwg, out3, M=M, wgroup=wgroup)
+    o3 = out3.view(n_sg, fps * HW, N)
+    assert torch.isnan(o3[1]).all() and torch.equal(o3[0], out.view(n_sg, fps * HW, N)[0]) and (n_sg < 3 or torch.equal(o3[2], out.view(n_sg, fps * HW, N)[2]))
+
+
 @pytest.mark.parametrize("splits", [1, 2])
 def test_gemm_geglu(splits):
     M, K, inner = 520, 320, 1280
