@@ -38,7 +38,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X dense fp16 MFMA (MI355X_MICROARCH.m
 # doubled per the gfx950 correction in MI355X_MICROARCH.md; Infinity-Cache hits are included in these counters).  The
 # figure is READ from the committed summary of the current kernels -- never a constant in this file -- and the JSON
 # names the file; it is null when no summary for this round exists.
-TRAFFIC_PROFILES = ("profiles/r05_pmc_traffic_per_forward.txt", "profiles/r04_pmc_traffic_per_forward.txt")
+TRAFFIC_PROFILES = ("profiles/r06_pmc_traffic_per_forward.txt", "profiles/r05_pmc_traffic_per_forward.txt")
 
 
 def traffic_from_profile():
