@@ -482,6 +482,60 @@ def test_fifo_engine_full_size_iteration_vs_oracle_step(full_dm):
         assert relerr(em[:, :, [i]], fr_h[i]) < 3e-2, f"emitted frame {i}"
 
 
+def test_fifo_engine_full_size_prompt_mode_vs_oracle_step(full_dm):
+    """The full-size iteration in PROMPT mode (what the `fifo_prompt_mode` / `video` bench legs time): no masks handed in, `ddim_step`
+    takes its segmentation branch (ddim.py:592-606 -> `_apply_segmentation` :739-903: t <= 300 only, previous-mask / IoU < 0.5 fallbacks,
+    > 80 % reset, factor 2) on scripted per-frame candidate masks, bookkeeping on the device inside the iteration graph: x_prev / pred_x0 of
+    the 8 windows against `oracle.sampler_oracle.ddim_step(sam_masks=...)` on the HIP eps, two iterations (the second one replays nothing
+    yet but moves the queue: other windows reach t <= 300)."""
+    import types
+    from helpers import loop_sam_candidates
+    from moca_video_amd.fifo import prepare_latents
+    from moca_video_amd.fifo_graph import FifoEngine, fifo_windows
+    from moca_video_amd.sampler import DDIMSampler
+    from oracle import sampler_oracle as SO
+    dm = full_dm
+    T, H, W, S = 16, 40, 64, 64
+    args = types.SimpleNamespace(num_inference_steps=S, video_length=T, lookahead_denoising=True, num_partitions=4, new_video_length=100)
+    s = DDIMSampler(dm)
+    s.make_schedule(S, ddim_eta=1.0, verbose=False)
+    Q = S + T // 2
+    fps = torch.tensor([10]).cuda()
+    c1, c2, ucx = (inp(f"full_it.{n}", (1, 77, 1024)).cuda() for n in ("c1", "c2", "uc"))
+    cond, uc = {"c_crossattn": [c1, c2], "fps": fps}, {"c_crossattn": [ucx], "fps": fps}
+    prep = [inp(f"full_it.prep{j}", (1, 4, 1, H, W)).cuda() for j in range(Q)]
+    lat0 = prepare_latents(args, None, s, initial_latents=inp("full_it.z", (1, 4, T, H, W)).cuda(), noises=prep)
+    cimg = (inp("full_it.cimg", (1, 4, 1, H, W)) * 0.25 + 0.5).clamp(0, 1)
+    eng = FifoEngine(args, dm, s, cond, uc, 12.0, lat0.clone(), conditioned_image=cimg.cuda(), n_slots=2, sam_capacity=2 * 8 * T)
+    wins = list(fifo_windows(args))
+    ts_all = np.concatenate([np.full((T // 2,), s.ddim_timesteps[0]), s.ddim_timesteps])
+    idx_all = np.concatenate([np.full((T // 2,), 0), np.arange(S)])
+    sch = SO.make_schedule(SO.ddpm_buffers(), S, 1.0)
+    mom = torch.zeros(1, 4, T, H, W)
+    injected = 0
+    for it in range(2):
+        noises = [inp(f"full_pm.n{it}.{w}", (1, 4, T, H, W)) for w in range(8)]
+        shift = inp(f"full_pm.sh{it}", (1, 4, H, W))
+        cands = [loop_sam_candidates(8 * it + w, T, H, W) for w in range(8)]
+        lat = eng.latents().cpu().clone()                       # the queue this iteration starts from
+        eng.step(noise=[n.cuda() for n in noises], shift_noise=shift.cuda(), sam_masks=cands)
+        eng.sync_to()
+        torch.cuda.synchronize()
+        eps = eng.plan.out.reshape(16, 4, T, H, W).float().cpu()
+        xp, p0 = eng.window_outputs()
+        for w, (s0, mid, e0) in enumerate(wins):
+            x = lat[:, :, s0:e0].clone()
+            e = eps[8 + w:9 + w] + 12.0 * (eps[w:w + 1] - eps[8 + w:9 + w])
+            t = torch.as_tensor(ts_all[s0:e0].copy()).long()
+            out, px0 = SO.ddim_step(sch, x, e, idx_all[s0:e0], cimg, t, [noises[w][:, :, [k]] for k in range(T)], mom, sam_masks=cands[w])
+            assert relerr(xp[w].cpu(), out) < 2e-5, f"iteration {it} window {w} x_prev"
+            assert relerr(p0[w].cpu(), px0) < 2e-5, f"iteration {it} window {w} pred_x0"
+            lat[:, :, mid:e0] = out[:, :, -(T // 2):]
+        injected += int((eng.sam_idx >= 0).sum())
+    assert injected > 0, "no window frame took the segmentation branch: the test would not see it"
+    eng.close()
+
+
 def test_reloading_weights_releases_the_old_graphs(reduced_model):
     """`load_state_dict` / `.to()` drop the recorded plans: their instantiated hipGraphs must be destroyed and the
     next forward must re-record and give the same result."""
