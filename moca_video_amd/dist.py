@@ -56,7 +56,8 @@ def broadcast_parameters(module, src=0, bucket_bytes=BUCKET_BYTES):
 def _walk_operands(v, pws, tensors):
     from .ops import PackedWeight
     if isinstance(v, PackedWeight):
-        pws.setdefault(id(v), v)
+        if not v.derived:              # (per-group weights of a folded GroupNorm are WRITTEN by a launch of the forward: not an operand to send)
+            pws.setdefault(id(v), v)
     elif torch.is_tensor(v):
         tensors.append(v)
     elif isinstance(v, (tuple, list)):

@@ -209,3 +209,26 @@ def test_bench_under_torchrun_env_does_not_relaunch():
     assert all(p.returncode == 0 for p in procs), [o[1][-1000:] for o in outs]
     assert json.loads(outs[0][0].strip().splitlines()[-1])["n_gpus"] == 2
     assert not any(l.lstrip().startswith("{") for l in outs[1][0].splitlines())      # only rank 0 prints the JSON line
+
+
+def test_packed_operands_skip_weights_written_by_the_forward():
+    """per-statistics-group weights of a folded GroupNorm (ops.groupnorm_fold_weights -> PackedWeight.derived) are OUTPUTS of a launch of
+    the forward: they must not enter the C1 broadcast set (uninitialised pool memory: NaN checksums on every rank -- caught by the
+    2-rank rehearsal of round 6), while the weights they are derived from must"""
+    import functools
+    from moca_video_amd import dist as mdist
+    from moca_video_amd.ops import PackedWeight
+    w, b = torch.zeros(64, 64, dtype=torch.float16), torch.zeros(64)
+    src = PackedWeight(w, b, 64, 64, 64)
+    der = PackedWeight(torch.full((128, 64), float("nan"), dtype=torch.float16), torch.full((128,), float("nan")), 64, 64, 64)
+    der.derived = True
+    gamma, beta = torch.ones(64), torch.zeros(64)
+
+    class Plan:
+        steps = [functools.partial(lambda *a, **k: None, src, gamma, beta, der.w, der.bias, n_sg=2),
+                 functools.partial(lambda *a, **k: None, torch.zeros(4, 64), der, wgroup=(2, 4096))]
+    ops_ = mdist.packed_operands({1: (gamma, beta)}, [Plan])
+    ptrs = {t.data_ptr() for t in ops_}
+    assert w.data_ptr() in ptrs and b.data_ptr() in ptrs and gamma.data_ptr() in ptrs and beta.data_ptr() in ptrs
+    assert der.w.data_ptr() not in ptrs and der.bias.data_ptr() not in ptrs
+    assert all(torch.isfinite(t.float()).all() for t in ops_)
