@@ -3613,6 +3613,7 @@ static int colsum_rows(const moca_gemm_params& pp) {
     moca_gemm_params p = pp;
     if (!(p.flags & (MOCA_EP_COLSUM | MOCA_EP_GSTAT))) p.flags |= MOCA_EP_COLSUM;      // (the question is about the call WITH column sums)
     if (p.splits != 1) return 0;
+    if ((p.flags & MOCA_EP_GSTAT) && takes_ws(p)) return 32;      // the weight-stationary kernel: finished statistics only, strips of 32 rows
     if (takes_w80s(p)) return w80s_wide(p) ? 160 : 320;
     if (!(p.flags & (MOCA_EP_GEGLU | MOCA_EP_OUT_F32)) && takes_glds_bn(p) != 0) return 256;
     return 0;
@@ -3683,6 +3684,7 @@ extern "C" int moca_gemm_cat_ok(const moca_gemm_params* pp) {
 // 160 x 320 tiling, 320 on 320 x 160) lie inside one group; bias / residual / row sums / LayerNorm store loop / column statistics
 static bool wgroup_ok(const moca_gemm_params& p) {
     if (p.wgroup_rows <= 0 || p.wgroup_stride < p.N * p.ldw || p.a_mode != MOCA_A_LINEAR || p.a2 || p.splits != 1) return false;
+    if (takes_ws(p)) return true;                     // the weight-stationary kernel deals its strips by weight group
     if (p.flags & ~(MOCA_EP_COLSUM | MOCA_EP_GSTAT | MOCA_EP_ROWSUM | MOCA_EP_LN)) return false;
     if (!takes_w80s(p) || p.M % p.wgroup_rows) return false;
     const int tm = w80s_wide(p) ? 160 : 320;

@@ -167,6 +167,21 @@ def test_gemm_groupnorm_folded_into_per_group_weights(Fr, HW, C, fps, mode):
         kw["ln"] = (lg, lb, lo, 1e-5)
     ops.gemm(x, pwg, out, M=M, wgroup=wgroup, **kw)
     check(out, ref, TOL16, "Linear(GroupNorm(x)) on per-group weights")
+    if C == 320 and mode != "ln":                      # the weight-stationary kernel deals its strips by weight group: same call, knob 2
+        old = L.set_tuning(L.MOCA_TUNE_GEMM_WS, 2)
+        try:
+            assert ops.gemm_wgroup_ok(x, pwg, M=M, wgroup=wgroup)
+            kw2 = dict(kw)
+            if mode == "rowsum":
+                cols2 = ops.gemm_rowsum_cols(x, pwg, M=M, rowsum=True, wgroup=wgroup)
+                assert cols2 == 80
+                kw2["rowsum"] = torch.empty(N // cols2 * M, 2, dtype=torch.float32, device=DEV)
+            outw = torch.empty_like(out)
+            ops.gemm(x, pwg, outw, M=M, wgroup=wgroup, **kw2)
+            check(outw, ref, TOL16, "Linear(GroupNorm(x)) on per-group weights, weight-stationary kernel")
+            assert relerr(outw, out) < 1e-3
+        finally:
+            L.set_tuning(L.MOCA_TUNE_GEMM_WS, old)
     if mode == "rowsum":
         ps, of = part.view(N // cols, M, 2).sum(0), out.float()
         assert relerr(ps[:, 0], of.sum(1)) < 1e-4 and relerr(ps[:, 1], (of * of).sum(1)) < 1e-4
@@ -190,6 +205,53 @@ def test_gemm_groupnorm_folded_into_per_group_weights(Fr, HW, C, fps, mode):
     ops.gemm(x, pwg, out3, M=M, wgroup=wgroup)
     o3 = out3.view(n_sg, fps * HW, N)
     assert torch.isnan(o3[1]).all() and torch.equal(o3[0], out.view(n_sg, fps * HW, N)[0]) and (n_sg < 3 or torch.equal(o3[2], out.view(n_sg, fps * HW, N)[2]))
+
+
+@pytest.mark.parametrize("Fr,HW,fps,res,cpg,coff", [(32, 2560, 1, True, 0, 0), (32, 2560, 16, True, 0, 0), (16, 1280, 1, False, 0, 0),
+                                                     (32, 2560, 1, True, 20, 320), (32, 2560, 1, True, 30, 0), (256, 2560, 1, True, 0, 0)])
+def test_gemm_weight_stationary_320_groupnorm_statistics(Fr, HW, fps, res, cpg, coff):
+    """MOCA_EP_GSTAT on the weight-stationary kernel (proj_out + the GroupNorm that follows, openaimodel3d.py:149; also as ONE SOURCE of a
+    virtual concat: gstat_cpg / gstat_coff).  The kernel deals its strips BY STATISTICS GROUP (several blocks per group, or whole groups per
+    block: 256 frames on 256 CUs), keeps the column sums in registers over a group's strips and flushes them once: the finished
+    fixed-point statistics against fp32 sums of what the launch stored (before the fp16 rounding, as the tiled kernels count them), the
+    GroupNorm fed by them against torch, and the tiled kernel's accumulators."""
+    M, K, N = Fr * HW, 320, 320
+    a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N, dtype=torch.float32)
+    pw = ops.pack_linear(w, b)
+    r = rnd(M, N) if res else None
+    ref = a.float() @ w.float().t() + b + (r.float() if res else 0.0)
+    n_sg = Fr // fps
+    accs, outs = [], []
+    for knob in (2, 0):
+        old = L.set_tuning(L.MOCA_TUNE_GEMM_WS, knob)
+        try:
+            gst = torch.zeros(n_sg * 64, dtype=torch.int64, device=DEV)
+            out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+            g = (gst, fps * HW) if cpg == 0 else (gst, fps * HW, cpg, coff)
+            ops.gemm(a, pw, out, M=M, residual=r, gstat=g)
+            check(out, ref, TOL16, f"ws={knob} linear +gstat")
+            accs.append(gst.clone()); outs.append(out.clone())
+        finally:
+            L.set_tuning(L.MOCA_TUNE_GEMM_WS, old)
+    assert relerr(outs[0], outs[1]) < 1e-3
+    sc = torch.tensor([2.0 ** -20, 2.0 ** -12], dtype=torch.float64, device=DEV)
+    got = accs[0].view(n_sg, 32, 2).double() * sc
+    cw = cpg if cpg else N // 32
+    groups = (coff + torch.arange(N, device=DEV)) // cw                       # consumer channel group of every column
+    xg = ref.view(n_sg, fps * HW, N).double()
+    want = torch.zeros(n_sg, 32, 2, dtype=torch.float64, device=DEV)
+    want[:, :, 0].index_add_(1, groups, xg.sum(1))
+    want[:, :, 1].index_add_(1, groups, (xg * xg).sum(1))
+    assert relerr(got[..., 0], want[..., 0]) < 1e-3 and relerr(got[..., 1], want[..., 1]) < 1e-3, "fixed-point statistics vs fp32 sums"
+    tiled = accs[1].view(n_sg, 32, 2).double() * sc
+    assert relerr(got, tiled) < 1e-4, "weight-stationary vs tiled accumulators"
+    if cpg == 0:                                                              # the GroupNorm that consumes them
+        gm, be = rnd(N, dtype=torch.float32) * 0.2 + 1.0, rnd(N, dtype=torch.float32) * 0.2
+        y = torch.empty_like(outs[0])
+        ops.groupnorm_gstat(outs[0], y, gm, be, accs[0], F=Fr, HW=HW, Cn=N, frames_per_stat=fps, eps=1e-5, silu=True)
+        xr = outs[0].float().view(n_sg, fps * HW, N).permute(0, 2, 1)
+        gref = F.silu(F.group_norm(xr, 32, gm, be, 1e-5)).permute(0, 2, 1).reshape(M, N)
+        check(y, gref, TOL16, "GroupNorm from the weight-stationary kernel's statistics")
 
 
 @pytest.mark.parametrize("splits", [1, 2])

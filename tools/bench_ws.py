@@ -15,7 +15,7 @@ from moca_video_amd import ops
 DEV = "cuda"
 
 
-def bench(M, res, rows, cold, knob, iters=30):
+def bench(M, res, rows, cold, knob, iters=30, gstat=False):
     old = L.set_tuning(L.MOCA_TUNE_GEMM_WS, knob)
     try:
         nset = max(1, int(1.5 * (256 << 20) / (M * 640 * (3 if res else 2)))) + 1 if cold else 1
@@ -27,7 +27,8 @@ def bench(M, res, rows, cold, knob, iters=30):
         outs = [torch.empty(M, 320, device=DEV, dtype=torch.float16) for _ in range(nset)]
         cols = ops.gemm_rowsum_cols(xs[0], pw, M=M, residual=rs[0], rowsum=True) if rows else 0
         part = torch.empty(320 // cols * M, 2, device=DEV, dtype=torch.float32) if rows else None
-        fn = lambda i: ops.gemm(xs[i % nset], pw, outs[i % nset], M=M, residual=rs[i % nset], rowsum=part)
+        gst = torch.zeros(M // 2560 * 64, dtype=torch.int64, device=DEV) if gstat else None          # per-frame statistics, 2560 pixels per frame
+        fn = lambda i: ops.gemm(xs[i % nset], pw, outs[i % nset], M=M, residual=rs[i % nset], rowsum=part, gstat=(gst, 2560) if gstat else None)
         for i in range(2 * nset + 2):
             fn(i)
         torch.cuda.synchronize()
@@ -48,12 +49,12 @@ if __name__ == "__main__":
     rounds = int(os.environ.get("ROUNDS", "2"))
     print(f"{'launch':44s} {'tiled us':>9s} {'GB/s':>6s} {'ws us':>9s} {'GB/s':>6s}  ws/tiled")
     for M in (81920, 655360):
-        for res, rows in ((False, False), (False, True), (True, False), (True, True)):
+        for res, rows in ((False, False), (False, True), (True, False), (True, True), (True, "gstat")):
             for cold in (False, True):
                 t = {0: [], 2: []}
                 for _ in range(rounds):
                     for knob in (0, 2):
-                        t[knob].append(bench(M, res, rows, cold, knob))
+                        t[knob].append(bench(M, res, rows is True, cold, knob, gstat=rows == "gstat"))
                 a, b = ((min(x[0] for x in tt), max(x[1] for x in tt)) for tt in (t[0], t[2]))
-                name = f"lin M={M} 320x320{' +res' if res else ''}{' +rowsum' if rows else ''} {'COLD' if cold else 'hot'}"
+                name = f"lin M={M} 320x320{' +res' if res else ''}{' +gstat' if rows == 'gstat' else (' +rowsum' if rows else '')} {'COLD' if cold else 'hot'}"
                 print(f"{name:44s} {a[0]:9.1f} {a[1]:6.0f} {b[0]:9.1f} {b[1]:6.0f}  {b[0] / a[0]:.3f}", flush=True)

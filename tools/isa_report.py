@@ -115,10 +115,12 @@ def loop_stats(ins, lo, hi):
 
 
 def main_loop(ins):
-    """the steady-state loop: among the loops that hold MFMAs -- those that also issue LDS-DMA, if any -- the one with the most
-    MFMAs, shortest body first (an enclosing tile loop repeats the inner loop's counts in a longer body)"""
-    cands = [loop_stats(ins, lo, hi) for lo, hi in loops(ins)]
-    cands = [c for c in cands if c["mfma"] > 0]
+    """the steady-state loop: among the INNERMOST loops that hold MFMAs (a loop that encloses another MFMA loop -- a tile / group walk --
+    is not one) -- those that also issue LDS-DMA, if any -- the one with the most MFMAs, shortest body first"""
+    spans = [(lo, hi, loop_stats(ins, lo, hi)) for lo, hi in loops(ins)]
+    spans = [sp for sp in spans if sp[2]["mfma"] > 0]
+    inner = [sp for sp in spans if not any((o[0] >= sp[0] and o[1] <= sp[1] and (o[0], o[1]) != (sp[0], sp[1])) for o in spans)]
+    cands = [sp[2] for sp in inner]
     if any(c["lds_dma"] for c in cands):
         cands = [c for c in cands if c["lds_dma"]]
     if not cands:
