@@ -387,12 +387,13 @@ def test_unet_full_width_b16_vs_reference_golden(full_dm):
     for r in range(16):
         name = f"{wins[r % 8]}_{154 if r < 8 else 77}"
         check(y2[r:r + 1].cpu(), torch.from_numpy(g[name]), TOL_UNET, f"b16 plain row {r} ({name})")
-    # batch consistency: row i of the B = 16 launch == the B = 1 launch of the same window (other tilings / split-K: tolerance),
-    # and rows that hold the same window agree with each other to the bit where the tile walk is per video
+    # batch consistency: row i of the B = 16 launch == the B = 1 launch of the same window (other tilings / split-K: tolerance)
     for r, L, ctx in ((0, 154, c154), (1, 154, c154), (9, 77, c77)):
         s = m(x[r % 8:r % 8 + 1], t[(r % 8) * 16:(r % 8) * 16 + 16], context=ctx, fps=fps)
         assert relerr(y[r:r + 1].cpu(), s.cpu()) < TOL_UNET, f"batch consistency row {r}"
-    assert relerr(y[1].cpu(), y[2].cpu()) < 1e-3 and relerr(y[8].cpu(), y[11].cpu()) < 1e-3      # same window in other rows
+    # the same window in other rows: equal to the fp16 noise level, not to the bit -- the weight-stationary kernel sums a statistics
+    # group's column sums in a per-group (rotated) strip order, so two rows' GroupNorm statistics differ in the last fp32 bit
+    assert relerr(y[1].cpu(), y[2].cpu()) < TOL_UNET and relerr(y[8].cpu(), y[11].cpu()) < TOL_UNET
 
 
 def test_fifo_engine_full_size_iteration_vs_oracle_step(full_dm):
